@@ -1,0 +1,244 @@
+"""ctypes binding of the product C ABI (include/hpmvs_amd.h -> hpmvs_amd/libhpmvs_amd.so).
+
+Plumbing only: it loads the in-tree shared library (built by `__graft_entry__.build()` /
+`make -C hpmvs_amd/csrc`), marshals numpy arrays or raw device pointers, and raises on any
+non-zero status.  There is no Python or CPU implementation of the hot path behind it: if the
+library or a GPU is missing the calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+try:  # torch first: it must be the one to load libamdhip64 ("one HIP runtime")
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is optional plumbing
+    torch = None
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhpmvs_amd.so")
+MAX_IMAGES = 64
+MAX_LEVELS = 8
+
+
+class HpmvsError(RuntimeError):
+    pass
+
+
+class Options(C.Structure):
+    _fields_ = [("MAXLEVEL", C.c_int32), ("MINLEVEL", C.c_int32), ("MAX_ANGLE", C.c_float),
+                ("MIN_ANGLE", C.c_float), ("MAX_IMAGES_PER_PATCH", C.c_int32),
+                ("MIN_IMAGES_PER_PATCH", C.c_int32), ("NCC_ALPHA_1", C.c_float), ("NCC_ALPHA_2", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("P0", C.c_float * 12), ("center", C.c_float * 4), ("xaxis", C.c_float * 3),
+                ("yaxis", C.c_float * 3), ("zaxis", C.c_float * 3), ("fsum", C.c_float), ("n_levels", C.c_int32)]
+
+
+class PatchBatch(C.Structure):
+    _fields_ = [("n", C.c_int32), ("max_images", C.c_int32), ("center", C.c_void_p), ("normal", C.c_void_p),
+                ("scale", C.c_void_p), ("n_images", C.c_void_p), ("images", C.c_void_p), ("ok", C.c_void_p),
+                ("color", C.c_void_p), ("ncc", C.c_void_p), ("fmin", C.c_void_p), ("x", C.c_void_p),
+                ("result", C.c_void_p), ("nevals", C.c_void_p), ("stage", C.c_void_p), ("ngrabs", C.c_void_p)]
+
+
+EXPORTS = [
+    "hpmvs_last_error", "hpmvs_device_count", "hpmvs_default_options", "hpmvs_camera_from_nvm",
+    "hpmvs_scene_create", "hpmvs_scene_set_view", "hpmvs_scene_set_covis", "hpmvs_scene_commit",
+    "hpmvs_scene_destroy", "hpmvs_scene_get_level", "hpmvs_scene_bytes", "hpmvs_build_pyramid",
+    "hpmvs_optimize_batch", "hpmvs_objective_batch", "hpmvs_inccs_batch", "hpmvs_last_kernel_ms",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HpmvsError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(there is no fallback implementation)")
+    L = C.CDLL(LIB_PATH)
+    L.hpmvs_last_error.restype = C.c_char_p
+    L.hpmvs_default_options.argtypes = [C.POINTER(Options)]
+    L.hpmvs_camera_from_nvm.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int,
+                                        C.c_int, C.POINTER(Camera)]
+    L.hpmvs_scene_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.hpmvs_scene_set_view.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(Camera)]
+    L.hpmvs_scene_set_covis.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int]
+    L.hpmvs_scene_commit.argtypes = [C.c_void_p]
+    L.hpmvs_scene_destroy.argtypes = [C.c_void_p]
+    L.hpmvs_scene_get_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int)]
+    L.hpmvs_scene_bytes.restype = C.c_size_t
+    L.hpmvs_scene_bytes.argtypes = [C.c_void_p]
+    L.hpmvs_build_pyramid.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.hpmvs_optimize_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(PatchBatch), C.c_int, C.c_void_p]
+    L.hpmvs_objective_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(PatchBatch), C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.hpmvs_inccs_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(PatchBatch), C.c_int, C.c_int,
+                                    C.c_void_p, C.c_int, C.c_void_p]
+    L.hpmvs_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != 0:
+        raise HpmvsError(f"hpmvs_amd error {rc}: {lib().hpmvs_last_error().decode()}")
+
+
+def device_count() -> int:
+    return lib().hpmvs_device_count()
+
+
+def default_options() -> Options:
+    o = Options()
+    lib().hpmvs_default_options(C.byref(o))
+    return o
+
+
+def camera_from_nvm(f, q, c, width, height, max_level=5) -> Camera:
+    cam = Camera()
+    qq = (C.c_double * 4)(*[float(t) for t in q])
+    cc = (C.c_double * 3)(*[float(t) for t in c])
+    _chk(lib().hpmvs_camera_from_nvm(float(f), qq, cc, int(width), int(height), int(max_level), C.byref(cam)))
+    return cam
+
+
+def _ptr(a):
+    """numpy array / torch tensor / int -> raw address (or None)."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    if isinstance(a, int):
+        return a
+    return a.data_ptr()  # torch tensor
+
+
+class Scene:
+    """HBM-resident scene: Scene::addCameras + extractCoVisiblilty state the path reads
+    (reference include/hpmvs/Scene.h:69-71)."""
+
+    def __init__(self, synth_scene, device: int = 0):
+        L = lib()
+        self.h = C.c_void_p()
+        self.device = device
+        self.n_views = synth_scene.n_views
+        _chk(L.hpmvs_scene_create(self.n_views, device, C.byref(self.h)))
+        for i, v in enumerate(synth_scene.views):
+            cam = camera_from_nvm(v.f, v.q, v.c, v.width, v.height, synth_scene.max_level)
+            rgb = v.rgb
+            if isinstance(rgb, np.ndarray):
+                rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+                _chk(L.hpmvs_scene_set_view(self.h, i, v.width, v.height, rgb.ctypes.data, 0, C.byref(cam)))
+            else:  # torch tensor already in HBM
+                rgb = rgb.contiguous()
+                _chk(L.hpmvs_scene_set_view(self.h, i, v.width, v.height, rgb.data_ptr(), 1, C.byref(cam)))
+        for i, lst in enumerate(synth_scene.covis):
+            arr = (C.c_int32 * max(1, len(lst)))(*lst)
+            _chk(L.hpmvs_scene_set_covis(self.h, i, arr, len(lst)))
+        _chk(L.hpmvs_scene_commit(self.h))
+
+    def close(self):
+        if self.h:
+            lib().hpmvs_scene_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bytes(self) -> int:
+        return lib().hpmvs_scene_bytes(self.h)
+
+    def level(self, view: int, level: int) -> np.ndarray:
+        w, h = C.c_int(), C.c_int()
+        _chk(lib().hpmvs_scene_get_level(self.h, view, level, None, 0, C.byref(w), C.byref(h)))
+        out = np.empty((h.value, w.value, 3), dtype=np.uint8)
+        _chk(lib().hpmvs_scene_get_level(self.h, view, level, out.ctypes.data, out.nbytes, C.byref(w), C.byref(h)))
+        return out
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _chk(lib().hpmvs_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+
+class Batch:
+    """Host-side (numpy) structure-of-arrays Patch3d batch."""
+
+    def __init__(self, center, normal, scale, n_images, images):
+        self.n = int(len(scale))
+        self.max_images = int(images.shape[1])
+        self.center = np.ascontiguousarray(center, dtype=np.float32).copy()
+        self.normal = np.ascontiguousarray(normal, dtype=np.float32).copy()
+        self.scale = np.ascontiguousarray(scale, dtype=np.float32).copy()
+        self.n_images = np.ascontiguousarray(n_images, dtype=np.int32).copy()
+        self.images = np.ascontiguousarray(images, dtype=np.int32).copy()
+        n = self.n
+        self.ok = np.zeros(n, dtype=np.uint8)
+        self.color = np.zeros((n, 3), dtype=np.float32)
+        self.ncc = np.zeros(n, dtype=np.float32)
+        self.fmin = np.zeros(n, dtype=np.float64)
+        self.x = np.zeros((n, 3), dtype=np.float64)
+        self.result = np.zeros(n, dtype=np.int32)
+        self.nevals = np.zeros(n, dtype=np.int32)
+        self.stage = np.zeros(n, dtype=np.int32)
+        self.ngrabs = np.zeros(n, dtype=np.int32)
+
+    @classmethod
+    def from_seeds(cls, seeds, idx=None):
+        if idx is None:
+            idx = np.arange(len(seeds.scale))
+        idx = np.asarray(idx)
+        return cls(seeds.center[idx], seeds.normal[idx], seeds.scale[idx], seeds.n_images[idx], seeds.images[idx])
+
+    def c_struct(self) -> PatchBatch:
+        b = PatchBatch()
+        b.n, b.max_images = self.n, self.max_images
+        for name in ("center", "normal", "scale", "n_images", "images", "ok", "color", "ncc", "fmin", "x", "result",
+                     "nevals", "stage", "ngrabs"):
+            setattr(b, name, _ptr(getattr(self, name)))
+        return b
+
+
+def optimize_batch(scene: Scene, batch: Batch, options: Options | None = None) -> Batch:
+    o = options or default_options()
+    b = batch.c_struct()
+    _chk(lib().hpmvs_optimize_batch(scene.h, C.byref(o), C.byref(b), 0, None))
+    return batch
+
+
+def objective_batch(scene: Scene, batch: Batch, x: np.ndarray, options: Options | None = None):
+    o = options or default_options()
+    b = batch.c_struct()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    f = np.zeros(batch.n, dtype=np.float64)
+    g = np.zeros(batch.n, dtype=np.int32)
+    _chk(lib().hpmvs_objective_batch(scene.h, C.byref(o), C.byref(b), x.ctypes.data, f.ctypes.data, g.ctypes.data, 0,
+                                     None))
+    return f, g
+
+
+def inccs_batch(scene: Scene, batch: Batch, ref_idx=0, robust=0, options: Options | None = None) -> np.ndarray:
+    o = options or default_options()
+    b = batch.c_struct()
+    out = np.zeros((batch.n, batch.max_images), dtype=np.float32)
+    _chk(lib().hpmvs_inccs_batch(scene.h, C.byref(o), C.byref(b), ref_idx, robust, out.ctypes.data, 0, None))
+    return out
+
+
+def build_pyramid(img: np.ndarray, device: int = 0) -> np.ndarray:
+    h, w, _ = img.shape
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.zeros((h // 2, w // 2, 3), dtype=np.uint8)
+    _chk(lib().hpmvs_build_pyramid(device, img.ctypes.data, w, h, out.ctypes.data, 0))
+    return out

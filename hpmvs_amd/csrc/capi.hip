@@ -1,0 +1,479 @@
+// capi.hip -- the C ABI of include/hpmvs_amd.h: scene residency in HBM + batch launches.
+// Host-side only; all arithmetic of the hot path is in the kernels.  There is no CPU fallback:
+// without a HIP device every compute entry point fails with HPMVS_ERR_NODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/hpmvs_amd.h"
+#include "dev_types.h"
+#include "launch.h"
+
+using namespace hpmvs;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return fail(HPMVS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+    } while (0)
+
+struct hpmvs_scene {
+    int device = 0;
+    int n_views = 0;
+    int n_cus = 256;
+    bool committed = false;
+    std::vector<DevView> hviews;
+    std::vector<char> view_set;
+    std::vector<std::vector<int32_t>> covis;
+    std::vector<void*> allocs;
+    DevView* dviews = nullptr;
+    int32_t* dcovis_off = nullptr;
+    int32_t* dcovis = nullptr;
+    int32_t* dqueue = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    mutable std::mutex mu;
+    mutable bool timed = false;
+};
+
+extern "C" {
+
+const char* hpmvs_last_error(void) { return g_err.c_str(); }
+
+int hpmvs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void hpmvs_default_options(hpmvs_options* o) {
+    // reference include/hpmvs/HpmvsOptions.h:29-58
+    o->MAXLEVEL = 5;
+    o->MINLEVEL = 0;
+    o->MAX_ANGLE = (float)(60.0f * M_PI / 180.0f);
+    o->MIN_ANGLE = (float)(10.0f * M_PI / 180.0f);
+    o->MAX_IMAGES_PER_PATCH = 6;
+    o->MIN_IMAGES_PER_PATCH = 3;
+    o->NCC_ALPHA_1 = 0.4f;
+    o->NCC_ALPHA_2 = 0.5f;
+}
+
+static DevOptions make_dev_options(const hpmvs_options* o) {
+    DevOptions d;
+    d.MAXLEVEL = o->MAXLEVEL; d.MINLEVEL = o->MINLEVEL;
+    d.MAX_ANGLE = o->MAX_ANGLE; d.MIN_ANGLE = o->MIN_ANGLE;
+    d.MAX_IMAGES_PER_PATCH = o->MAX_IMAGES_PER_PATCH; d.MIN_IMAGES_PER_PATCH = o->MIN_IMAGES_PER_PATCH;
+    d.NCC_ALPHA_1 = o->NCC_ALPHA_1; d.NCC_ALPHA_2 = o->NCC_ALPHA_2;
+    d.cos_max_d = cos((double)o->MAX_ANGLE);
+    d.cos_max_f = std::cos(o->MAX_ANGLE);
+    d.sort_thr = (float)(1.0f - cos(10.0 * M_PI / 180.0));
+    d.angle_scale = (float)(M_PI / 48.0f);
+    return d;
+}
+
+// Camera::init, reference src/hpmvs/Camera.cpp:34-81 (float32 after the float64 quaternion)
+int hpmvs_camera_from_nvm(double f, const double q[4], const double c[3], int width, int height, int max_level,
+                          hpmvs_camera* out) {
+    if (!q || !c || !out || width < 1 || height < 1 || max_level < 0 || max_level + 1 > HPMVS_MAX_LEVELS)
+        return fail(HPMVS_ERR_ARG, "camera_from_nvm: bad argument");
+    const float K[9] = {(float)f, 0.f, (float)(width / 2.0), 0.f, (float)f, (float)(height / 2.0), 0.f, 0.f, 1.f};
+    // Eigen::Quaterniond::matrix() in double (Camera.cpp:43-50), no normalisation
+    const double tx = 2.0 * q[1], ty = 2.0 * q[2], tz = 2.0 * q[3];
+    const double twx = tx * q[0], twy = ty * q[0], twz = tz * q[0];
+    const double txx = tx * q[1], txy = ty * q[1], txz = tz * q[1];
+    const double tyy = ty * q[2], tyz = tz * q[2], tzz = tz * q[3];
+    const float R[9] = {(float)(1.0 - (tyy + tzz)), (float)(txy - twz), (float)(txz + twy),
+                        (float)(txy + twz), (float)(1.0 - (txx + tzz)), (float)(tyz - twx),
+                        (float)(txz - twy), (float)(tyz + twx), (float)(1.0 - (txx + tyy))};
+    const float cf[3] = {(float)c[0], (float)c[1], (float)c[2]};
+    float Rt[12];
+    for (int r = 0; r < 3; r++) {
+        Rt[r * 4 + 0] = R[r * 3 + 0]; Rt[r * 4 + 1] = R[r * 3 + 1]; Rt[r * 4 + 2] = R[r * 3 + 2];
+        Rt[r * 4 + 3] = -((R[r * 3 + 0] * cf[0] + R[r * 3 + 1] * cf[1]) + R[r * 3 + 2] * cf[2]);
+    }
+    for (int r = 0; r < 3; r++)
+        for (int col = 0; col < 4; col++)
+            out->P0[r * 4 + col] =
+                (K[r * 3 + 0] * Rt[0 * 4 + col] + K[r * 3 + 1] * Rt[1 * 4 + col]) + K[r * 3 + 2] * Rt[2 * 4 + col];
+    out->center[0] = cf[0]; out->center[1] = cf[1]; out->center[2] = cf[2]; out->center[3] = 1.0f;
+    const float* r2 = &out->P0[8];
+    const float nrm = std::sqrt((r2[0] * r2[0] + r2[1] * r2[1]) + r2[2] * r2[2]);
+    float z[3] = {r2[0] / nrm, r2[1] / nrm, r2[2] / nrm};
+    float x[3] = {out->P0[0], out->P0[1], out->P0[2]};
+    auto cross = [](const float* a, const float* b, float* o) {
+        const float o0 = a[1] * b[2] - a[2] * b[1], o1 = a[2] * b[0] - a[0] * b[2], o2 = a[0] * b[1] - a[1] * b[0];
+        o[0] = o0; o[1] = o1; o[2] = o2;
+    };
+    auto normalize = [](float* a) {
+        const float n2 = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+        if (n2 > 0.f) { const float n = std::sqrt(n2); a[0] /= n; a[1] /= n; a[2] /= n; }
+    };
+    float y[3];
+    cross(z, x, y); normalize(y);
+    cross(y, z, x); normalize(x);
+    for (int k = 0; k < 3; k++) { out->xaxis[k] = x[k]; out->yaxis[k] = y[k]; out->zaxis[k] = z[k]; }
+    out->fsum = K[0] + K[4];
+    out->n_levels = max_level + 1;
+    return HPMVS_OK;
+}
+
+int hpmvs_scene_create(int n_views, int device, hpmvs_scene** out) {
+    if (!out || n_views <= 0 || n_views > 65535) return fail(HPMVS_ERR_ARG, "scene_create: bad n_views/out");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(HPMVS_ERR_NODEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(HPMVS_ERR_ARG, "scene_create: bad device index");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    hpmvs_scene* s = new hpmvs_scene();
+    s->device = device;
+    s->n_views = n_views;
+    s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    s->hviews.resize(n_views);
+    memset(s->hviews.data(), 0, sizeof(DevView) * (size_t)n_views);
+    s->view_set.assign(n_views, 0);
+    s->covis.resize(n_views);
+    HIPCHK(hipEventCreate(&s->ev0));
+    HIPCHK(hipEventCreate(&s->ev1));
+    *out = s;
+    return HPMVS_OK;
+}
+
+int hpmvs_scene_set_view(hpmvs_scene* s, int view, int width, int height, const uint8_t* rgb_l0, int rgb_on_device,
+                         const hpmvs_camera* cam) {
+    if (!s || !cam || !rgb_l0) return fail(HPMVS_ERR_ARG, "scene_set_view: null argument");
+    if (s->committed) return fail(HPMVS_ERR_STATE, "scene_set_view: scene already committed");
+    if (view < 0 || view >= s->n_views || width < 2 || height < 2) return fail(HPMVS_ERR_ARG, "scene_set_view: bad view/size");
+    if (cam->n_levels < 1 || cam->n_levels > HPMVS_MAX_LEVELS) return fail(HPMVS_ERR_ARG, "scene_set_view: bad n_levels");
+    HIPCHK(hipSetDevice(s->device));
+    DevView& V = s->hviews[view];
+    // Image::init/load: max(1, MAXLEVEL) + 1 pyramid levels (reference Image.cpp:33-57); the camera has
+    // MAXLEVEL + 1 projection levels (Camera.cpp:36).  Both are MAXLEVEL + 1 for MAXLEVEL >= 1.
+    const int levels = cam->n_levels < 2 ? 2 : cam->n_levels;
+    int w = width, h = height;
+    for (int l = 0; l < levels; l++) {
+        if (w < 1 || h < 1) return fail(HPMVS_ERR_ARG, "scene_set_view: image too small for the pyramid depth");
+        uint8_t* d = nullptr;
+        const size_t nb = (size_t)w * h * 3;
+        HIPCHK(hipMalloc((void**)&d, nb + 16));
+        HIPCHK(hipMemset(d + nb, 0, 16));
+        s->allocs.push_back(d);
+        s->bytes += nb + 16;
+        if (l == 0) {
+            HIPCHK(hipMemcpy(d, rgb_l0, nb, rgb_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        } else {
+            launch_half_resize(V.pix[l - 1], V.w[l - 1], V.h[l - 1], d, nullptr);
+            HIPCHK(hipGetLastError());
+        }
+        V.pix[l] = d; V.w[l] = w; V.h[l] = h;
+        w /= 2; h /= 2;
+    }
+    HIPCHK(hipDeviceSynchronize());
+    memcpy(V.P0, cam->P0, sizeof(float) * 12);
+    memcpy(V.center, cam->center, sizeof(float) * 4);
+    for (int k = 0; k < 3; k++) { V.xaxis[k] = cam->xaxis[k]; V.yaxis[k] = cam->yaxis[k]; V.zaxis[k] = cam->zaxis[k]; }
+    V.xaxis[3] = V.yaxis[3] = V.zaxis[3] = 0.0f;
+    V.fsum = cam->fsum;
+    V.n_levels = levels;
+    s->view_set[view] = 1;
+    return HPMVS_OK;
+}
+
+int hpmvs_scene_set_covis(hpmvs_scene* s, int view, const int32_t* ids, int n) {
+    if (!s || (n > 0 && !ids)) return fail(HPMVS_ERR_ARG, "scene_set_covis: null argument");
+    if (s->committed) return fail(HPMVS_ERR_STATE, "scene_set_covis: scene already committed");
+    if (view < 0 || view >= s->n_views || n < 0) return fail(HPMVS_ERR_ARG, "scene_set_covis: bad view");
+    for (int k = 0; k < n; k++)
+        if (ids[k] < 0 || ids[k] >= s->n_views) return fail(HPMVS_ERR_ARG, "scene_set_covis: id out of range");
+    s->covis[view].assign(ids, ids + n);
+    return HPMVS_OK;
+}
+
+int hpmvs_scene_commit(hpmvs_scene* s) {
+    if (!s) return fail(HPMVS_ERR_ARG, "scene_commit: null scene");
+    if (s->committed) return fail(HPMVS_ERR_STATE, "scene_commit: already committed");
+    for (int v = 0; v < s->n_views; v++)
+        if (!s->view_set[v]) return fail(HPMVS_ERR_STATE, "scene_commit: view " + std::to_string(v) + " not set");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMalloc((void**)&s->dviews, sizeof(DevView) * (size_t)s->n_views));
+    HIPCHK(hipMemcpy(s->dviews, s->hviews.data(), sizeof(DevView) * (size_t)s->n_views, hipMemcpyHostToDevice));
+    std::vector<int32_t> off(s->n_views + 1, 0), flat;
+    for (int v = 0; v < s->n_views; v++) {
+        off[v + 1] = off[v] + (int32_t)s->covis[v].size();
+        flat.insert(flat.end(), s->covis[v].begin(), s->covis[v].end());
+    }
+    if (flat.empty()) flat.push_back(0);
+    HIPCHK(hipMalloc((void**)&s->dcovis_off, sizeof(int32_t) * off.size()));
+    HIPCHK(hipMemcpy(s->dcovis_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&s->dcovis, sizeof(int32_t) * flat.size()));
+    HIPCHK(hipMemcpy(s->dcovis, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&s->dqueue, 256));
+    HIPCHK(hipMemset(s->dqueue, 0, 256));
+    s->bytes += sizeof(DevView) * (size_t)s->n_views + sizeof(int32_t) * (off.size() + flat.size());
+    s->committed = true;
+    return HPMVS_OK;
+}
+
+int hpmvs_scene_destroy(hpmvs_scene* s) {
+    if (!s) return HPMVS_OK;
+    hipSetDevice(s->device);
+    for (void* p : s->allocs) hipFree(p);
+    if (s->dviews) hipFree(s->dviews);
+    if (s->dcovis_off) hipFree(s->dcovis_off);
+    if (s->dcovis) hipFree(s->dcovis);
+    if (s->dqueue) hipFree(s->dqueue);
+    if (s->ev0) hipEventDestroy(s->ev0);
+    if (s->ev1) hipEventDestroy(s->ev1);
+    delete s;
+    return HPMVS_OK;
+}
+
+int hpmvs_scene_get_level(const hpmvs_scene* s, int view, int level, uint8_t* host_out, size_t cap, int* w, int* h) {
+    if (!s || !w || !h) return fail(HPMVS_ERR_ARG, "scene_get_level: null argument");
+    if (view < 0 || view >= s->n_views || !s->view_set[view]) return fail(HPMVS_ERR_ARG, "scene_get_level: bad view");
+    const DevView& V = s->hviews[view];
+    if (level < 0 || level >= V.n_levels) return fail(HPMVS_ERR_ARG, "scene_get_level: bad level");
+    *w = V.w[level]; *h = V.h[level];
+    const size_t nb = (size_t)V.w[level] * V.h[level] * 3;
+    if (host_out) {
+        if (cap < nb) return fail(HPMVS_ERR_ARG, "scene_get_level: buffer too small");
+        HIPCHK(hipSetDevice(s->device));
+        HIPCHK(hipMemcpy(host_out, V.pix[level], nb, hipMemcpyDeviceToHost));
+    }
+    return HPMVS_OK;
+}
+
+size_t hpmvs_scene_bytes(const hpmvs_scene* s) { return s ? s->bytes : 0; }
+
+int hpmvs_build_pyramid(int device, const uint8_t* src, int w, int h, uint8_t* dst, int on_device) {
+    if (!src || !dst || w < 2 || h < 2) return fail(HPMVS_ERR_ARG, "build_pyramid: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(HPMVS_ERR_NODEVICE, "no HIP device visible");
+    HIPCHK(hipSetDevice(device));
+    const size_t nb = (size_t)w * h * 3, nb2 = (size_t)(w / 2) * (h / 2) * 3;
+    if (on_device) {
+        launch_half_resize(src, w, h, dst, nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
+        return HPMVS_OK;
+    }
+    uint8_t *ds = nullptr, *dd = nullptr;
+    HIPCHK(hipMalloc((void**)&ds, nb));
+    HIPCHK(hipMalloc((void**)&dd, nb2 + 16));
+    HIPCHK(hipMemcpy(ds, src, nb, hipMemcpyHostToDevice));
+    launch_half_resize(ds, w, h, dd, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(dst, dd, nb2, hipMemcpyDeviceToHost));
+    hipFree(ds); hipFree(dd);
+    return HPMVS_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// batch staging: host arrays <-> device arrays
+
+namespace {
+
+struct Staged {
+    DevBatch d;
+    std::vector<void*> tmp;
+    bool staged = false;
+    ~Staged() { for (void* p : tmp) hipFree(p); }
+};
+
+template <typename T>
+int stage_in(Staged& st, T*& dst, const T* host, size_t count, bool copy) {
+    dst = nullptr;
+    if (!host || count == 0) return HPMVS_OK;
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, sizeof(T) * count));
+    st.tmp.push_back(p);
+    if (copy) HIPCHK(hipMemcpy(p, host, sizeof(T) * count, hipMemcpyHostToDevice));
+    else HIPCHK(hipMemset(p, 0, sizeof(T) * count));
+    dst = (T*)p;
+    return HPMVS_OK;
+}
+
+template <typename T>
+int stage_out(T* host, const T* dev, size_t count) {
+    if (!host || !dev || count == 0) return HPMVS_OK;
+    HIPCHK(hipMemcpy(host, dev, sizeof(T) * count, hipMemcpyDeviceToHost));
+    return HPMVS_OK;
+}
+
+int check_batch(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_patch_batch* b) {
+    if (!s || !o || !b) return fail(HPMVS_ERR_ARG, "null scene/options/batch");
+    if (!s->committed) return fail(HPMVS_ERR_STATE, "scene not committed");
+    if (b->n < 0 || b->max_images < 1 || b->max_images > HPMVS_MAX_IMAGES) return fail(HPMVS_ERR_ARG, "bad n/max_images");
+    if (b->n > 0 && (!b->center || !b->normal || !b->scale || !b->n_images || !b->images))
+        return fail(HPMVS_ERR_ARG, "batch input arrays missing");
+    if (o->MAXLEVEL < 1 || o->MAXLEVEL >= HPMVS_MAX_LEVELS) return fail(HPMVS_ERR_ARG, "MAXLEVEL out of range");
+    return HPMVS_OK;
+}
+
+int stage_batch(Staged& st, const hpmvs_patch_batch* b, bool on_device, bool outputs) {
+    DevBatch& d = st.d;
+    memset(&d, 0, sizeof(d));
+    d.n = b->n; d.max_images = b->max_images;
+    const size_t n = (size_t)b->n;
+    if (on_device) {
+        d.center = b->center; d.normal = b->normal; d.scale = b->scale; d.n_images = b->n_images; d.images = b->images;
+        d.ok = b->ok; d.color = b->color; d.ncc = b->ncc; d.fmin = b->fmin; d.x = b->x; d.result = b->result;
+        d.nevals = b->nevals; d.stage = b->stage; d.ngrabs = b->ngrabs;
+        return HPMVS_OK;
+    }
+    st.staged = true;
+    int rc;
+    if ((rc = stage_in(st, d.center, b->center, 4 * n, true))) return rc;
+    if ((rc = stage_in(st, d.normal, b->normal, 4 * n, true))) return rc;
+    if ((rc = stage_in(st, d.scale, b->scale, n, true))) return rc;
+    if ((rc = stage_in(st, d.n_images, b->n_images, n, true))) return rc;
+    if ((rc = stage_in(st, d.images, b->images, n * b->max_images, true))) return rc;
+    if (outputs) {
+        if ((rc = stage_in(st, d.ok, b->ok, n, false))) return rc;
+        if ((rc = stage_in(st, d.color, b->color, 3 * n, false))) return rc;
+        if ((rc = stage_in(st, d.ncc, b->ncc, n, false))) return rc;
+        if ((rc = stage_in(st, d.fmin, b->fmin, n, false))) return rc;
+        if ((rc = stage_in(st, d.x, b->x, 3 * n, false))) return rc;
+        if ((rc = stage_in(st, d.result, b->result, n, false))) return rc;
+        if ((rc = stage_in(st, d.nevals, b->nevals, n, false))) return rc;
+        if ((rc = stage_in(st, d.stage, b->stage, n, false))) return rc;
+        if ((rc = stage_in(st, d.ngrabs, b->ngrabs, n, false))) return rc;
+    }
+    return HPMVS_OK;
+}
+
+DevScene dev_scene(const hpmvs_scene* s) {
+    DevScene sc;
+    sc.views = s->dviews; sc.covis_off = s->dcovis_off; sc.covis = s->dcovis; sc.n_views = s->n_views;
+    return sc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_patch_batch* b, int on_device,
+                         void* stream) {
+    int rc = check_batch(s, o, b);
+    if (rc) return rc;
+    if (!b->ok) return fail(HPMVS_ERR_ARG, "optimize_batch: ok[] is required");
+    if (b->n == 0) return HPMVS_OK;
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    Staged sg;
+    rc = stage_batch(sg, b, on_device != 0, true);
+    if (rc) return rc;
+    const DevOptions d = make_dev_options(o);
+    {
+        std::lock_guard<std::mutex> lk(s->mu);  // one work-queue counter + one event pair per scene
+        HIPCHK(hipMemsetAsync(s->dqueue, 0, 256, st));
+        HIPCHK(hipEventRecord(s->ev0, st));
+        launch_optimize(dev_scene(s), d, sg.d, s->dqueue, s->n_cus, st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(s->ev1, st));
+        s->timed = true;
+        if (!on_device) HIPCHK(hipStreamSynchronize(st));
+    }
+    if (!on_device) {
+        const size_t n = (size_t)b->n;
+        const DevBatch& D = sg.d;
+        if ((rc = stage_out(b->center, D.center, 4 * n))) return rc;
+        if ((rc = stage_out(b->normal, D.normal, 4 * n))) return rc;
+        if ((rc = stage_out(b->n_images, D.n_images, n))) return rc;
+        if ((rc = stage_out(b->images, D.images, n * b->max_images))) return rc;
+        if ((rc = stage_out(b->ok, D.ok, n))) return rc;
+        if ((rc = stage_out(b->color, D.color, 3 * n))) return rc;
+        if ((rc = stage_out(b->ncc, D.ncc, n))) return rc;
+        if ((rc = stage_out(b->fmin, D.fmin, n))) return rc;
+        if ((rc = stage_out(b->x, D.x, 3 * n))) return rc;
+        if ((rc = stage_out(b->result, D.result, n))) return rc;
+        if ((rc = stage_out(b->nevals, D.nevals, n))) return rc;
+        if ((rc = stage_out(b->stage, D.stage, n))) return rc;
+        if ((rc = stage_out(b->ngrabs, D.ngrabs, n))) return rc;
+    }
+    return HPMVS_OK;
+}
+
+int hpmvs_objective_batch(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_patch_batch* b, const double* x,
+                          double* f_out, int32_t* ngrabs_out, int on_device, void* stream) {
+    int rc = check_batch(s, o, b);
+    if (rc) return rc;
+    if (!x || !f_out) return fail(HPMVS_ERR_ARG, "objective_batch: x/f_out missing");
+    if (b->n == 0) return HPMVS_OK;
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    Staged sg;
+    rc = stage_batch(sg, b, on_device != 0, false);
+    if (rc) return rc;
+    const DevOptions d = make_dev_options(o);
+    const size_t n = (size_t)b->n;
+    if (on_device) {
+        launch_objective(dev_scene(s), d, sg.d, x, f_out, ngrabs_out, st);
+        HIPCHK(hipGetLastError());
+        return HPMVS_OK;
+    }
+    double *dx = nullptr, *df = nullptr;
+    int32_t* dg = nullptr;
+    if ((rc = stage_in(sg, dx, x, 3 * n, true))) return rc;
+    if ((rc = stage_in(sg, df, f_out, n, false))) return rc;
+    if ((rc = stage_in(sg, dg, ngrabs_out, n, false))) return rc;
+    launch_objective(dev_scene(s), d, sg.d, dx, df, dg, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    if ((rc = stage_out(f_out, df, n))) return rc;
+    if ((rc = stage_out(ngrabs_out, dg, n))) return rc;
+    return HPMVS_OK;
+}
+
+int hpmvs_inccs_batch(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_patch_batch* b, int ref_idx, int robust,
+                      float* out, int on_device, void* stream) {
+    int rc = check_batch(s, o, b);
+    if (rc) return rc;
+    if (!out || ref_idx < 0) return fail(HPMVS_ERR_ARG, "inccs_batch: out/ref_idx");
+    if (b->n == 0) return HPMVS_OK;
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    Staged sg;
+    rc = stage_batch(sg, b, on_device != 0, false);
+    if (rc) return rc;
+    const DevOptions d = make_dev_options(o);
+    const size_t n = (size_t)b->n;
+    if (on_device) {
+        launch_inccs(dev_scene(s), d, sg.d, ref_idx, robust, out, st);
+        HIPCHK(hipGetLastError());
+        return HPMVS_OK;
+    }
+    float* dout = nullptr;
+    if ((rc = stage_in(sg, dout, out, n * b->max_images, false))) return rc;
+    launch_inccs(dev_scene(s), d, sg.d, ref_idx, robust, dout, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return stage_out(out, dout, n * b->max_images);
+}
+
+int hpmvs_last_kernel_ms(const hpmvs_scene* s, float* ms) {
+    if (!s || !ms) return fail(HPMVS_ERR_ARG, "last_kernel_ms: null argument");
+    if (!s->timed) return fail(HPMVS_ERR_STATE, "last_kernel_ms: no optimize launch yet");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipEventSynchronize(s->ev1));
+    HIPCHK(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    return HPMVS_OK;
+}
+
+}  // extern "C"

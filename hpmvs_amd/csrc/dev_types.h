@@ -1,0 +1,58 @@
+// dev_types.h -- HBM-resident scene tables shared by the host C-ABI layer and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+namespace hpmvs {
+
+constexpr int kMaxLevels = 8;
+constexpr int kMaxImages = 64;   // = wavefront width: lane v <-> attached image v
+constexpr int kTex = 7;          // PatchTex = Patch2d<7,float> (reference Patch2d.hpp:88)
+constexpr int kTexPix = 49;
+
+// One view: what PatchOptimizer reads of mo3d::Camera + mo3d::Image
+// (reference Camera.h:87-105, Image.h:63-64,89-115).  Pyramid levels are separate allocations of
+// interleaved u8 RGB, 3*(y*W+x)+c, padded by 16 B so the 8-byte tap loads never leave the buffer.
+struct alignas(16) DevView {
+    const uint8_t* pix[kMaxLevels];
+    int32_t w[kMaxLevels];
+    int32_t h[kMaxLevels];
+    float P0[12];      // level 0; level l = diag(2^-l, 2^-l, 1) * P0 (Camera.cpp:55-63)
+    float center[4];
+    float xaxis[4];
+    float yaxis[4];
+    float zaxis[4];
+    float fsum;        // kMat_[0](0,0) + kMat_[0](1,1)
+    int32_t n_levels;  // projection_.size()
+    int32_t pad[2];
+};
+
+struct DevScene {
+    const DevView* views;
+    const int32_t* covis_off;  // n_views + 1
+    const int32_t* covis;
+    int32_t n_views;
+};
+
+// HpmvsOptions (reference HpmvsOptions.h:29-58) + host-precomputed thresholds so device and host
+// agree on them bit for bit.
+struct DevOptions {
+    int32_t MAXLEVEL, MINLEVEL;
+    float MAX_ANGLE, MIN_ANGLE;
+    int32_t MAX_IMAGES_PER_PATCH, MIN_IMAGES_PER_PATCH;
+    float NCC_ALPHA_1, NCC_ALPHA_2;
+    double cos_max_d;  // cos((double)MAX_ANGLE): PatchOptimizer.cpp:484 (unqualified cos)
+    float cos_max_f;   // std::cos(MAX_ANGLE): PatchOptimizer.cpp:129,238
+    float sort_thr;    // 1 - cos(10 deg): PatchOptimizer.cpp:184
+    float angle_scale; // M_PI / 48.0f: PatchOptimizer.cpp:398
+};
+
+// Batch arrays on the device (see hpmvs_patch_batch in include/hpmvs_amd.h)
+struct DevBatch {
+    int32_t n, max_images;
+    float* center; float* normal; float* scale;
+    int32_t* n_images; int32_t* images;
+    uint8_t* ok; float* color; float* ncc;
+    double* fmin; double* x; int32_t* result; int32_t* nevals; int32_t* stage; int32_t* ngrabs;
+};
+
+}  // namespace hpmvs

@@ -1,0 +1,121 @@
+// kernels_basic.hip -- gfx950 kernels: pyramid build, batched objective, batched setINCCs.
+// (The full refinement kernel lives in kernel_optimize.hip.)
+#include <hip/hip_runtime.h>
+
+#include "launch.h"
+#include "photometric.hpp"
+
+namespace hpmvs {
+
+// ------------------------------------------------------------------------------------------
+// CImg get_resize_halfXY on interleaved u8 RGB (reference thirdLibs/cimg/CImg.h:21189-21203 with
+// the clamped 3x3 walk of cimg_for3x3, CImg.h:1159-1175; called from Image::load,
+// src/hpmvs/Image.cpp:55-57).  One thread per output pixel (3 channels), rows of threads read
+// consecutive source pixels, so a wave covers 64*2*3 contiguous bytes of each of three rows.
+// No FMA contraction: the u8 truncation must match the CPU bit for bit.
+__global__ void __launch_bounds__(256) half_resize_kernel(const uint8_t* __restrict__ src, int w, int h,
+                                                          uint8_t* __restrict__ dst) {
+#pragma clang fp contract(off)
+    const int w2 = w / 2, h2 = h / 2;
+    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+    const int oy = blockIdx.y;
+    if (ox >= w2 || oy >= h2) return;
+    const int x = 2 * ox + 1, y = 2 * oy + 1;
+    const int xp = x - 1, xn = (x + 1 < w) ? x + 1 : w - 1;
+    const int yp = y - 1, yn = (y + 1 < h) ? y + 1 : h - 1;
+    const float m0 = 0.07842776544f, m1 = 0.1231940459f, m4 = 0.1935127547f;
+    const uint8_t* r0 = src + (size_t)yp * w * 3;
+    const uint8_t* r1 = src + (size_t)y * w * 3;
+    const uint8_t* r2 = src + (size_t)yn * w * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float v = (float)r0[3 * xp + c] * m0;
+        v = v + (float)r0[3 * x + c] * m1;
+        v = v + (float)r0[3 * xn + c] * m0;
+        v = v + (float)r1[3 * xp + c] * m1;
+        v = v + (float)r1[3 * x + c] * m4;
+        v = v + (float)r1[3 * xn + c] * m1;
+        v = v + (float)r2[3 * xp + c] * m0;
+        v = v + (float)r2[3 * x + c] * m1;
+        v = v + (float)r2[3 * xn + c] * m0;
+        dst[3 * ((size_t)oy * w2 + ox) + c] = (uint8_t)v;
+    }
+}
+
+void launch_half_resize(const uint8_t* src, int w, int h, uint8_t* dst, hipStream_t st) {
+    const int w2 = w / 2, h2 = h / 2;
+    if (w2 <= 0 || h2 <= 0) return;
+    dim3 block(256), grid((w2 + 255) / 256, h2);
+    hipLaunchKernelGGL(half_resize_kernel, grid, block, 0, st, src, w, h, dst);
+}
+
+// ------------------------------------------------------------------------------------------
+// objective_fn for a batch: one wavefront per patch, grid-stride.
+__global__ void __launch_bounds__(256) objective_kernel(DevScene sc, DevOptions o, DevBatch b,
+                                                        const double* __restrict__ xs, double* __restrict__ f_out,
+                                                        int32_t* __restrict__ ngrabs_out) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int p = wave; p < b.n; p += nwaves) {
+        const int nimg = b.n_images[p];
+        const int32_t* list = b.images + (size_t)p * b.max_images;
+        double f = 2.0;
+        int ngr = 0;
+        if (nimg > 0 && nimg <= kMaxImages) {
+            const float c0[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
+            OptFields F;
+            set_optimization_fields(sc.views[list[0]], c0, F);
+            const double x[3] = {xs[3 * p], xs[3 * p + 1], xs[3 * p + 2]};
+            float c[3], n[3];
+            set_center_norm(F, o, x, c, n);
+            const EvalResult r = wave_eval<true>(sc, o, list, nimg, 0, c, n, b.scale[p], 0);
+            f = r.obj;
+            ngr = r.ngrabs;
+        }
+        if (lane_id() == 0) {
+            f_out[p] = f;
+            if (ngrabs_out) ngrabs_out[p] = ngr;
+        }
+    }
+}
+
+void launch_objective(const DevScene& sc, const DevOptions& o, const DevBatch& b, const double* xs, double* f_out,
+                      int32_t* ngrabs_out, hipStream_t st) {
+    if (b.n <= 0) return;
+    const int waves_per_block = 4;
+    int blocks = (b.n + waves_per_block - 1) / waves_per_block;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(objective_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, st, sc, o, b, xs, f_out,
+                       ngrabs_out);
+}
+
+// setINCCs(ref_idx, robust) for a batch
+__global__ void __launch_bounds__(256) inccs_kernel(DevScene sc, DevOptions o, DevBatch b, int ref_idx, int robust,
+                                                    float* __restrict__ out) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int p = wave; p < b.n; p += nwaves) {
+        const int nimg = b.n_images[p];
+        const int32_t* list = b.images + (size_t)p * b.max_images;
+        const int lane = lane_id();
+        float mine = 2.0f;
+        if (nimg > 0 && nimg <= kMaxImages && ref_idx < nimg) {
+            const float c[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
+            const float n[3] = {b.normal[4 * p], b.normal[4 * p + 1], b.normal[4 * p + 2]};
+            const EvalResult r = wave_eval<false>(sc, o, list, nimg, ref_idx, c, n, b.scale[p], robust);
+            mine = r.incc_lane;
+        }
+        if (lane < b.max_images) out[(size_t)p * b.max_images + lane] = (lane < nimg) ? mine : 0.0f;
+    }
+}
+
+void launch_inccs(const DevScene& sc, const DevOptions& o, const DevBatch& b, int ref_idx, int robust, float* out,
+                  hipStream_t st) {
+    if (b.n <= 0) return;
+    const int waves_per_block = 4;
+    int blocks = (b.n + waves_per_block - 1) / waves_per_block;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(inccs_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, st, sc, o, b, ref_idx, robust, out);
+}
+
+}  // namespace hpmvs

@@ -1,0 +1,18 @@
+// launch.h -- host-callable launchers of the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dev_types.h"
+
+namespace hpmvs {
+
+void launch_half_resize(const uint8_t* src, int w, int h, uint8_t* dst, hipStream_t st);
+void launch_objective(const DevScene& sc, const DevOptions& o, const DevBatch& b, const double* xs, double* f_out,
+                      int32_t* ngrabs_out, hipStream_t st);
+void launch_inccs(const DevScene& sc, const DevOptions& o, const DevBatch& b, int ref_idx, int robust, float* out,
+                  hipStream_t st);
+// workspace: one int32 work-queue counter (zeroed by the launcher on `st`)
+void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* queue_counter,
+                     int n_cus, hipStream_t st);
+
+}  // namespace hpmvs

@@ -1,0 +1,374 @@
+// photometric.hpp -- gfx950 device code for the photometric primitives of the HPMVS hot path.
+//
+// Two kinds of code live here:
+//   * per-lane scalar helpers (patch axes, optimiser-variable <-> centre/normal maps, the
+//     per-image gates/level/projection "prep"): plain SIMT code, one patch or one image per lane;
+//   * the wave-cooperative evaluator `wave_eval`: ONE wavefront evaluates ONE patch against its
+//     whole image list.  Lane v < nimg prepares image v (gates, pyramid level, projected window
+//     geometry); then for every image the 49 texels of the 7x7 window are fetched by lanes 0..48
+//     (lane = yy*7+xx, two 8-byte loads per lane covering the 2x2x3 bilinear taps), and the means,
+//     the variance and the NCC dot product are DPP wave reductions.  The reference texture lives
+//     in three registers per lane; nothing goes through LDS.
+//
+// Reference functions restated here (file:line relative to the reference root):
+//   calc_patch_axes        <- PatchOptimizer::calculatePatchAxis   src/hpmvs/PatchOptimizer.cpp:532-548
+//   prep_image + grab      <- PatchOptimizer::sampleTexture        src/hpmvs/PatchOptimizer.cpp:476-529
+//                             Camera::project / getLeveli          include/hpmvs/Camera.h:45-62, src/hpmvs/Camera.cpp:92-99
+//                             Image::getColor                      include/hpmvs/Image.h:89-115
+//                             Patch2d::normalize / dot             include/hpmvs/Patch2d.hpp:37-84
+//   wave_eval<true>        <- PatchOptimizer::objective_fn         src/hpmvs/PatchOptimizer.cpp:286-311
+//   wave_eval<false>       <- PatchOptimizer::setINCCs             src/hpmvs/PatchOptimizer.cpp:448-474
+//   set_optimization_fields, set_center_norm, parameters_from_center_norm
+//                          <- src/hpmvs/PatchOptimizer.cpp:384-446
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dev_types.h"
+
+namespace hpmvs {
+
+// ------------------------------------------------------------------------------------------
+// wave64 helpers
+
+__device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(t);
+}
+
+// Sum over the 64 lanes; the result is wave-uniform (broadcast from lane 63 through an SGPR).
+// quad_perm xor1, xor2, row_half_mirror, row_mirror leave every lane of a 16-lane row holding the
+// row sum; row_bcast:15 / row_bcast:31 (GFX9 DPP) fold the four rows into lane 63.
+__device__ __forceinline__ float wave_sum(float v) {
+    v = dpp_add<0xB1, 0xF>(v);   // quad_perm:[1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);   // quad_perm:[2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);  // row_mirror
+    v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 -> rows 1,3
+    v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ float bcast_f(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+__device__ __forceinline__ int bcast_i(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+__device__ __forceinline__ double bcast_d(double v, int src_lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src_lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ const uint8_t* bcast_p(const uint8_t* p, int src_lane) {
+    const unsigned long long b = (unsigned long long)p;
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(b & 0xffffffffull), src_lane);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+    return (const uint8_t*)(((unsigned long long)hi << 32) | lo);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-lane scalar helpers (float32 in the reference's evaluation order)
+
+__device__ __forceinline__ float dot3f(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+__device__ __forceinline__ void cross3f(const float* a, const float* b, float* r) {
+    const float r0 = a[1] * b[2] - a[2] * b[1];
+    const float r1 = a[2] * b[0] - a[0] * b[2];
+    const float r2 = a[0] * b[1] - a[1] * b[0];
+    r[0] = r0; r[1] = r1; r[2] = r2;
+}
+__device__ __forceinline__ void normalized3f(const float* a, float* r) {
+    const float n2 = dot3f(a, a);
+    if (n2 > 0.0f) { const float n = sqrtf(n2); r[0] = a[0] / n; r[1] = a[1] / n; r[2] = a[2] / n; }
+    else { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
+}
+
+// PatchOptimizer::calculatePatchAxis (PatchOptimizer.cpp:532-548)
+__device__ __forceinline__ void calc_patch_axes(const float* cam_xaxis, const float* cam_yaxis, const float* n,
+                                                float scale, float* px, float* py, float* pz) {
+    float t[3], x[3], y[3];
+    normalized3f(n, pz);
+    cross3f(pz, cam_xaxis, t); normalized3f(t, y);
+    cross3f(y, pz, t); normalized3f(t, x);
+    for (int k = 0; k < 3; k++) { x[k] *= scale; y[k] *= scale; }
+    float yn[3], yan[3];
+    normalized3f(y, yn); normalized3f(cam_yaxis, yan);
+    const float fs = dot3f(yn, yan);
+    for (int k = 0; k < 3; k++) { px[k] = x[k]; py[k] = y[k] * fs; }
+}
+
+// Camera::project at level 0 (Camera.h:45-62), X.w = 1
+__device__ __forceinline__ void project0(const float* P, float X0, float X1, float X2, float& u, float& v) {
+    const float r0 = ((P[0] * X0 + P[1] * X1) + P[2] * X2) + P[3];
+    const float r1 = ((P[4] * X0 + P[5] * X1) + P[6] * X2) + P[7];
+    const float r2 = ((P[8] * X0 + P[9] * X1) + P[10] * X2) + P[11];
+    if (r2 <= 0.0f) { u = -65535.0f; v = -65535.0f; return; }
+    const float lo = -2147483648.0f, hi = 2147483648.0f;  // (float)(INT_MIN+3.0f), (float)(INT_MAX-3.0f)
+    u = fmaxf(lo, fminf(hi, r0 / r2));
+    v = fmaxf(lo, fminf(hi, r1 / r2));
+}
+
+// Camera::getLeveli (Camera.cpp:92-99): clamp(round(log2(scale*fsum/(2*fz))), 0, max_level),
+// evaluated as a count of thresholds r >= 2^(k+1/2) in float64 (no log, no division).
+__device__ __forceinline__ int level_clamped(float scale, float fsum, float fz, int max_level) {
+    const double num = (double)(scale * fsum);
+    const double den = 2.0 * (double)fz;
+    int lvl = 0;
+    double t = 1.4142135623730951;  // 2^(0+1/2)
+    for (int k = 0; k < kMaxLevels - 1; k++) {
+        if (k < max_level && num >= t * den) lvl++;
+        t *= 2.0;
+    }
+    return lvl;
+}
+
+struct Prep {
+    int ok;                // gates passed
+    float tlx, tly;        // top-left sample position (level-l pixels)
+    float dxx, dxy;        // step per xx
+    float dyx, dyy;        // step per yy
+    const uint8_t* pix;    // level-l image
+    int W;                 // level-l width
+};
+
+// The per-image, patch-uniform part of sampleTexture (PatchOptimizer.cpp:476-508): angle gate,
+// pyramid level, projected window, bounding-box gate.
+__device__ __forceinline__ Prep prep_image(const DevView& V, const DevOptions& o, const float* c, float scale,
+                                           const float* pxa, const float* pya, const float* zax) {
+    Prep r;
+    r.ok = 0; r.tlx = r.tly = r.dxx = r.dxy = r.dyx = r.dyy = 0.0f; r.pix = nullptr; r.W = 0;
+    const float d0 = V.center[0] - c[0], d1 = V.center[1] - c[1], d2 = V.center[2] - c[2];
+    const float n2 = (d0 * d0 + d1 * d1) + d2 * d2;  // w components cancel (1 - 1)
+    const float nn = sqrtf(n2);
+    float g;
+    if (n2 > 0.0f) g = ((d0 / nn) * zax[0] + (d1 / nn) * zax[1]) + (d2 / nn) * zax[2];
+    else g = (d0 * zax[0] + d1 * zax[1]) + d2 * zax[2];
+    if ((double)g < o.cos_max_d) return r;
+
+    const int lvl = level_clamped(scale, V.fsum, nn, o.MAXLEVEL - 1);
+    float P[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) P[k] = V.P0[k];
+    float cu, cv, xu, xv, yu, yv;
+    project0(P, c[0], c[1], c[2], cu, cv);
+    project0(P, c[0] + pxa[0], c[1] + pxa[1], c[2] + pxa[2], xu, xv);
+    project0(P, c[0] + pya[0], c[1] + pya[1], c[2] + pya[2], yu, yv);
+    const float s = __int_as_float((127 - lvl) << 23);  // 2^-lvl, exact
+    cu *= s; cv *= s;
+    const float dxx = xu * s - cu, dxy = xv * s - cv;
+    const float dyx = yu * s - cu, dyy = yv * s - cv;
+    const float hs = 3.5f;
+    const float tlx = (cu - hs * dxx) - hs * dyx, tly = (cv - hs * dxy) - hs * dyy;
+    const float trx = (cu + hs * dxx) - hs * dyx, try_ = (cv + hs * dxy) - hs * dyy;
+    const float blx = (cu - hs * dxx) + hs * dyx, bly = (cv - hs * dxy) + hs * dyy;
+    const float brx = (cu + hs * dxx) + hs * dyx, bry = (cv + hs * dxy) + hs * dyy;
+    const float mnx = fminf(fminf(fminf(tlx, trx), blx), brx), mny = fminf(fminf(fminf(tly, try_), bly), bry);
+    const float mxx = fmaxf(fmaxf(fmaxf(tlx, trx), blx), brx), mxy = fmaxf(fmaxf(fmaxf(tly, try_), bly), bry);
+    const int W = V.w[lvl], H = V.h[lvl];
+    const float m = 3.0f;
+    if (mnx < m || mny < m || mxx >= (float)(W - 3) || mxy >= (float)(H - 3)) return r;
+    r.ok = 1;
+    r.tlx = tlx; r.tly = tly; r.dxx = dxx; r.dxy = dxy; r.dyx = dyx; r.dyy = dyy;
+    r.pix = V.pix[lvl];
+    r.W = W;
+    return r;
+}
+
+// 8 unaligned bytes from global memory (address space 1, so the compiler emits
+// global_load_dwordx2 rather than a flat load for a pointer that travelled through readlane)
+__device__ __forceinline__ uint2 load8(const uint8_t* p) {
+    typedef __attribute__((address_space(1))) const uint8_t gbyte;
+    gbyte* g = (gbyte*)(unsigned long long)p;
+    uint2 v;
+    __builtin_memcpy(&v, g, 8);
+    return v;
+}
+
+// Lanes 0..48 fetch one texel each (Image::getColor, Image.h:89-115) at
+// tl + yy*dy + xx*dx; then Patch2d::normalize (Patch2d.hpp:46-84) across the wave.
+// Outputs the lane's normalised (r,g,b); lanes >= 49 get zeros.  All arguments except fx, fy,
+// active are wave-uniform.
+__device__ __forceinline__ void grab_normalized(float tlx, float tly, float dxx, float dxy, float dyx, float dyy,
+                                                const uint8_t* pix, int W, float fx, float fy, bool active,
+                                                float& n0, float& n1, float& n2) {
+    const float x = (tlx + fy * dyx) + fx * dxx;
+    const float y = (tly + fy * dyy) + fx * dxy;
+    const int lx = (int)x, ly = (int)y;
+    const uint8_t* p0 = pix + 3 * (ly * W + lx);
+    const uint8_t* p1 = p0 + 3 * W;
+    const uint2 a = load8(p0);
+    const uint2 b = load8(p1);
+    const float dx1 = x - (float)lx, dx0 = 1.0f - dx1;
+    const float dy1 = y - (float)ly, dy0 = 1.0f - dy1;
+    const float f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
+    float r = (float)(a.x & 0xff) * f00 + (float)(b.x & 0xff) * f01;
+    float g = (float)((a.x >> 8) & 0xff) * f00 + (float)((b.x >> 8) & 0xff) * f01;
+    float bl = (float)((a.x >> 16) & 0xff) * f00 + (float)((b.x >> 16) & 0xff) * f01;
+    r += (float)(a.x >> 24) * f10 + (float)(b.x >> 24) * f11;
+    g += (float)(a.y & 0xff) * f10 + (float)(b.y & 0xff) * f11;
+    bl += (float)((a.y >> 8) & 0xff) * f10 + (float)((b.y >> 8) & 0xff) * f11;
+    if (!active) { r = 0.0f; g = 0.0f; bl = 0.0f; }
+    const float a0 = wave_sum(r) / 49.0f;
+    const float a1 = wave_sum(g) / 49.0f;
+    const float a2 = wave_sum(bl) / 49.0f;
+    const float e0 = a0 - r, e1 = a1 - g, e2 = a2 - bl;
+    float sq = (e0 * e0 + e1 * e1) + e2 * e2;
+    if (!active) sq = 0.0f;
+    float ave2 = sqrtf(wave_sum(sq) / 147.0f);
+    if (ave2 == 0.0f) ave2 = 1.0f;
+    n0 = active ? (r - a0) / ave2 : 0.0f;
+    n1 = active ? (g - a1) / ave2 : 0.0f;
+    n2 = active ? (bl - a2) / ave2 : 0.0f;
+}
+
+__device__ __forceinline__ float robustincc(float rhs) { return rhs / (1 + 3 * rhs); }  // PatchOptimizer.h:92-94
+
+struct EvalResult {
+    double obj;       // OBJ: objective_fn value
+    float incc_lane;  // INCC: lane v holds inccs[v]
+    float incc_sum;   // INCC: sequential float sum of inccs (std::accumulate, PatchOptimizer.cpp:165)
+    int ngrabs;       // grabs that passed the gates
+};
+
+// One wavefront evaluates one patch.  Everything passed in is wave-uniform; `list` holds the
+// attached image ids (LDS uint16 rows in the refinement kernel, global int32 rows elsewhere).
+//   OBJ = true : objective_fn  (z axis of the angle gate = normalised normal, plateau 2.0)
+//   OBJ = false: setINCCs(ref_slot, robust) (z axis = the raw normal)
+template <bool OBJ, typename ListT>
+__device__ __forceinline__ EvalResult wave_eval(const DevScene& sc, const DevOptions& o, const ListT* list, int nimg,
+                                                int ref_slot, const float* c, const float* n, float scale,
+                                                int robust) {
+    EvalResult res;
+    res.obj = 2.0; res.incc_lane = 2.0f; res.incc_sum = 0.0f; res.ngrabs = 0;
+    const int lane = lane_id();
+    const int sl = lane < kTexPix ? lane : kTexPix - 1;
+    const float fy = (float)(sl / kTex), fx = (float)(sl % kTex);
+    const bool active = lane < kTexPix;
+
+    // patch axes from the reference image's camera (uniform)
+    const DevView& RV = sc.views[(int)list[ref_slot]];
+    float px[3], py[3], pz[3];
+    calc_patch_axes(RV.xaxis, RV.yaxis, n, scale, px, py, pz);
+    const float* zax = OBJ ? pz : n;
+
+    // lane v prepares image v
+    Prep P;
+    P.ok = 0; P.tlx = P.tly = P.dxx = P.dxy = P.dyx = P.dyy = 0.0f; P.pix = nullptr; P.W = 0;
+    if (lane < nimg) P = prep_image(sc.views[(int)list[lane]], o, c, scale, px, py, zax);
+
+    // reference texture
+    if (!bcast_i(P.ok, ref_slot)) {
+        // objective: 2.0; setINCCs: every entry 2.0
+        if (!OBJ) {
+            float s = 0.0f;
+            for (int k = 0; k < nimg; k++) s += 2.0f;
+            res.incc_sum = s;
+        }
+        return res;
+    }
+    float r0, r1, r2;
+    grab_normalized(bcast_f(P.tlx, ref_slot), bcast_f(P.tly, ref_slot), bcast_f(P.dxx, ref_slot),
+                    bcast_f(P.dxy, ref_slot), bcast_f(P.dyx, ref_slot), bcast_f(P.dyy, ref_slot),
+                    bcast_p(P.pix, ref_slot), bcast_i(P.W, ref_slot), fx, fy, active, r0, r1, r2);
+    int ngr = 1;
+    double val = 0.0;
+    int nok = 0;
+    float fsum = 0.0f;
+    float mine = 2.0f;
+    for (int v = 0; v < nimg; v++) {
+        float e;
+        if (v == ref_slot) {
+            e = 0.0f;
+            if (OBJ) continue;
+        } else if (!bcast_i(P.ok, v)) {
+            e = 2.0f;
+            if (OBJ) continue;
+        } else {
+            float c0, c1, c2;
+            grab_normalized(bcast_f(P.tlx, v), bcast_f(P.tly, v), bcast_f(P.dxx, v), bcast_f(P.dxy, v),
+                            bcast_f(P.dyx, v), bcast_f(P.dyy, v), bcast_p(P.pix, v), bcast_i(P.W, v), fx, fy,
+                            active, c0, c1, c2);
+            ngr++;
+            const float dot = wave_sum((r0 * c0 + r1 * c1) + r2 * c2) / 147.0f;
+            const float raw = 1.0f - dot;
+            if (OBJ) {
+                val += (double)robustincc(raw);
+                nok++;
+                continue;
+            }
+            e = robust ? robustincc(raw) : raw;
+        }
+        fsum += e;
+        if (lane == v) mine = e;
+    }
+    res.ngrabs = ngr;
+    if (OBJ) {
+        res.obj = (nok < o.MIN_IMAGES_PER_PATCH - 1) ? 2.0 : val / (double)nok;
+    } else {
+        res.incc_lane = mine;
+        res.incc_sum = fsum;
+    }
+    return res;
+}
+
+// ------------------------------------------------------------------------------------------
+// optimiser-variable <-> patch maps (per-lane scalar)
+
+struct OptFields {       // setOptimizationFields (PatchOptimizer.cpp:384-399)
+    float refCenter[3];  // w = 1
+    float refRay[3];     // w = 0
+    float imgX[3], imgY[3], imgZ[3];  // axes of the reference image's camera, normalised
+};
+
+__device__ __forceinline__ void set_optimization_fields(const DevView& V0, const float* c, OptFields& F) {
+    normalized3f(V0.xaxis, F.imgX);
+    normalized3f(V0.yaxis, F.imgY);
+    normalized3f(V0.zaxis, F.imgZ);
+    F.refCenter[0] = c[0]; F.refCenter[1] = c[1]; F.refCenter[2] = c[2];
+    const float d[3] = {c[0] - V0.center[0], c[1] - V0.center[1], c[2] - V0.center[2]};
+    normalized3f(d, F.refRay);
+}
+
+// setCenterNorm (PatchOptimizer.cpp:401-414); depthScale_ = 1
+__device__ __forceinline__ void set_center_norm(const OptFields& F, const DevOptions& o, const double* x, float* c,
+                                                float* n) {
+    const float x0 = (float)x[0];
+    for (int k = 0; k < 3; k++) c[k] = F.refCenter[k] + (x0 * F.refRay[k]) * 1.0f;
+    const float angle1 = (float)(x[1] * (double)o.angle_scale);
+    const float angle2 = (float)(x[2] * (double)o.angle_scale);
+    const double s1 = sin((double)angle1), c1 = cos((double)angle1);
+    const double s2 = sin((double)angle2), c2 = cos((double)angle2);
+    const float fx = (float)(s1 * c2);
+    const float fy = (float)s2;
+    const float fz = (float)(-c1 * c2);
+    for (int k = 0; k < 3; k++) n[k] = (F.imgX[k] * fx + F.imgY[k] * fy) + F.imgZ[k] * fz;
+}
+
+// parametersFromCenterNorm (PatchOptimizer.cpp:416-446) for c = refCenter_ (the only call site)
+__device__ __forceinline__ void parameters_from_center_norm(const OptFields& F, const DevOptions& o, const float* n,
+                                                            const double* lb, const double* ub, double* x) {
+    x[0] = 0.0;  // (refCenter - refCenter) . refRay
+    const float fx = dot3f(F.imgX, n), fy = dot3f(F.imgY, n), fz = dot3f(F.imgZ, n);
+    x[2] = (double)asinf(fy);
+    double t = (x[2] < 1.0) ? x[2] : 1.0;
+    t = (-1.0 < t) ? t : -1.0;
+    const float cosb = (float)cos(t);
+    if (cosb == 0.0f) x[1] = 0.0;
+    else {
+        const double sina = (double)(fx / cosb);
+        const double cosa = (double)(-fz / cosb);
+        double u = (-1.0 < cosa) ? cosa : -1.0;
+        u = (u < 1.0) ? u : 1.0;
+        x[1] = acos(u);
+        if (sina < 0.0) x[1] = -x[1];
+    }
+    x[1] /= (double)o.angle_scale;
+    x[2] /= (double)o.angle_scale;
+    for (int k = 0; k < 3; k++) {
+        const double v = (lb[k] < x[k]) ? x[k] : lb[k];
+        x[k] = (v < ub[k]) ? v : ub[k];
+    }
+}
+
+}  // namespace hpmvs

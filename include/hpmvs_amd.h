@@ -1,0 +1,148 @@
+/*
+ * hpmvs_amd.h -- C ABI of the MI355X-native HPMVS patch-refinement path.
+ *
+ * This is the drop-in boundary for the ONE hot path of alexlocher/hpmvs:
+ * mo3d::PatchOptimizer::optimize(Patch3d&) and everything below it
+ * (reference src/hpmvs/PatchOptimizer.cpp:78-103).  Plain pointers and sizes only;
+ * no C++/torch types.  The C++ mirror of the reference interface
+ * (include/hpmvs/PatchOptimizer.h, Patch3d.h, ...) is a thin layer over these calls.
+ *
+ * Every entry point returns HPMVS_OK or a negative error; hpmvs_last_error() gives text.
+ * Per-patch failure ("drop this patch", the reference's `return false`) is NOT an error:
+ * it is reported in hpmvs_patch_batch::ok.
+ *
+ * Reference interfaces replaced (file:line relative to the reference root):
+ *   hpmvs_scene_*            <- the const Scene view PatchOptimizer caches at construction,
+ *                               src/hpmvs/PatchOptimizer.cpp:38-41 (cameras_, images_, covis_;
+ *                               include/hpmvs/Scene.h:69-71), filled by Scene::addCameras
+ *                               (src/hpmvs/Scene.cpp:42-88: Image::load pyramid, Camera::init)
+ *                               and Scene::extractCoVisiblilty (Scene.cpp:241-298).
+ *   hpmvs_optimize_batch     <- PatchOptimizer::optimize, PatchOptimizer.cpp:78-103, over a batch
+ *                               (the OpenMP seed loop of Scene::initPatches, Scene.cpp:114-167).
+ *   hpmvs_objective_batch    <- PatchOptimizer::static_objective_fn / objective_fn,
+ *                               PatchOptimizer.cpp:286-320 (what NLopt calls back).
+ *   hpmvs_inccs_batch        <- PatchOptimizer::setINCCs, PatchOptimizer.cpp:448-474.
+ *   hpmvs_build_pyramid      <- Image::load's pyramid, src/hpmvs/Image.cpp:55-63
+ *                               (CImg get_resize_halfXY, thirdLibs/cimg/CImg.h:21189-21203).
+ */
+#ifndef HPMVS_AMD_H
+#define HPMVS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPMVS_OK 0
+#define HPMVS_ERR_HIP (-1)     /* a HIP runtime call failed */
+#define HPMVS_ERR_ARG (-2)     /* bad argument */
+#define HPMVS_ERR_STATE (-3)   /* scene not committed / already committed */
+#define HPMVS_ERR_NODEVICE (-4) /* no gfx950 device visible: there is NO CPU fallback */
+
+#define HPMVS_MAX_LEVELS 8
+#define HPMVS_MAX_IMAGES 64 /* images attached to one patch (reference: unbounded vector<int>); overflow => stage 100 */
+
+typedef struct hpmvs_scene hpmvs_scene; /* opaque; owns the HBM-resident pyramids and tables */
+
+/* include/hpmvs/HpmvsOptions.h:29-58, the fields the path reads */
+typedef struct {
+    int32_t MAXLEVEL;             /* 5 */
+    int32_t MINLEVEL;             /* 0 */
+    float MAX_ANGLE;              /* 60 deg in rad */
+    float MIN_ANGLE;              /* 10 deg in rad */
+    int32_t MAX_IMAGES_PER_PATCH; /* 6 (dead in the reference) */
+    int32_t MIN_IMAGES_PER_PATCH; /* 3 */
+    float NCC_ALPHA_1;            /* 0.4 */
+    float NCC_ALPHA_2;            /* 0.5 */
+} hpmvs_options;
+
+/* What the path reads of mo3d::Camera (include/hpmvs/Camera.h:87-105).  Level l's projection is
+ * diag(2^-l, 2^-l, 1) * P0 exactly (src/hpmvs/Camera.cpp:55-63 halves rows 0,1 per level), so only
+ * level 0 is passed. */
+typedef struct {
+    float P0[12];    /* projection_[0], row-major 3x4 */
+    float center[4]; /* center_ (w = 1) */
+    float xaxis[3];  /* xAxis_ */
+    float yaxis[3];  /* yAxis_ */
+    float zaxis[3];  /* zAxis_ */
+    float fsum;      /* kMat_[0](0,0) + kMat_[0](1,1) */
+    int32_t n_levels; /* projection_.size() = MAXLEVEL + 1 */
+} hpmvs_camera;
+
+/* A batch of Patch3d records (include/hpmvs/Patch3d.h:33-83) in structure-of-arrays form.
+ * All pointers are host pointers unless `on_device` is set in the call, in which case all are
+ * device pointers on the scene's GPU.  Inputs are updated in place only for patches with ok=1
+ * (reference: patch untouched on failure, PatchOptimizer.cpp:86-87). */
+typedef struct {
+    int32_t n;           /* number of patches */
+    int32_t max_images;  /* row stride of `images` (<= HPMVS_MAX_IMAGES) */
+    float *center;       /* [n][4] center_ (w = 1)            in/out */
+    float *normal;       /* [n][4] normal_ (w = 0)            in/out */
+    float *scale;        /* [n]    scale_3dx_                 in (returned unchanged) */
+    int32_t *n_images;   /* [n]    images_.size()             in/out */
+    int32_t *images;     /* [n][max_images] images_, [0] = reference image   in/out */
+    uint8_t *ok;         /* [n]    return value of optimize() out */
+    float *color;        /* [n][3] color_ (valid when ok)     out */
+    float *ncc;          /* [n]    ncc_ (constant 1.4f as in the reference, PatchOptimizer.cpp:95) out */
+    /* diagnostics the reference computes and discards (may be NULL) */
+    double *fmin;        /* [n]    final mean robust INCC (NLopt minf) */
+    double *x;           /* [n][3] final optimiser variables (depth, angle1, angle2) */
+    int32_t *result;     /* [n]    nlopt_result code of the BOBYQA run */
+    int32_t *nevals;     /* [n]    objective evaluations */
+    int32_t *stage;      /* [n]    0 = ok, else index of the pipeline stage that returned false */
+    int32_t *ngrabs;     /* [n]    sampleTexture calls that passed the gates (588 B of image each) */
+} hpmvs_patch_batch;
+
+/* ---- library ---------------------------------------------------------------------------- */
+const char *hpmvs_last_error(void);
+int hpmvs_device_count(void);
+void hpmvs_default_options(hpmvs_options *o);
+
+/* Host-side Camera::init (reference src/hpmvs/Camera.cpp:34-81): NVM camera (focal length,
+ * rotation quaternion wxyz world->camera in double, centre; include/hpmvs/NVMReader.h:44-50) and the
+ * level-0 image size -> the float32 tables above.  Pure host code, usable without a GPU. */
+int hpmvs_camera_from_nvm(double f, const double q_wxyz[4], const double c[3], int width, int height,
+                          int max_level, hpmvs_camera *out);
+
+/* ---- scene (HBM-resident, immutable after commit; shared read-only by all callers) ------- */
+int hpmvs_scene_create(int n_views, int device, hpmvs_scene **out);
+/* Level-0 interleaved u8 RGB (row-major, 3*(y*W+x)+c: reference Image.h:93-105).  The pyramid is
+ * built on the GPU by the half-resize kernel.  rgb_on_device != 0: `rgb_l0` is a device pointer. */
+int hpmvs_scene_set_view(hpmvs_scene *s, int view, int width, int height, const uint8_t *rgb_l0,
+                         int rgb_on_device, const hpmvs_camera *cam);
+int hpmvs_scene_set_covis(hpmvs_scene *s, int view, const int32_t *ids, int n);
+int hpmvs_scene_commit(hpmvs_scene *s);
+int hpmvs_scene_destroy(hpmvs_scene *s);
+/* copy one pyramid level back to the host (tests: bit-exact pyramid parity) */
+int hpmvs_scene_get_level(const hpmvs_scene *s, int view, int level, uint8_t *host_out, size_t cap,
+                          int *w, int *h);
+size_t hpmvs_scene_bytes(const hpmvs_scene *s);
+
+/* stand-alone pyramid kernel: src (w x h, device or host) -> dst (w/2 x h/2) */
+int hpmvs_build_pyramid(int device, const uint8_t *src, int w, int h, uint8_t *dst, int on_device);
+
+/* ---- the hot path ------------------------------------------------------------------------- */
+/* Full optimize() for every patch of the batch.  `stream` is a hipStream_t (NULL = default
+ * stream); with on_device != 0 the call only enqueues work on `stream`. */
+int hpmvs_optimize_batch(const hpmvs_scene *s, const hpmvs_options *o, hpmvs_patch_batch *b,
+                         int on_device, void *stream);
+
+/* objective_fn at optimiser variables x[n][3] for each patch's current image list, with
+ * refCenter_/refRay_/axes taken from the patch as optimizePatch does.  f_out[n]. */
+int hpmvs_objective_batch(const hpmvs_scene *s, const hpmvs_options *o, const hpmvs_patch_batch *b,
+                          const double *x, double *f_out, int32_t *ngrabs_out, int on_device,
+                          void *stream);
+
+/* setINCCs(ref_idx, robust) for each patch: out[n][max_images] */
+int hpmvs_inccs_batch(const hpmvs_scene *s, const hpmvs_options *o, const hpmvs_patch_batch *b,
+                      int ref_idx, int robust, float *out, int on_device, void *stream);
+
+/* last optimize launch: kernel time measured with HIP events on the launch stream (ms) */
+int hpmvs_last_kernel_ms(const hpmvs_scene *s, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPMVS_AMD_H */

@@ -1,0 +1,784 @@
+/*
+ * hpmvs_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ * See hpmvs_oracle.h for the rules and the parity status.
+ *
+ * Plain-C restatement of the reference hot path.  All geometry/texture
+ * arithmetic is float32 in the reference's evaluation order (sequential sums,
+ * no FMA contraction: build with -ffp-contract=off); optimiser variables are
+ * float64.  File:line citations are relative to the reference root.
+ */
+#define _GNU_SOURCE
+#include "hpmvs_oracle.h"
+
+#include <dlfcn.h>
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* tiny float vector helpers (Eigen fixed-size ops restated as scalar loops)  */
+
+static inline float dot3(const float *a, const float *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static inline float dot4(const float *a, const float *b) {
+    return ((a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]) + a[3] * b[3];
+}
+static inline void cross3(const float *a, const float *b, float *r) {
+    const float r0 = a[1] * b[2] - a[2] * b[1];
+    const float r1 = a[2] * b[0] - a[0] * b[2];
+    const float r2 = a[0] * b[1] - a[1] * b[0];
+    r[0] = r0; r[1] = r1; r[2] = r2;
+}
+static inline void normalized3(const float *a, float *r) {
+    const float n2 = dot3(a, a);
+    if (n2 > 0.0f) { const float n = sqrtf(n2); r[0] = a[0] / n; r[1] = a[1] / n; r[2] = a[2] / n; }
+    else { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
+}
+static inline void normalized4(const float *a, float *r) {
+    const float n2 = dot4(a, a);
+    if (n2 > 0.0f) { const float n = sqrtf(n2); for (int i = 0; i < 4; i++) r[i] = a[i] / n; }
+    else { for (int i = 0; i < 4; i++) r[i] = a[i]; }
+}
+static inline void sub4(const float *a, const float *b, float *r) { for (int i = 0; i < 4; i++) r[i] = a[i] - b[i]; }
+static inline void add4(const float *a, const float *b, float *r) { for (int i = 0; i < 4; i++) r[i] = a[i] + b[i]; }
+static inline float norm4(const float *a) { return sqrtf(dot4(a, a)); }
+
+/* ------------------------------------------------------------------------- */
+
+void orc_default_options(orc_options *o) {
+    /* include/hpmvs/HpmvsOptions.h:29-58 */
+    o->MAXLEVEL = 5;
+    o->MINLEVEL = 0;
+    o->MAX_ANGLE = (float)(60.0f * M_PI / 180.0f);
+    o->MIN_ANGLE = (float)(10.0f * M_PI / 180.0f);
+    o->MAX_IMAGES_PER_PATCH = 6;
+    o->MIN_IMAGES_PER_PATCH = 3;
+    o->NCC_ALPHA_1 = 0.4f;
+    o->NCC_ALPHA_2 = 0.5f;
+}
+
+orc_scene *orc_scene_create(int n_views) {
+    orc_scene *s = (orc_scene *)calloc(1, sizeof(orc_scene));
+    s->n_views = n_views;
+    s->cams = (orc_camera *)calloc((size_t)n_views, sizeof(orc_camera));
+    s->imgs = (orc_image *)calloc((size_t)n_views, sizeof(orc_image));
+    s->covis_off = (int *)calloc((size_t)n_views + 1, sizeof(int));
+    s->covis = NULL;
+    return s;
+}
+
+void orc_scene_destroy(orc_scene *s) {
+    if (!s) return;
+    for (int i = 0; i < s->n_views; i++)
+        for (int l = 0; l < ORC_MAX_LEVELS; l++) free(s->imgs[i].pix[l]);
+    free(s->cams); free(s->imgs); free(s->covis_off); free(s->covis); free(s);
+}
+
+/* thirdLibs/cimg/CImg.h:21189-21203 (get_resize_halfXY) with the 3x3 neighbourhood walk of
+ * cimg_for3x3 (CImg.h:1159-1175: previous/next indices clamped to the image) applied per
+ * channel; the reference runs it on planar data before permute_axes("cxyz")
+ * (src/hpmvs/Image.cpp:55-63), which is the same arithmetic per channel. */
+void orc_half_resize(const uint8_t *src, int w, int h, uint8_t *dst) {
+    const float m0 = 0.07842776544f, m1 = 0.1231940459f, m4 = 0.1935127547f;
+    const int w2 = w / 2, h2 = h / 2;
+    for (int c = 0; c < 3; c++)
+        for (int y = 1; y < h; y += 2) {
+            const int yp = y - 1, yn = (y + 1 < h) ? y + 1 : h - 1;
+            if (y / 2 >= h2) break;
+            for (int x = 1; x < w; x += 2) {
+                const int xp = x - 1, xn = (x + 1 < w) ? x + 1 : w - 1;
+                if (x / 2 >= w2) break;
+#define PX(xx, yy) ((float)src[3 * ((size_t)(yy) * w + (xx)) + c])
+                const float v = PX(xp, yp) * m0 + PX(x, yp) * m1 + PX(xn, yp) * m0 +
+                                PX(xp, y) * m1 + PX(x, y) * m4 + PX(xn, y) * m1 +
+                                PX(xp, yn) * m0 + PX(x, yn) * m1 + PX(xn, yn) * m0;
+#undef PX
+                dst[3 * ((size_t)(y / 2) * w2 + (x / 2)) + c] = (uint8_t)v;
+            }
+        }
+}
+
+/* Camera::init, src/hpmvs/Camera.cpp:34-81 */
+static void camera_init(orc_camera *cam, double f, const double q[4], const double c[3], int width,
+                        int height, int max_level) {
+    cam->n_levels = max_level + 1;
+    float K[9] = {(float)f, 0, (float)(width / 2.0), 0, (float)f, (float)(height / 2.0), 0, 0, 1};
+    memcpy(cam->K0, K, sizeof(K));
+    /* Eigen::Quaterniond::matrix() in double, then cast<float>() (Camera.cpp:43-50) */
+    const double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+    const double tx = 2.0 * qx, ty = 2.0 * qy, tz = 2.0 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw;
+    const double txx = tx * qx, txy = ty * qx, txz = tz * qx;
+    const double tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    float R[9];
+    R[0] = (float)(1.0 - (tyy + tzz)); R[1] = (float)(txy - twz); R[2] = (float)(txz + twy);
+    R[3] = (float)(txy + twz); R[4] = (float)(1.0 - (txx + tzz)); R[5] = (float)(tyz - twx);
+    R[6] = (float)(txz - twy); R[7] = (float)(tyz + twx); R[8] = (float)(1.0 - (txx + tyy));
+    const float cf[3] = {(float)c[0], (float)c[1], (float)c[2]};
+    float Rt[12];
+    for (int r = 0; r < 3; r++) {
+        Rt[r * 4 + 0] = R[r * 3 + 0]; Rt[r * 4 + 1] = R[r * 3 + 1]; Rt[r * 4 + 2] = R[r * 3 + 2];
+        Rt[r * 4 + 3] = -((R[r * 3 + 0] * cf[0] + R[r * 3 + 1] * cf[1]) + R[r * 3 + 2] * cf[2]);
+    }
+    /* projection_[0] = kMat_[0] * [R | -R c] (Camera.cpp:52) */
+    for (int r = 0; r < 3; r++)
+        for (int col = 0; col < 4; col++)
+            cam->P[0][r * 4 + col] =
+                (K[r * 3 + 0] * Rt[0 * 4 + col] + K[r * 3 + 1] * Rt[1 * 4 + col]) + K[r * 3 + 2] * Rt[2 * 4 + col];
+    /* lower levels: rows 0,1 halved (Camera.cpp:55-63) */
+    for (int l = 1; l < cam->n_levels; l++) {
+        memcpy(cam->P[l], cam->P[l - 1], sizeof(float) * 12);
+        for (int k = 0; k < 8; k++) cam->P[l][k] = (float)(cam->P[l][k] / 2.0);
+    }
+    cam->center[0] = cf[0]; cam->center[1] = cf[1]; cam->center[2] = cf[2]; cam->center[3] = 1.0f;
+    /* axes (Camera.cpp:65-76) */
+    const float *r2 = &cam->P[0][8];
+    const float n = sqrtf(dot3(r2, r2));
+    for (int k = 0; k < 4; k++) cam->oaxis[k] = r2[k] / n;
+    for (int k = 0; k < 3; k++) cam->zaxis[k] = cam->oaxis[k];
+    float xa[3] = {cam->P[0][0], cam->P[0][1], cam->P[0][2]};
+    float ya[3];
+    cross3(cam->zaxis, xa, ya);
+    normalized3(ya, cam->yaxis);
+    cross3(cam->yaxis, cam->zaxis, xa);
+    normalized3(xa, cam->xaxis);
+}
+
+void orc_scene_set_view(orc_scene *s, int i, int w, int h, const uint8_t *rgb_l0, double f,
+                        const double q_wxyz[4], const double c[3], int max_level) {
+    /* Image::init/load: maxLevel_ = max(1, maxLevel); maxLevel_+1 levels (Image.cpp:33-57) */
+    const int img_levels = (max_level > 1 ? max_level : 1) + 1;
+    orc_image *im = &s->imgs[i];
+    for (int l = 0; l < ORC_MAX_LEVELS; l++) { free(im->pix[l]); im->pix[l] = NULL; }
+    im->n_levels = img_levels;
+    im->w[0] = w; im->h[0] = h;
+    im->pix[0] = (uint8_t *)malloc((size_t)w * h * 3 + 16);
+    memcpy(im->pix[0], rgb_l0, (size_t)w * h * 3);
+    for (int l = 1; l < img_levels; l++) {
+        im->w[l] = im->w[l - 1] / 2; im->h[l] = im->h[l - 1] / 2;
+        im->pix[l] = (uint8_t *)calloc((size_t)im->w[l] * im->h[l] * 3 + 16, 1);
+        orc_half_resize(im->pix[l - 1], im->w[l - 1], im->h[l - 1], im->pix[l]);
+    }
+    camera_init(&s->cams[i], f, q_wxyz, c, w, h, max_level);
+}
+
+void orc_scene_set_covis(orc_scene *s, int i, const int *ids, int n) {
+    /* lists must be set in view order 0..n_views-1 */
+    const int off = s->covis_off[i];
+    s->covis = (int *)realloc(s->covis, sizeof(int) * (size_t)(off + n + 1));
+    memcpy(s->covis + off, ids, sizeof(int) * (size_t)n);
+    for (int k = i + 1; k <= s->n_views; k++) s->covis_off[k] = off + n;
+}
+
+const orc_camera *orc_scene_camera(const orc_scene *s, int i) { return &s->cams[i]; }
+const uint8_t *orc_scene_level(const orc_scene *s, int i, int level, int *w, int *h) {
+    *w = s->imgs[i].w[level]; *h = s->imgs[i].h[level];
+    return s->imgs[i].pix[level];
+}
+
+/* ------------------------------------------------------------------------- */
+/* L1 primitives                                                              */
+
+/* Camera::project, include/hpmvs/Camera.h:45-62 */
+static void cam_project(const orc_camera *cam, const float *X, int level, float *out) {
+    if (level >= cam->n_levels) { fprintf(stderr, "Illegal level access in Camera"); exit(1); }
+    const float *P = cam->P[level];
+    float r[3];
+    for (int k = 0; k < 3; k++)
+        r[k] = ((P[k * 4 + 0] * X[0] + P[k * 4 + 1] * X[1]) + P[k * 4 + 2] * X[2]) + P[k * 4 + 3] * X[3];
+    if (r[2] <= 0.0f) {
+        out[0] = -65535.0f; out[1] = -65535.0f; out[2] = -1.0f;
+    } else {
+        const float lo = (float)(INT_MIN + 3.0f), hi = (float)(INT_MAX - 3.0f);
+        r[0] = r[0] / r[2]; r[1] = r[1] / r[2]; r[2] = r[2] / r[2];
+        out[0] = fmaxf(lo, fminf(hi, r[0]));
+        out[1] = fmaxf(lo, fminf(hi, r[1]));
+        out[2] = r[2];
+    }
+}
+
+/* Camera::getScale, src/hpmvs/Camera.cpp:83-90 */
+static float cam_get_scale(const orc_camera *cam, const float *X, int level) {
+    float d[4]; sub4(X, cam->center, d);
+    const float fz = norm4(d);
+    const float ftmp = cam->K0[0] + cam->K0[4];
+    if (ftmp == 0.0) return 1.0f;
+    return (float)(2.0 * fz * (0x0001 << level) / ftmp);
+}
+/* Camera::getLevel, src/hpmvs/Camera.cpp:92-95 */
+static float cam_get_level(const orc_camera *cam, const float *X, float scale) {
+    float d[4]; sub4(X, cam->center, d);
+    const float fz = norm4(d);
+    return (float)log2(scale * (float)(cam->K0[0] + cam->K0[4]) / (2.0 * fz));
+}
+/* Camera::getLeveli, src/hpmvs/Camera.cpp:97-99 */
+static int cam_get_leveli(const orc_camera *cam, const float *X, float scale, int max_level) {
+    const int l = (int)roundf(cam_get_level(cam, X, scale));
+    const int a = l < max_level ? l : max_level;
+    return a > 0 ? a : 0;
+}
+
+/* Image::getColor, include/hpmvs/Image.h:89-115 */
+static void img_get_color(const orc_image *im, float x, float y, int level, float *rgb) {
+    const int W = im->w[level];
+    const int lx = (int)x, ly = (int)y;
+    const long index = 3 * ((long)ly * W + lx);
+    const float dx1 = x - lx, dx0 = 1.0f - dx1;
+    const float dy1 = y - ly, dy0 = 1.0f - dy1;
+    const float f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
+    const uint8_t *p0 = im->pix[level] + index;
+    const uint8_t *p1 = p0 + 3 * (long)W;
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    r += p0[0] * f00 + p1[0] * f01;
+    g += p0[1] * f00 + p1[1] * f01;
+    b += p0[2] * f00 + p1[2] * f01;
+    r += p0[3] * f10 + p1[3] * f11;
+    g += p0[4] * f10 + p1[4] * f11;
+    b += p0[5] * f10 + p1[5] * f11;
+    rgb[0] = r; rgb[1] = g; rgb[2] = b;
+}
+
+/* Patch2d::normalize, include/hpmvs/Patch2d.hpp:46-84 */
+static void tex_normalize(float *d) {
+    float ave[3] = {0, 0, 0};
+    for (int i = 0; i < 49; i++) { ave[0] += d[3 * i]; ave[1] += d[3 * i + 1]; ave[2] += d[3 * i + 2]; }
+    ave[0] /= 49; ave[1] /= 49; ave[2] /= 49;
+    float ave2 = 0.0f;
+    for (int i = 0; i < 49; i++) {
+        const float f0 = ave[0] - d[3 * i], f1 = ave[1] - d[3 * i + 1], f2 = ave[2] - d[3 * i + 2];
+        ave2 += f0 * f0 + f1 * f1 + f2 * f2;
+    }
+    ave2 = sqrtf(ave2 / 147);
+    if (ave2 == 0.0f) ave2 = 1.0f;
+    for (int i = 0; i < 49; i++)
+        for (int c = 0; c < 3; c++) { d[3 * i + c] -= ave[c]; d[3 * i + c] /= ave2; }
+}
+/* Patch2d::dot, include/hpmvs/Patch2d.hpp:37-44 */
+static float tex_dot(const float *a, const float *b) {
+    float ans = 0.0f;
+    for (int i = 0; i < 147; i++) ans += a[i] * b[i];
+    return ans / 147;
+}
+
+/* PatchOptimizer.h:92-98 */
+static inline float robustincc(const float rhs) { return rhs / (1 + 3 * rhs); }
+
+/* ------------------------------------------------------------------------- */
+/* L2: the PatchOptimizer state (include/hpmvs/PatchOptimizer.h:103-131)      */
+
+typedef struct {
+    const orc_scene *s;
+    const orc_options *o;
+    float pCenter[4], pNormal[4], pScale;
+    float pX[4], pY[4], pZ[4];
+    int nimg;
+    int img[ORC_MAX_IMAGES];
+    float refCenter[4], refRay[4];
+    float imgX0[3], imgY0[3], imgZ0[3]; /* only index 0 of imgX_/imgY_/imgZ_ is ever read */
+    float depthScale, angleScale;
+    float refTex[147], comTex[147];
+    long ngrabs, ngrabs_all;
+    int last_level;
+    float last_cdxdy[6];
+} popt;
+
+/* PatchOptimizer::calculatePatchAxis, src/hpmvs/PatchOptimizer.cpp:532-548 */
+static void calculate_patch_axis(popt *po, int refCam, const float *n, float scale) {
+    const orc_camera *rc = &po->s->cams[refCam];
+    float x[3], y[3], z[3], t[3];
+    normalized3(n, z);
+    cross3(z, rc->xaxis, t); normalized3(t, y);
+    cross3(y, z, t); normalized3(t, x);
+    for (int k = 0; k < 3; k++) { x[k] *= scale; y[k] *= scale; }
+    float yn[3], yan[3];
+    normalized3(y, yn); normalized3(rc->yaxis, yan);
+    const float fs = dot3(yn, yan);
+    for (int k = 0; k < 3; k++) y[k] = y[k] * fs;
+    for (int k = 0; k < 3; k++) { po->pX[k] = x[k]; po->pY[k] = y[k]; po->pZ[k] = z[k]; }
+    po->pX[3] = po->pY[3] = po->pZ[3] = 0.0f;
+}
+
+/* PatchOptimizer::sampleTexture, src/hpmvs/PatchOptimizer.cpp:476-529 */
+static int sample_texture(popt *po, const float *pCenter, float pScale, const float *pxaxis,
+                          const float *pyaxis, const float *pzaxis, int camIdx, float *tex) {
+    const orc_image *image = &po->s->imgs[camIdx];
+    const orc_camera *camera = &po->s->cams[camIdx];
+    po->ngrabs_all++;
+    float d[4], dn[4];
+    sub4(camera->center, pCenter, d); normalized4(d, dn);
+    if (dot4(dn, pzaxis) < cos(po->o->MAX_ANGLE)) return 0;
+
+    const int lvl = cam_get_leveli(camera, pCenter, pScale, po->o->MAXLEVEL - 1);
+    float pc[3], px[3], py[3], tmp[4];
+    cam_project(camera, pCenter, lvl, pc);
+    add4(pCenter, pxaxis, tmp); cam_project(camera, tmp, lvl, px);
+    add4(pCenter, pyaxis, tmp); cam_project(camera, tmp, lvl, py);
+    const float center[2] = {pc[0], pc[1]};
+    const float dx[2] = {px[0] - center[0], px[1] - center[1]};
+    const float dy[2] = {py[0] - center[0], py[1] - center[1]};
+
+    const float halfSize = 7 / 2.0f;
+    float tl[2], tr[2], bl[2], br[2], mn[2], mx[2];
+    for (int k = 0; k < 2; k++) {
+        tl[k] = (center[k] - halfSize * dx[k]) - halfSize * dy[k];
+        tr[k] = (center[k] + halfSize * dx[k]) - halfSize * dy[k];
+        bl[k] = (center[k] - halfSize * dx[k]) + halfSize * dy[k];
+        br[k] = (center[k] + halfSize * dx[k]) + halfSize * dy[k];
+        mn[k] = fminf(fminf(fminf(tl[k], tr[k]), bl[k]), br[k]);
+        mx[k] = fmaxf(fmaxf(fmaxf(tl[k], tr[k]), bl[k]), br[k]);
+    }
+    const int m = 3;
+    if (mn[0] < m || mn[1] < m || mx[0] >= image->w[lvl] - m || mx[1] >= image->h[lvl] - m) return 0;
+
+    po->ngrabs++;
+    po->last_level = lvl;
+    po->last_cdxdy[0] = center[0]; po->last_cdxdy[1] = center[1];
+    po->last_cdxdy[2] = dx[0]; po->last_cdxdy[3] = dx[1];
+    po->last_cdxdy[4] = dy[0]; po->last_cdxdy[5] = dy[1];
+
+    float *target = tex;
+    float l[2] = {tl[0], tl[1]};
+    for (int yy = 0; yy < 7; yy++) {
+        float c[2] = {l[0], l[1]};
+        l[0] += dy[0]; l[1] += dy[1];
+        for (int xx = 0; xx < 7; xx++) {
+            float color[3];
+            img_get_color(image, c[0], c[1], lvl, color);
+            *(target++) = color[0]; *(target++) = color[1]; *(target++) = color[2];
+            c[0] += dx[0]; c[1] += dx[1];
+        }
+    }
+    tex_normalize(tex);
+    return 1;
+}
+
+/* PatchOptimizer::setINCCs, src/hpmvs/PatchOptimizer.cpp:448-474 */
+static void set_inccs(popt *po, float *inccs, const int *indexes, int n, int refIdx, int robust) {
+    calculate_patch_axis(po, indexes[refIdx], po->pNormal, po->pScale);
+    if (!sample_texture(po, po->pCenter, po->pScale, po->pX, po->pY, po->pNormal, indexes[refIdx], po->refTex)) {
+        for (int i = 0; i < n; i++) inccs[i] = 2.0f;
+        return;
+    }
+    for (int ii = 0; ii < n; ii++) {
+        if (ii == refIdx) inccs[ii] = 0.0f;
+        else if (!sample_texture(po, po->pCenter, po->pScale, po->pX, po->pY, po->pNormal, indexes[ii], po->comTex))
+            inccs[ii] = 2.0f;
+        else if (robust) inccs[ii] = robustincc(1.0f - tex_dot(po->refTex, po->comTex));
+        else inccs[ii] = 1.0f - tex_dot(po->refTex, po->comTex);
+    }
+}
+
+/* PatchOptimizer::addImages, src/hpmvs/PatchOptimizer.cpp:225-258 */
+static int add_images(popt *po) {
+    if (po->nimg <= 0) return 0;
+    const orc_scene *s = po->s;
+    const int refImg = po->img[0];
+    const int n_existing = po->nimg;
+    for (int ci = s->covis_off[refImg]; ci < s->covis_off[refImg + 1]; ci++) {
+        const int cv = s->covis[ci];
+        int found = 0;
+        for (int k = 0; k < n_existing; k++) if (po->img[k] == cv) { found = 1; break; }
+        if (found) continue;
+        const orc_camera *cam = &s->cams[cv];
+        float d[4], dn[4];
+        sub4(cam->center, po->pCenter, d); normalized4(d, dn);
+        if (dot4(dn, po->pNormal) < cosf(po->o->MAX_ANGLE)) continue;
+        const int imgLevel = (int)roundf(cam_get_level(cam, po->pCenter, po->pScale));
+        if (imgLevel < po->o->MINLEVEL || imgLevel >= po->o->MAXLEVEL - 2) continue;
+        float pc[3];
+        cam_project(cam, po->pCenter, imgLevel, pc);
+        if (pc[0] < 0.0f || s->imgs[cv].w[imgLevel] - 1 <= pc[0] || pc[1] < 0.0f ||
+            s->imgs[cv].h[imgLevel] - 1 <= pc[1])
+            continue;
+        if (po->nimg < ORC_MAX_IMAGES) po->img[po->nimg++] = cv;
+    }
+    return po->nimg >= po->o->MIN_IMAGES_PER_PATCH;
+}
+
+/* PatchOptimizer::filterImagesNCC, src/hpmvs/PatchOptimizer.cpp:138-152 */
+static int filter_images_ncc(popt *po, float threshold) {
+    float inccs[ORC_MAX_IMAGES];
+    set_inccs(po, inccs, po->img, po->nimg, 0, 0);
+    int n = 1;
+    for (int i = 1; i < po->nimg; i++)
+        if (inccs[i] < 1.0f - threshold) po->img[n++] = po->img[i];
+    po->nimg = n;
+    return po->nimg >= po->o->MIN_IMAGES_PER_PATCH;
+}
+
+/* PatchOptimizer::sortImages + getAngleWeightedScales, src/hpmvs/PatchOptimizer.cpp:183-223, 260-284 */
+static int sort_images(popt *po) {
+    const float threshold = (float)(1.0f - cos(10.0 * M_PI / 180.0));
+    int indexes[ORC_MAX_IMAGES], n = 0;
+    float wScales[ORC_MAX_IMAGES];
+    float rays[ORC_MAX_IMAGES][4];
+    if (po->nimg > 0) {
+        const orc_camera *c0 = &po->s->cams[po->img[0]];
+        int refLevel = (int)roundf(cam_get_level(c0, po->pCenter, po->pScale));
+        if (refLevel > po->o->MAXLEVEL - 1) refLevel = po->o->MAXLEVEL - 1;
+        if (refLevel < 0) refLevel = 0;
+        float nn[4]; normalized4(po->pNormal, nn);
+        for (int k = 0; k < po->nimg; k++) {
+            const orc_camera *cam = &po->s->cams[po->img[k]];
+            float d[4], ray[4];
+            sub4(cam->center, po->pCenter, d); normalized4(d, ray);
+            const float cosa = dot4(ray, nn);
+            if (cosa > 0) {
+                indexes[n] = po->img[k];
+                memcpy(rays[n], ray, sizeof(ray));
+                wScales[n] = cam_get_scale(cam, po->pCenter, refLevel) / cosa;
+                n++;
+            }
+        }
+    }
+    po->nimg = 0;
+    if (n < 2) return 0;
+    wScales[0] = 0.0f;
+    while (n > 0) {
+        int index = 0;
+        for (int j = 1; j < n; j++) if (wScales[j] < wScales[index]) index = j;
+        po->img[po->nimg++] = indexes[index];
+        float ri[4]; memcpy(ri, rays[index], sizeof(ri));
+        int m = 0;
+        for (int j = 0; j < n; j++) {
+            if (j == index) continue;
+            const float ftmp = fminf(threshold, fmaxf(threshold / 2.0f, 1.0f - dot4(ri, rays[j])));
+            const float ws = wScales[j] * (threshold / ftmp);
+            indexes[m] = indexes[j];
+            if (m != j) memcpy(rays[m], rays[j], sizeof(ri));
+            wScales[m] = ws;
+            m++;
+        }
+        n = m;
+    }
+    return po->nimg >= po->o->MIN_IMAGES_PER_PATCH;
+}
+
+/* PatchOptimizer::assureImageAngles, src/hpmvs/PatchOptimizer.cpp:105-123 */
+static int assure_image_angles(popt *po) {
+    float rays[ORC_MAX_IMAGES][4];
+    for (int k = 0; k < po->nimg; k++) {
+        float d[4]; sub4(po->s->cams[po->img[k]].center, po->pCenter, d); normalized4(d, rays[k]);
+    }
+    for (int ii = 0; ii < po->nimg - 1; ii++)
+        for (int jj = ii + 1; jj < po->nimg; jj++) {
+            const float a = acosf(dot4(rays[ii], rays[jj]));
+            if (a < po->o->MAX_ANGLE && a > po->o->MIN_ANGLE) return 1;
+        }
+    return 0;
+}
+
+/* PatchOptimizer::filterImagesByAngle, src/hpmvs/PatchOptimizer.cpp:125-136 */
+static int filter_images_by_angle(popt *po) {
+    int n = 0;
+    for (int k = 0; k < po->nimg; k++) {
+        float d[4], dn[4];
+        sub4(po->s->cams[po->img[k]].center, po->pCenter, d); normalized4(d, dn);
+        if (dot4(dn, po->pNormal) > cosf(po->o->MAX_ANGLE)) po->img[n++] = po->img[k];
+    }
+    po->nimg = n;
+    return po->nimg >= po->o->MIN_IMAGES_PER_PATCH;
+}
+
+/* PatchOptimizer::setRefImage, src/hpmvs/PatchOptimizer.cpp:154-181 */
+static void set_ref_image(popt *po) {
+    if (po->nimg <= 1) return;
+    float incc[ORC_MAX_IMAGES];
+    int refindex = -1;
+    float refncc = 3.402823466e+38f;
+    for (int ii = 0; ii < po->nimg; ii++) {
+        set_inccs(po, incc, po->img, po->nimg, ii, 1);
+        float sum = 0.0f;
+        for (int k = 0; k < po->nimg; k++) sum += incc[k];
+        if (sum < refncc) { refncc = sum; refindex = ii; }
+    }
+    if (refindex < 0) return; /* reference would index out of bounds; cannot happen (sums <= 2V) */
+    const int refIndex = po->img[refindex];
+    for (int i = 0; i < po->nimg; i++)
+        if (po->img[i] == refIndex) {
+            const int itmp = po->img[0];
+            po->img[0] = refIndex;
+            po->img[i] = itmp;
+            break;
+        }
+}
+
+/* PatchOptimizer::setOptimizationFields, src/hpmvs/PatchOptimizer.cpp:384-399 */
+static void set_optimization_fields(popt *po) {
+    const orc_camera *c0 = &po->s->cams[po->img[0]];
+    normalized3(c0->xaxis, po->imgX0);
+    normalized3(c0->yaxis, po->imgY0);
+    normalized3(c0->zaxis, po->imgZ0);
+    memcpy(po->refCenter, po->pCenter, sizeof(float) * 4);
+    float d[4]; sub4(po->refCenter, c0->center, d); normalized4(d, po->refRay);
+    po->depthScale = 1.0f;
+    po->angleScale = (float)(M_PI / 48.0f);
+}
+
+/* PatchOptimizer::setCenterNorm, src/hpmvs/PatchOptimizer.cpp:401-414 */
+static void set_center_norm(popt *po, const double *x) {
+    const float x0 = (float)x[0];
+    for (int k = 0; k < 4; k++) po->pCenter[k] = po->refCenter[k] + (x0 * po->refRay[k]) * po->depthScale;
+    const float angle1 = (float)(x[1] * po->angleScale);
+    const float angle2 = (float)(x[2] * po->angleScale);
+    const float fx = (float)(sin(angle1) * cos(angle2));
+    const float fy = (float)sin(angle2);
+    const float fz = (float)(-cos(angle1) * cos(angle2));
+    for (int k = 0; k < 3; k++)
+        po->pNormal[k] = (po->imgX0[k] * fx + po->imgY0[k] * fy) + po->imgZ0[k] * fz;
+    po->pNormal[3] = 0.0f;
+}
+
+/* PatchOptimizer::parametersFromCenterNorm, src/hpmvs/PatchOptimizer.cpp:416-446 */
+static void parameters_from_center_norm(popt *po, const float *c, const float *n, const double *lb,
+                                        const double *ub, double *x) {
+    float d[4]; sub4(c, po->refCenter, d);
+    x[0] = dot4(d, po->refRay) / po->depthScale;
+    const float fx = dot3(po->imgX0, n), fy = dot3(po->imgY0, n), fz = dot3(po->imgZ0, n);
+    x[2] = asinf(fy);
+    /* std::max(-1.0, std::min(1.0, x[2])) with the std:: NaN semantics (first argument wins) */
+    double t = (x[2] < 1.0) ? x[2] : 1.0;
+    t = (-1.0 < t) ? t : -1.0;
+    const float cosb = (float)cos(t);
+    if (cosb == 0.0) x[1] = 0.0;
+    else {
+        const double sina = fx / cosb;
+        const double cosa = -fz / cosb;
+        double u = (-1.0 < cosa) ? cosa : -1.0;
+        u = (u < 1.0) ? u : 1.0;
+        x[1] = acos(u);
+        if (sina < 0.0) x[1] = -x[1];
+    }
+    x[1] /= po->angleScale;
+    x[2] /= po->angleScale;
+    for (int k = 0; k < 3; k++) {
+        double v = (lb[k] < x[k]) ? x[k] : lb[k]; /* std::max(lb, x) */
+        x[k] = (v < ub[k]) ? v : ub[k];           /* std::min(ub, .) */
+    }
+}
+
+/* PatchOptimizer::objective_fn, src/hpmvs/PatchOptimizer.cpp:286-311 */
+static double objective_fn(popt *po) {
+    calculate_patch_axis(po, po->img[0], po->pNormal, po->pScale);
+    if (!sample_texture(po, po->pCenter, po->pScale, po->pX, po->pY, po->pZ, po->img[0], po->refTex)) return 2.0;
+    double val = 0.0;
+    int nImgs = 0;
+    for (int ii = 1; ii < po->nimg; ii++) {
+        if (!sample_texture(po, po->pCenter, po->pScale, po->pX, po->pY, po->pZ, po->img[ii], po->comTex)) continue;
+        val += robustincc((float)(1.0 - tex_dot(po->refTex, po->comTex)));
+        nImgs++;
+    }
+    if (nImgs < po->o->MIN_IMAGES_PER_PATCH - 1) return 2.0;
+    return val / nImgs;
+}
+
+/* PatchOptimizer::static_objective_fn, src/hpmvs/PatchOptimizer.cpp:313-320 */
+static double static_objective_fn(unsigned n, const double *x, double *grad, void *data) {
+    (void)n; (void)grad;
+    popt *po = (popt *)data;
+    set_center_norm(po, x);
+    return objective_fn(po);
+}
+
+/* ------------------------------------------------------------------------- */
+/* L1': NLopt front end (N1-N3) around BOBYQA                                  */
+
+typedef int (*ref_bobyqa_fn)(int n, int npt, double *x, const double *lb, const double *ub, const double *dx,
+                             double xtol_rel, int maxeval, double *minf, int *nevals, orc_obj_fn f, void *data);
+int orc_port_bobyqa(int n, int npt, double *x, const double *lb, const double *ub, const double *dx,
+                    double xtol_rel, int maxeval, double *minf, int *nevals, orc_obj_fn f, void *data);
+int orc_port_bobyqa_available(void);
+
+static ref_bobyqa_fn g_ref_bobyqa = NULL;
+static int g_ref_tried = 0;
+
+static ref_bobyqa_fn load_ref_bobyqa(void) {
+    if (g_ref_tried) return g_ref_bobyqa;
+    g_ref_tried = 1;
+    Dl_info info;
+    char path[4096];
+    if (dladdr((void *)&load_ref_bobyqa, &info) && info.dli_fname) {
+        snprintf(path, sizeof(path), "%s", info.dli_fname);
+        char *slash = strrchr(path, '/');
+        if (slash) *slash = 0; else snprintf(path, sizeof(path), ".");
+        strncat(path, "/_ref/libref_bobyqa.so", sizeof(path) - strlen(path) - 1);
+        void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (h) g_ref_bobyqa = (ref_bobyqa_fn)dlsym(h, "ref_bobyqa_run");
+    }
+    return g_ref_bobyqa;
+}
+
+int orc_optimizer_available(int which) {
+    if (which == ORC_OPT_REF) return load_ref_bobyqa() ? 0 : -1;
+    return orc_port_bobyqa_available() ? 0 : -1;
+}
+
+static int is_inf(double x) { return fabs(x) >= HUGE_VAL * 0.99 || isinf(x); } /* api/general.c:30-36 */
+
+/* nlopt_optimize_ for LN_BOBYQA: thirdLibs/nlopt-2.4.2/api/optimize.c:368-416, 669-681 with the
+ * default initial step of api/options.c:686-728.  Returns the nlopt_result code. */
+int orc_bobyqa_minimize(int which, int n, orc_obj_fn f, void *data, double *x, const double *lb,
+                        const double *ub, double xtol_rel, int maxeval, double *minf, int *nevals) {
+    *minf = HUGE_VAL;
+    *nevals = 0;
+    for (int i = 0; i < n; i++)
+        if (lb[i] > ub[i] || x[i] < lb[i] || x[i] > ub[i]) return -2; /* NLOPT_INVALID_ARGS */
+    double dx[16];
+    for (int i = 0; i < n; i++) {
+        double step = HUGE_VAL;
+        if (!is_inf(ub[i]) && !is_inf(lb[i]) && (ub[i] - lb[i]) * 0.25 < step && ub[i] > lb[i])
+            step = (ub[i] - lb[i]) * 0.25;
+        if (!is_inf(ub[i]) && ub[i] - x[i] < step && ub[i] > x[i]) step = (ub[i] - x[i]) * 0.75;
+        if (!is_inf(lb[i]) && x[i] - lb[i] < step && x[i] > lb[i]) step = (x[i] - lb[i]) * 0.75;
+        if (is_inf(step)) {
+            if (!is_inf(ub[i]) && fabs(ub[i] - x[i]) < fabs(step)) step = (ub[i] - x[i]) * 1.1;
+            if (!is_inf(lb[i]) && fabs(x[i] - lb[i]) < fabs(step)) step = (x[i] - lb[i]) * 1.1;
+        }
+        if (is_inf(step) || step == 0) step = x[i];
+        if (is_inf(step) || step == 0) step = 1;
+        dx[i] = step;
+    }
+    if (which == ORC_OPT_REF) {
+        ref_bobyqa_fn fn = load_ref_bobyqa();
+        if (!fn) { fprintf(stderr, "oracle: oracle/_ref/libref_bobyqa.so missing\n"); return -1; }
+        return fn(n, 2 * n + 1, x, lb, ub, dx, xtol_rel, maxeval, minf, nevals, f, data);
+    }
+    return orc_port_bobyqa(n, 2 * n + 1, x, lb, ub, dx, xtol_rel, maxeval, minf, nevals, f, data);
+}
+
+/* PatchOptimizer::optimizePatch, src/hpmvs/PatchOptimizer.cpp:322-382 */
+static int optimize_patch(popt *po, int which, orc_patch *diag) {
+    if (po->nimg < po->o->MIN_IMAGES_PER_PATCH) return 0;
+    const double min_angle = -23.99999, max_angle = 23.99999;
+    const double lb[3] = {-HUGE_VAL, min_angle, min_angle};
+    const double ub[3] = {HUGE_VAL, max_angle, max_angle};
+    double x[3] = {0, 0, 0};
+    set_optimization_fields(po);
+    parameters_from_center_norm(po, po->refCenter, po->pNormal, lb, ub, x);
+    double minf;
+    int nevals = 0;
+    const int result = orc_bobyqa_minimize(which, 3, static_objective_fn, po, x, lb, ub, 1.e-7, 1000, &minf, &nevals);
+    diag->nlopt_result = result;
+    diag->nevals = nevals;
+    diag->fmin = minf;
+    diag->x[0] = x[0]; diag->x[1] = x[1]; diag->x[2] = x[2];
+    /* SUCCESS, STOPVAL_REACHED, FTOL_REACHED, XTOL_REACHED; negative codes throw in nlopt.hpp:138-147 */
+    const int success = (result == 1 || result == 2 || result == 3 || result == 4);
+    if (!success) return 0;
+    set_center_norm(po, x);
+    return 1;
+}
+
+/* Scene::getColor(const Patch3d&), src/hpmvs/Scene.cpp:300-327 */
+static void scene_get_color(const orc_scene *s, const float *center, float scale, const int *img, int nimg,
+                            float *out) {
+    float colors[ORC_MAX_IMAGES][3];
+    float norms[ORC_MAX_IMAGES];
+    for (int k = 0; k < nimg; k++) {
+        const orc_camera *cam = &s->cams[img[k]];
+        const int lvl = cam_get_leveli(cam, center, scale, cam->n_levels - 1);
+        float c[3];
+        cam_project(cam, center, lvl, c);
+        img_get_color(&s->imgs[img[k]], c[0], c[1], lvl, colors[k]);
+        norms[k] = sqrtf(dot3(colors[k], colors[k]));
+    }
+    /* std::sort by norm: insertion sort (stable; ties are measure-zero) */
+    int order[ORC_MAX_IMAGES];
+    for (int k = 0; k < nimg; k++) order[k] = k;
+    for (int i = 1; i < nimg; i++) {
+        const int v = order[i];
+        int j = i - 1;
+        while (j >= 0 && norms[order[j]] > norms[v]) { order[j + 1] = order[j]; j--; }
+        order[j + 1] = v;
+    }
+    const int med = order[nimg / 2];
+    const int pick = (norms[med] > 250.0) ? order[0] : med;
+    out[0] = colors[pick][0]; out[1] = colors[pick][1]; out[2] = colors[pick][2];
+}
+
+static void popt_begin(popt *po, const orc_scene *s, const orc_options *o, const orc_patch *p) {
+    memset(po, 0, sizeof(*po));
+    po->s = s; po->o = o;
+    memcpy(po->pCenter, p->center, sizeof(float) * 4);
+    memcpy(po->pNormal, p->normal, sizeof(float) * 4);
+    po->pScale = p->scale;
+    po->nimg = p->n_images;
+    memcpy(po->img, p->images, sizeof(int) * (size_t)p->n_images);
+}
+
+/* PatchOptimizer::optimize + runOptimization, src/hpmvs/PatchOptimizer.cpp:48-103 */
+int orc_optimize(const orc_scene *s, const orc_options *o, orc_patch *p, int which) {
+    popt po;
+    popt_begin(&po, s, o, p);
+    p->nlopt_result = 0; p->nevals = 0; p->fmin = 0; p->x[0] = p->x[1] = p->x[2] = 0;
+    int stage = 0;
+    do {
+        stage = 1; if (!add_images(&po)) break;
+        stage = 2; if (!filter_images_ncc(&po, o->NCC_ALPHA_1)) break;
+        sort_images(&po); /* return value ignored, PatchOptimizer.cpp:54 */
+        stage = 3; if (!assure_image_angles(&po)) break;
+        stage = 4; if (!optimize_patch(&po, which, p)) break;
+        stage = 5; if (!add_images(&po)) break;
+        stage = 6; if (!filter_images_ncc(&po, o->NCC_ALPHA_2)) break;
+        stage = 7; if (!filter_images_by_angle(&po)) break;
+        stage = 8; if (!assure_image_angles(&po)) break;
+        set_ref_image(&po);
+        stage = 9; if (!filter_images_ncc(&po, o->NCC_ALPHA_2)) break;
+        stage = 0;
+    } while (0);
+    p->stage = stage;
+    p->ngrabs = po.ngrabs;
+    p->ngrabs_all = po.ngrabs_all;
+    if (stage != 0) return 0; /* patch untouched on failure (PatchOptimizer.cpp:86-87) */
+    memcpy(p->center, po.pCenter, sizeof(float) * 4);
+    memcpy(p->normal, po.pNormal, sizeof(float) * 4);
+    p->scale = po.pScale;
+    p->n_images = po.nimg;
+    memcpy(p->images, po.img, sizeof(int) * (size_t)po.nimg);
+    p->ncc_const = 1.4f;
+    scene_get_color(s, p->center, p->scale, p->images, p->n_images, p->color);
+    return 1;
+}
+
+void orc_optimize_batch(const orc_scene *s, const orc_options *o, orc_patch *p, int n, int which, int n_threads) {
+    /* the reference's data-parallel form: src/hpmvs/Scene.cpp:94-96,114,166-167 */
+    (void)n_threads;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(n_threads > 0 ? n_threads : 1)
+    for (int i = 0; i < n; i++) orc_optimize(s, o, &p[i], which);
+}
+
+double orc_objective_at(const orc_scene *s, const orc_options *o, const orc_patch *p, const double x[3]) {
+    popt po;
+    popt_begin(&po, s, o, p);
+    set_optimization_fields(&po);
+    return static_objective_fn(3, x, NULL, &po);
+}
+
+void orc_initial_parameters(const orc_scene *s, const orc_options *o, const orc_patch *p, double x[3]) {
+    popt po;
+    popt_begin(&po, s, o, p);
+    set_optimization_fields(&po);
+    const double lb[3] = {-HUGE_VAL, -23.99999, -23.99999}, ub[3] = {HUGE_VAL, 23.99999, 23.99999};
+    parameters_from_center_norm(&po, po.refCenter, po.pNormal, lb, ub, x);
+}
+
+void orc_inccs(const orc_scene *s, const orc_options *o, const orc_patch *p, int ref_idx, int robust, float *out) {
+    popt po;
+    popt_begin(&po, s, o, p);
+    set_inccs(&po, out, po.img, po.nimg, ref_idx, robust);
+}
+
+int orc_sample_texture(const orc_scene *s, const orc_options *o, const orc_patch *p, int ref_slot, int slot,
+                       float *tex147, int *level, float *cdxdy6) {
+    popt po;
+    popt_begin(&po, s, o, p);
+    calculate_patch_axis(&po, po.img[ref_slot], po.pNormal, po.pScale);
+    const int ok = sample_texture(&po, po.pCenter, po.pScale, po.pX, po.pY, po.pZ, po.img[slot], tex147);
+    if (ok) { *level = po.last_level; memcpy(cdxdy6, po.last_cdxdy, sizeof(float) * 6); }
+    return ok;
+}

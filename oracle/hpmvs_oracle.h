@@ -1,0 +1,136 @@
+/*
+ * hpmvs_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the reference's patch-refinement hot path
+ * (mo3d::PatchOptimizer::optimize and everything below it), used ONLY by
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the
+ * checker for the HIP path.  Nothing under hpmvs_amd/ may include, link or
+ * call this.
+ *
+ * Parity status: the photometric part (everything except BOBYQA) is a
+ * restatement of reference sources that cannot be compiled here (Eigen3, glog
+ * absent) and the reference ships no tests/golden vectors for it -> "parity
+ * unpinned" for that part, anchored only by analytic known-answer tests.  The
+ * optimiser part is pinned: it runs the reference's genuine vendored NLopt
+ * 2.4.2 BOBYQA, compiled in place from /root/reference into oracle/_ref/
+ * (see oracle/Makefile), and the own C port (oracle/bobyqa_port.c) is checked
+ * against it evaluation by evaluation.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference root).
+ */
+#ifndef HPMVS_ORACLE_H
+#define HPMVS_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_LEVELS 8
+#define ORC_MAX_IMAGES 64 /* cap on images attached to one patch (reference: unbounded vector) */
+
+/* include/hpmvs/HpmvsOptions.h:29-58 (only the fields the path reads) */
+typedef struct {
+    int MAXLEVEL;              /* 5 */
+    int MINLEVEL;              /* 0 */
+    float MAX_ANGLE;           /* 60 deg */
+    float MIN_ANGLE;           /* 10 deg */
+    int MAX_IMAGES_PER_PATCH;  /* 6 (dead in the reference) */
+    int MIN_IMAGES_PER_PATCH;  /* 3 */
+    float NCC_ALPHA_1;         /* 0.4 */
+    float NCC_ALPHA_2;         /* 0.5 */
+} orc_options;
+
+/* include/hpmvs/Camera.h:87-105 */
+typedef struct {
+    int n_levels;
+    float P[ORC_MAX_LEVELS][12]; /* row-major 3x4 per level */
+    float K0[9];                 /* row-major 3x3, level 0 */
+    float center[4];
+    float oaxis[4];
+    float xaxis[3], yaxis[3], zaxis[3];
+} orc_camera;
+
+/* include/hpmvs/Image.h:89-115 storage: interleaved u8 RGB per level */
+typedef struct {
+    int n_levels;
+    int w[ORC_MAX_LEVELS], h[ORC_MAX_LEVELS];
+    uint8_t *pix[ORC_MAX_LEVELS];
+} orc_image;
+
+typedef struct {
+    int n_views;
+    orc_camera *cams;
+    orc_image *imgs;
+    int *covis_off; /* n_views+1 */
+    int *covis;     /* flattened lists */
+} orc_scene;
+
+/* I/O record of optimize(): include/hpmvs/Patch3d.h:33-83 */
+typedef struct {
+    float center[4];
+    float normal[4];
+    float scale;
+    int n_images;
+    int images[ORC_MAX_IMAGES];
+    /* outputs (valid when ok) */
+    float ncc_const; /* 1.4f, PatchOptimizer.cpp:95 */
+    float color[3];
+    /* diagnostics the reference discards */
+    double fmin;   /* final mean robust INCC (minf) */
+    double x[3];   /* final optimiser variables */
+    int nlopt_result;
+    int nevals;
+    int stage;     /* 0 = ok, else index of the pipeline stage that returned false */
+    long ngrabs;   /* sampleTexture calls that passed the gates (588 B each) */
+    long ngrabs_all; /* all sampleTexture calls */
+} orc_patch;
+
+enum { ORC_OPT_REF = 0, ORC_OPT_PORT = 1 };
+
+void orc_default_options(orc_options *o);
+
+orc_scene *orc_scene_create(int n_views);
+void orc_scene_destroy(orc_scene *s);
+/* Camera::init (src/hpmvs/Camera.cpp:34-81) + Image::load pyramid (src/hpmvs/Image.cpp:41-66) */
+void orc_scene_set_view(orc_scene *s, int i, int w, int h, const uint8_t *rgb_l0,
+                        double f, const double q_wxyz[4], const double c[3], int max_level);
+void orc_scene_set_covis(orc_scene *s, int i, const int *ids, int n);
+const orc_camera *orc_scene_camera(const orc_scene *s, int i);
+const uint8_t *orc_scene_level(const orc_scene *s, int i, int level, int *w, int *h);
+
+/* thirdLibs/cimg/CImg.h:21189-21203 on interleaved RGB */
+void orc_half_resize(const uint8_t *src, int w, int h, uint8_t *dst);
+
+/* 0 if the chosen optimiser back-end is available */
+int orc_optimizer_available(int which);
+
+/* PatchOptimizer::optimize, src/hpmvs/PatchOptimizer.cpp:78-103. returns 1 on success */
+int orc_optimize(const orc_scene *s, const orc_options *o, orc_patch *p, int which_optimizer);
+void orc_optimize_batch(const orc_scene *s, const orc_options *o, orc_patch *p, int n,
+                        int which_optimizer, int n_threads);
+
+/* objective_fn at given optimiser variables x (PatchOptimizer.cpp:286-320) for the patch's
+ * current image list; the seed centre/normal define refCenter_/refRay_/axes as optimizePatch does. */
+double orc_objective_at(const orc_scene *s, const orc_options *o, const orc_patch *p, const double x[3]);
+/* parametersFromCenterNorm for the seed (PatchOptimizer.cpp:416-446) */
+void orc_initial_parameters(const orc_scene *s, const orc_options *o, const orc_patch *p, double x[3]);
+/* setINCCs (PatchOptimizer.cpp:448-474) */
+void orc_inccs(const orc_scene *s, const orc_options *o, const orc_patch *p, int ref_idx, int robust,
+               float *out);
+/* one sampleTexture (PatchOptimizer.cpp:476-529) with axes from calculatePatchAxis(ref image) */
+int orc_sample_texture(const orc_scene *s, const orc_options *o, const orc_patch *p, int ref_slot,
+                       int slot, float *tex147, int *level, float *cdxdy6);
+
+/* optimiser-only entry (for pinning the port against the genuine library):
+ * minimise f over 3 variables exactly as PatchOptimizer.cpp:348-365 configures NLopt */
+typedef double (*orc_obj_fn)(unsigned n, const double *x, double *grad, void *data);
+int orc_bobyqa_minimize(int which, int n, orc_obj_fn f, void *data, double *x, const double *lb,
+                        const double *ub, double xtol_rel, int maxeval, double *minf, int *nevals);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,201 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Product code under hpmvs_amd/ must never import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_IMAGES = 64
+MAX_LEVELS = 8
+OPT_REF, OPT_PORT = 0, 1
+
+
+class Options(C.Structure):
+    _fields_ = [("MAXLEVEL", C.c_int), ("MINLEVEL", C.c_int), ("MAX_ANGLE", C.c_float), ("MIN_ANGLE", C.c_float),
+                ("MAX_IMAGES_PER_PATCH", C.c_int), ("MIN_IMAGES_PER_PATCH", C.c_int),
+                ("NCC_ALPHA_1", C.c_float), ("NCC_ALPHA_2", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("n_levels", C.c_int), ("P", (C.c_float * 12) * MAX_LEVELS), ("K0", C.c_float * 9),
+                ("center", C.c_float * 4), ("oaxis", C.c_float * 4), ("xaxis", C.c_float * 3),
+                ("yaxis", C.c_float * 3), ("zaxis", C.c_float * 3)]
+
+
+class Patch(C.Structure):
+    _fields_ = [("center", C.c_float * 4), ("normal", C.c_float * 4), ("scale", C.c_float),
+                ("n_images", C.c_int), ("images", C.c_int * MAX_IMAGES), ("ncc_const", C.c_float),
+                ("color", C.c_float * 3), ("fmin", C.c_double), ("x", C.c_double * 3),
+                ("nlopt_result", C.c_int), ("nevals", C.c_int), ("stage", C.c_int),
+                ("ngrabs", C.c_long), ("ngrabs_all", C.c_long)]
+
+
+OBJ_FN = C.CFUNCTYPE(C.c_double, C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+
+_lib = None
+
+
+def build(force: bool = False):
+    """Compile oracle/liboracle.so (and oracle/_ref when /root/reference is present)."""
+    so = os.path.join(HERE, "liboracle.so")
+    if force or not os.path.exists(so) or os.path.exists("/root/reference/thirdLibs/nlopt-2.4.2"):
+        subprocess.run(["make", "-C", HERE, "-s"], check=True, capture_output=True)
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = os.path.join(HERE, "liboracle.so")
+    if not os.path.exists(so):
+        build()
+    L = C.CDLL(so)
+    L.orc_scene_create.restype = C.c_void_p
+    L.orc_scene_create.argtypes = [C.c_int]
+    L.orc_scene_destroy.argtypes = [C.c_void_p]
+    L.orc_scene_set_view.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double,
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+    L.orc_scene_set_covis.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
+    L.orc_scene_camera.restype = C.POINTER(Camera)
+    L.orc_scene_camera.argtypes = [C.c_void_p, C.c_int]
+    L.orc_scene_level.restype = C.POINTER(C.c_uint8)
+    L.orc_scene_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_half_resize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.orc_default_options.argtypes = [C.POINTER(Options)]
+    L.orc_optimizer_available.argtypes = [C.c_int]
+    L.orc_optimize.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Patch), C.c_int]
+    L.orc_optimize_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Patch), C.c_int, C.c_int, C.c_int]
+    L.orc_objective_at.restype = C.c_double
+    L.orc_objective_at.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Patch), C.POINTER(C.c_double)]
+    L.orc_initial_parameters.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Patch), C.POINTER(C.c_double)]
+    L.orc_inccs.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Patch), C.c_int, C.c_int,
+                            C.POINTER(C.c_float)]
+    L.orc_sample_texture.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Patch), C.c_int, C.c_int,
+                                     C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float)]
+    L.orc_bobyqa_minimize.argtypes = [C.c_int, C.c_int, OBJ_FN, C.c_void_p, C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_int,
+                                      C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+def default_options() -> Options:
+    o = Options()
+    lib().orc_default_options(C.byref(o))
+    return o
+
+
+def optimizer_available(which: int) -> bool:
+    return lib().orc_optimizer_available(which) == 0
+
+
+def best_optimizer() -> int:
+    """Genuine NLopt BOBYQA when oracle/_ref travelled, else the own port."""
+    if optimizer_available(OPT_REF):
+        return OPT_REF
+    if optimizer_available(OPT_PORT):
+        return OPT_PORT
+    raise RuntimeError("oracle: neither oracle/_ref/libref_bobyqa.so nor the BOBYQA port is available")
+
+
+class OracleScene:
+    """Scene::addCameras + extractCoVisiblilty state for the oracle (reference Scene.cpp:42-88, 241-298)."""
+
+    def __init__(self, synth_scene):
+        L = lib()
+        self.n_views = synth_scene.n_views
+        self.max_level = synth_scene.max_level
+        self.h = L.orc_scene_create(self.n_views)
+        for i, v in enumerate(synth_scene.views):
+            rgb = v.rgb
+            if not isinstance(rgb, np.ndarray):
+                rgb = rgb.cpu().numpy()
+            rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+            q = (C.c_double * 4)(*[float(t) for t in v.q])
+            c = (C.c_double * 3)(*[float(t) for t in v.c])
+            L.orc_scene_set_view(self.h, i, v.width, v.height, rgb.ctypes.data, float(v.f), q, c, self.max_level)
+        for i, lst in enumerate(synth_scene.covis):
+            arr = (C.c_int * max(1, len(lst)))(*lst)
+            L.orc_scene_set_covis(self.h, i, arr, len(lst))
+
+    def __del__(self):
+        try:
+            lib().orc_scene_destroy(self.h)
+        except Exception:
+            pass
+
+    def camera(self, i) -> Camera:
+        return lib().orc_scene_camera(self.h, i).contents
+
+    def level(self, i, level) -> np.ndarray:
+        w, h = C.c_int(), C.c_int()
+        p = lib().orc_scene_level(self.h, i, level, C.byref(w), C.byref(h))
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
+
+
+def patches_from_seeds(seeds, idx=None):
+    idx = range(len(seeds.scale)) if idx is None else idx
+    arr = (Patch * len(idx))()
+    for k, i in enumerate(idx):
+        p = arr[k]
+        p.center[:] = seeds.center[i].tolist()
+        p.normal[:] = seeds.normal[i].tolist()
+        p.scale = float(seeds.scale[i])
+        n = int(seeds.n_images[i])
+        p.n_images = n
+        for j in range(n):
+            p.images[j] = int(seeds.images[i, j])
+    return arr
+
+
+def optimize_batch(scene: OracleScene, patches, which=None, options=None, n_threads=1):
+    L = lib()
+    which = best_optimizer() if which is None else which
+    o = options or default_options()
+    L.orc_optimize_batch(scene.h, C.byref(o), patches, len(patches), which, n_threads)
+    return patches
+
+
+def objective_at(scene: OracleScene, patch: Patch, x, options=None) -> float:
+    o = options or default_options()
+    xx = (C.c_double * 3)(*x)
+    return lib().orc_objective_at(scene.h, C.byref(o), C.byref(patch), xx)
+
+
+def initial_parameters(scene: OracleScene, patch: Patch, options=None):
+    o = options or default_options()
+    xx = (C.c_double * 3)()
+    lib().orc_initial_parameters(scene.h, C.byref(o), C.byref(patch), xx)
+    return [xx[0], xx[1], xx[2]]
+
+
+def inccs(scene: OracleScene, patch: Patch, ref_idx=0, robust=0, options=None):
+    o = options or default_options()
+    out = (C.c_float * MAX_IMAGES)()
+    lib().orc_inccs(scene.h, C.byref(o), C.byref(patch), ref_idx, robust, out)
+    return np.array(out[:patch.n_images], dtype=np.float32)
+
+
+def sample_texture(scene: OracleScene, patch: Patch, ref_slot, slot, options=None):
+    o = options or default_options()
+    tex = (C.c_float * 147)()
+    lvl = C.c_int()
+    geo = (C.c_float * 6)()
+    ok = lib().orc_sample_texture(scene.h, C.byref(o), C.byref(patch), ref_slot, slot, tex, C.byref(lvl), geo)
+    return bool(ok), np.array(tex, dtype=np.float32), lvl.value, np.array(geo, dtype=np.float32)
+
+
+def half_resize(img: np.ndarray) -> np.ndarray:
+    h, w, _ = img.shape
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.zeros((h // 2, w // 2, 3), dtype=np.uint8)
+    lib().orc_half_resize(img.ctypes.data, w, h, out.ctypes.data)
+    return out

@@ -1,0 +1,64 @@
+"""GPU parity of the photometric kernels against the CPU oracle (through the C ABI).
+
+Tolerances (float32 path; the GPU uses FMA contraction and tree-shaped wave reductions where the
+reference sums sequentially):
+  pyramid            : bit-exact (u8)
+  setINCCs entries   : |d| <= 2e-5
+  objective_fn value : |d| <= 2e-5   (SURVEY 8d proposed 1e-4)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pyramid_bit_exact(tiny_scene, oracle_scene, gpu_scene):
+    for view in range(tiny_scene.n_views):
+        for level in range(6):
+            a = oracle_scene.level(view, level)
+            b = gpu_scene.level(view, level)
+            assert a.shape == b.shape
+            assert np.array_equal(a, b), f"view {view} level {level}: {(a != b).sum()} bytes differ"
+
+
+def test_pyramid_odd_sizes():
+    from hpmvs_amd import api
+    from oracle import oracle as orc
+    rng = np.random.default_rng(7)
+    for (h, w) in [(2, 2), (3, 5), (7, 9), (33, 17), (101, 257), (480, 641)]:
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        assert np.array_equal(orc.half_resize(img), api.build_pyramid(img)), (h, w)
+
+
+def test_inccs_parity(tiny_seeds, oracle_scene, gpu_scene):
+    from hpmvs_amd import api
+    from oracle import oracle as orc
+    idx = np.nonzero(tiny_seeds.n_images >= 2)[0]
+    batch = api.Batch.from_seeds(tiny_seeds, idx)
+    P = orc.patches_from_seeds(tiny_seeds, idx)
+    for ref_idx, robust in [(0, 0), (0, 1), (1, 1)]:
+        got = api.inccs_batch(gpu_scene, batch, ref_idx, robust)
+        worst = 0.0
+        for k in range(len(idx)):
+            want = orc.inccs(oracle_scene, P[k], ref_idx, robust)
+            n = P[k].n_images
+            worst = max(worst, float(np.abs(got[k, :n] - want).max()))
+        assert worst <= 2e-5, (ref_idx, robust, worst)
+
+
+def test_objective_parity(tiny_seeds, oracle_scene, gpu_scene):
+    from hpmvs_amd import api
+    from oracle import oracle as orc
+    idx = np.nonzero(tiny_seeds.n_images >= 3)[0]
+    batch = api.Batch.from_seeds(tiny_seeds, idx)
+    P = orc.patches_from_seeds(tiny_seeds, idx)
+    rng = np.random.default_rng(11)
+    x0 = np.array([orc.initial_parameters(oracle_scene, P[k]) for k in range(len(idx))])
+    for trial in range(4):
+        x = x0 + (rng.uniform(-1, 1, size=x0.shape) * np.array([0.3, 2.0, 2.0]) if trial else 0.0)
+        f_gpu, g_gpu = api.objective_batch(gpu_scene, batch, x)
+        f_cpu = np.array([orc.objective_at(oracle_scene, P[k], x[k]) for k in range(len(idx))])
+        # plateau decisions (2.0) must agree exactly, values within tolerance
+        assert np.array_equal(f_gpu == 2.0, f_cpu == 2.0)
+        assert np.abs(f_gpu - f_cpu).max() <= 2e-5, np.abs(f_gpu - f_cpu).max()
+        assert (f_cpu < 2.0).sum() > 10
