@@ -1,0 +1,26 @@
+// Host build of the product's BOBYQA state machine (hpmvs_amd/csrc/bobyqa3.hpp) behind a callback
+// interface, so CPU tests can pin it against the genuine NLopt library (oracle/_ref).
+#include <cstring>
+#include <vector>
+#include "../../hpmvs_amd/csrc/bobyqa3.hpp"
+
+using namespace hpmvs;
+typedef double (*obj_fn)(unsigned n, const double* x, double* grad, void* data);
+
+extern "C" int bq3_minimize(obj_fn f, void* data, double* x, const double* lb, const double* ub, double xtol_rel,
+                            int maxeval, double* minf, int* nevals, double* trace, int trace_cap) {
+    Bobyqa3 B;
+    double dx[3];
+    bq_default_step(x, lb, ub, dx);
+    int st = bq_start(B, x, lb, ub, dx, xtol_rel, maxeval);
+    int nt = 0;
+    while (st == BQ_CONTINUE) {
+        const double fv = f(3, B.xeval, nullptr, data);
+        if (trace && nt < trace_cap) { std::memcpy(trace + 4 * nt, B.xeval, 24); trace[4 * nt + 3] = fv; nt++; }
+        st = bq_step(B, fv);
+    }
+    for (int i = 0; i < 3; i++) x[i] = B.xfinal[i];
+    *minf = B.minf;
+    *nevals = B.nevals;
+    return B.rc;
+}
