@@ -1,6 +1,404 @@
-// kernel_optimize.hip -- placeholder until the refinement kernel lands.
+// kernel_optimize.hip -- the batched PatchOptimizer::optimize kernel for gfx950.
+//
+// Mapping (MI355X-first, not a translation of the reference's one-thread-per-patch OpenMP loop):
+//
+//   * A persistent grid of single-wave workgroups pulls patches from a global work queue.
+//   * Each of the 64 LANES of a wave owns one patch ("slot") and runs that patch's control
+//     logic as plain SIMT code: the optimize() pipeline of the reference
+//     (src/hpmvs/PatchOptimizer.cpp:48-103: addImages / filterImagesNCC / sortImages /
+//     assureImageAngles / optimizePatch / ... / setRefImage) and the BOBYQA state machine
+//     (bobyqa3.hpp).  This is "phase A"; it ends when the lane needs photometric data.
+//   * Photometric work is done by the WHOLE WAVE for one patch at a time ("phase B"): the wave
+//     loops over the lanes that posted a request, broadcasts the request (centre, normal, scale,
+//     image list) with v_readlane, and evaluates it with wave_eval_rt (photometric.hpp): lane v
+//     prepares image v, lanes 0..48 fetch the 7x7 window texels, DPP reductions give mean /
+//     variance / NCC.  The scalar result goes back to the requesting lane.
+//
+//   So the optimiser algebra (float64, ~1-2 kflop per iteration) costs 1/64 of a wave per patch
+//   instead of a whole wave, and the texture sampling keeps 49 of 64 lanes busy with coalescable
+//   8-byte taps.  Patches finish at different times (40-1000 evaluations); a finished lane
+//   immediately pulls the next patch from the queue, so lanes stay busy until the queue drains.
+//
+//   Per-lane optimiser state lives in private memory (the compiler's scratch, lane-interleaved
+//   and therefore coalesced); per-lane image lists live in LDS (uint16 ids, padded rows).
 #include <hip/hip_runtime.h>
+
+#include "bobyqa3.hpp"
 #include "launch.h"
+#include "photometric.hpp"
+
 namespace hpmvs {
-void launch_optimize(const DevScene&, const DevOptions&, const DevBatch&, int32_t*, int, hipStream_t) {}
+
+namespace {
+
+constexpr int kRow = 66;  // uint16 per LDS row: 64 ids + 2 pad -> row stride 33 dwords, conflict-free per lane
+
+enum Op { OP_NONE = 0, OP_OBJ = 1, OP_INCC = 2, OP_REFSUM = 3 };
+enum Stage {
+    S_FETCH = 0, S_F1, S_BQ, S_F2, S_RS, S_F3, S_IDLE
+};
+
+__device__ __forceinline__ void ray_to_cam(const DevView& V, const float* c, float* ray) {
+    // (camera.center_ - pCenter).normalized() on 4-vectors whose w components cancel
+    const float d[3] = {V.center[0] - c[0], V.center[1] - c[1], V.center[2] - c[2]};
+    normalized3f(d, ray);
 }
+
+// PatchOptimizer::addImages (PatchOptimizer.cpp:225-258).  Returns the new count, or -1 on overflow.
+__device__ int add_images(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg, const float* c,
+                          const float* n, float scale) {
+    if (nimg <= 0) return 0;
+    const int ref = row[0];
+    const int existing = nimg;
+    const int beg = sc.covis_off[ref], end = sc.covis_off[ref + 1];
+    for (int ci = beg; ci < end; ci++) {
+        const int cv = sc.covis[ci];
+        bool found = false;
+        for (int k = 0; k < existing; k++) found |= (row[k] == cv);
+        if (found) continue;
+        const DevView& V = sc.views[cv];
+        float ray[3];
+        ray_to_cam(V, c, ray);
+        if (dot3f(ray, n) < o.cos_max_f) continue;
+        // Camera::getLevel (Camera.cpp:92-95) then std::round
+        const float dd[3] = {c[0] - V.center[0], c[1] - V.center[1], c[2] - V.center[2]};
+        const float fz = sqrtf(dot3f(dd, dd));
+        const float lv = (float)log2((double)(scale * V.fsum) / (2.0 * (double)fz));
+        const int il = (int)roundf(lv);
+        if (il < o.MINLEVEL || il >= o.MAXLEVEL - 2) continue;
+        float P[12];
+        for (int k = 0; k < 12; k++) P[k] = V.P0[k];
+        float u, v;
+        project0(P, c[0], c[1], c[2], u, v);
+        const float s = __int_as_float((127 - il) << 23);
+        u *= s; v *= s;
+        if (u < 0.0f || (float)(V.w[il] - 1) <= u || v < 0.0f || (float)(V.h[il] - 1) <= v) continue;
+        if (nimg >= kMaxImages) return -1;
+        row[nimg++] = (uint16_t)cv;
+    }
+    return nimg;
+}
+
+// PatchOptimizer::sortImages + getAngleWeightedScales (PatchOptimizer.cpp:183-223, 260-284).
+// Rewrites the row; returns the new count (the reference ignores the boolean result).
+__device__ int sort_images(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg, const float* c,
+                           const float* n, float scale) {
+    uint16_t idx[kMaxImages];
+    float ws[kMaxImages];
+    float rays[kMaxImages][3];
+    int m = 0;
+    if (nimg > 0) {
+        const DevView& V0 = sc.views[row[0]];
+        const float dd[3] = {c[0] - V0.center[0], c[1] - V0.center[1], c[2] - V0.center[2]};
+        const float fz0 = sqrtf(dot3f(dd, dd));
+        int refLevel = (int)roundf((float)log2((double)(scale * V0.fsum) / (2.0 * (double)fz0)));
+        refLevel = refLevel < o.MAXLEVEL - 1 ? refLevel : o.MAXLEVEL - 1;
+        refLevel = refLevel > 0 ? refLevel : 0;
+        float nn[3];
+        normalized3f(n, nn);
+        for (int k = 0; k < nimg; k++) {
+            const DevView& V = sc.views[row[k]];
+            float ray[3];
+            ray_to_cam(V, c, ray);
+            const float cosa = dot3f(ray, nn);
+            if (cosa > 0.0f) {
+                idx[m] = row[k];
+                rays[m][0] = ray[0]; rays[m][1] = ray[1]; rays[m][2] = ray[2];
+                // Camera::getScale (Camera.cpp:83-90)
+                const float e[3] = {c[0] - V.center[0], c[1] - V.center[1], c[2] - V.center[2]};
+                const float fz = sqrtf(dot3f(e, e));
+                const float sc_ = (V.fsum == 0.0f) ? 1.0f : (float)(2.0 * (double)fz * (double)(1 << refLevel) / (double)V.fsum);
+                ws[m] = sc_ / cosa;
+                m++;
+            }
+        }
+    }
+    if (m < 2) return 0;  // pImages_ was cleared
+    ws[0] = 0.0f;
+    const float thr = o.sort_thr;
+    int out = 0;
+    while (m > 0) {
+        int best = 0;
+        for (int j = 1; j < m; j++)
+            if (ws[j] < ws[best]) best = j;
+        row[out++] = idx[best];
+        const float rb[3] = {rays[best][0], rays[best][1], rays[best][2]};
+        int q = 0;
+        for (int j = 0; j < m; j++) {
+            if (j == best) continue;
+            const float ftmp = fminf(thr, fmaxf(thr / 2.0f, 1.0f - dot3f(rb, rays[j])));
+            const float w = ws[j] * (thr / ftmp);
+            idx[q] = idx[j];
+            rays[q][0] = rays[j][0]; rays[q][1] = rays[j][1]; rays[q][2] = rays[j][2];
+            ws[q] = w;
+            q++;
+        }
+        m = q;
+    }
+    return out;
+}
+
+// PatchOptimizer::assureImageAngles (PatchOptimizer.cpp:105-123)
+__device__ bool assure_image_angles(const DevScene& sc, const DevOptions& o, const uint16_t* row, int nimg,
+                                    const float* c) {
+    for (int ii = 0; ii < nimg - 1; ii++) {
+        float ri[3];
+        ray_to_cam(sc.views[row[ii]], c, ri);
+        for (int jj = ii + 1; jj < nimg; jj++) {
+            float rj[3];
+            ray_to_cam(sc.views[row[jj]], c, rj);
+            const float a = acosf(dot3f(ri, rj));
+            if (a < o.MAX_ANGLE && a > o.MIN_ANGLE) return true;
+        }
+    }
+    return false;
+}
+
+// PatchOptimizer::filterImagesByAngle (PatchOptimizer.cpp:125-136)
+__device__ int filter_images_by_angle(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg,
+                                      const float* c, const float* n) {
+    int m = 0;
+    for (int k = 0; k < nimg; k++) {
+        float ray[3];
+        ray_to_cam(sc.views[row[k]], c, ray);
+        if (dot3f(ray, n) > o.cos_max_f) row[m++] = row[k];
+    }
+    return m;
+}
+
+// keep image 0 and the images whose bit is set (PatchOptimizer.cpp:144-151)
+__device__ int apply_keep_mask(uint16_t* row, int nimg, unsigned long long keep) {
+    int m = 1;
+    for (int i = 1; i < nimg; i++)
+        if ((keep >> i) & 1ull) row[m++] = row[i];
+    return m;
+}
+
+// Scene::getColor(const Patch3d&) (Scene.cpp:300-327): bilinear colour at the projected centre in
+// every attached image, median by norm (darkest if the median is brighter than 250).
+__device__ void colour_at(const DevView& V, const float* c, float scale, float* rgb) {
+    const float dd[3] = {c[0] - V.center[0], c[1] - V.center[1], c[2] - V.center[2]};
+    const float fz = sqrtf(dot3f(dd, dd));
+    const int lvl = level_clamped(scale, V.fsum, fz, V.n_levels - 1);
+    float P[12];
+    for (int k = 0; k < 12; k++) P[k] = V.P0[k];
+    float x, y;
+    project0(P, c[0], c[1], c[2], x, y);
+    const float s = __int_as_float((127 - lvl) << 23);
+    x *= s; y *= s;
+    const int W = V.w[lvl];
+    const int lx = (int)x, ly = (int)y;
+    const uint8_t* p0 = V.pix[lvl] + 3 * (ly * W + lx);
+    const uint8_t* p1 = p0 + 3 * W;
+    const float dx1 = x - (float)lx, dx0 = 1.0f - dx1;
+    const float dy1 = y - (float)ly, dy0 = 1.0f - dy1;
+    const float f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
+    for (int ch = 0; ch < 3; ch++) {
+        float v = (float)p0[ch] * f00 + (float)p1[ch] * f01;
+        v += (float)p0[3 + ch] * f10 + (float)p1[3 + ch] * f11;
+        rgb[ch] = v;
+    }
+}
+
+__device__ void patch_colour(const DevScene& sc, const uint16_t* row, int nimg, const float* c, float scale,
+                             float* out) {
+    float norms[kMaxImages];
+    for (int k = 0; k < nimg; k++) {
+        float rgb[3];
+        colour_at(sc.views[row[k]], c, scale, rgb);
+        norms[k] = sqrtf(dot3f(rgb, rgb));
+    }
+    // rank selection instead of std::sort: element of rank nimg/2 and the minimum
+    const int want = nimg / 2;
+    int med = 0, mn = 0;
+    for (int k = 0; k < nimg; k++) {
+        int rank = 0;
+        for (int j = 0; j < nimg; j++) rank += (norms[j] < norms[k]) || (norms[j] == norms[k] && j < k);
+        if (rank == want) med = k;
+        if (rank == 0) mn = k;
+    }
+    const int pick = (norms[med] > 250.0f) ? mn : med;
+    colour_at(sc.views[row[pick]], c, scale, out);
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(64) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
+    __shared__ uint16_t lists[64 * kRow];
+    const int lane = lane_id();
+    uint16_t* row = &lists[lane * kRow];
+
+    // ---- per-lane slot state
+    int stage = S_FETCH;
+    int idx = -1, nimg = 0, ii = 0, refindex = -1, ngrabs = 0, fail_stage = 0, nl_result = 0;
+    float c0[3] = {0, 0, 0}, n0[3] = {0, 0, 0};  // optimize() input (kept for "patch untouched")
+    float c[3] = {0, 0, 0}, n[3] = {0, 0, 1};    // pCenter_, pNormal_
+    float scale = 1.0f, refbest = 0.0f;
+    OptFields F;
+    Bobyqa3 B;
+    B.nevals = 0; B.minf = 0.0; B.rc = 0; B.xfinal[0] = B.xfinal[1] = B.xfinal[2] = 0.0;
+    // request posted to phase B
+    int op = OP_NONE, req_ref = 0, req_robust = 0;
+    float req_thr = 0.0f;
+    // results delivered by phase B
+    double res_f = 0.0;
+    unsigned long long res_mask = 0ull;
+    float res_sum = 0.0f;
+    const double lbv[3] = {-HUGE_VAL, -23.99999, -23.99999};  // PatchOptimizer.cpp:326-336
+    const double ubv[3] = {HUGE_VAL, 23.99999, 23.99999};
+
+    for (;;) {
+        // ================= phase A: every lane advances its own patch until it needs the wave
+        while (op == OP_NONE && stage != S_IDLE) {
+            bool finish_fail = false, finish_ok = false;
+            switch (stage) {
+            case S_FETCH: {
+                idx = atomicAdd(queue, 1);
+                if (idx >= b.n) { stage = S_IDLE; break; }
+                for (int k = 0; k < 3; k++) { c0[k] = b.center[4 * idx + k]; n0[k] = b.normal[4 * idx + k]; c[k] = c0[k]; n[k] = n0[k]; }
+                scale = b.scale[idx];
+                nimg = b.n_images[idx];
+                ngrabs = 0; nl_result = 0; B.nevals = 0; B.minf = 0.0;
+                B.xfinal[0] = B.xfinal[1] = B.xfinal[2] = 0.0;
+                if (nimg > kMaxImages || nimg > b.max_images) { fail_stage = 100; finish_fail = true; break; }
+                for (int k = 0; k < nimg; k++) row[k] = (uint16_t)b.images[(size_t)idx * b.max_images + k];
+                nimg = add_images(sc, o, row, nimg, c, n, scale);
+                if (nimg < 0) { fail_stage = 100; finish_fail = true; break; }
+                if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 1; finish_fail = true; break; }
+                op = OP_INCC; req_ref = 0; req_robust = 0; req_thr = o.NCC_ALPHA_1;
+                stage = S_F1;
+                break;
+            }
+            case S_F1: {  // filterImagesNCC(alpha1) result -> sortImages, assureImageAngles, optimizePatch start
+                nimg = apply_keep_mask(row, nimg, res_mask);
+                if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 2; finish_fail = true; break; }
+                nimg = sort_images(sc, o, row, nimg, c, n, scale);
+                if (!assure_image_angles(sc, o, row, nimg, c)) { fail_stage = 3; finish_fail = true; break; }
+                if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 4; finish_fail = true; break; }
+                set_optimization_fields(sc.views[row[0]], c, F);
+                double x0[3], dx[3];
+                parameters_from_center_norm(F, o, n, lbv, ubv, x0);
+                bq_default_step(x0, lbv, ubv, dx);
+                if (bq_start(B, x0, lbv, ubv, dx, 1.e-7, 1000) != BQ_CONTINUE) {
+                    nl_result = B.rc; fail_stage = 4; finish_fail = true; break;
+                }
+                set_center_norm(F, o, B.xeval, c, n);
+                op = OP_OBJ;
+                stage = S_BQ;
+                break;
+            }
+            case S_BQ: {  // objective value arrived: advance BOBYQA
+                if (bq_step(B, res_f) == BQ_CONTINUE) {
+                    set_center_norm(F, o, B.xeval, c, n);
+                    op = OP_OBJ;
+                    break;
+                }
+                nl_result = B.rc;
+                // SUCCESS / STOPVAL / FTOL / XTOL only (PatchOptimizer.cpp:367-368); negative codes throw
+                if (!(B.rc >= 1 && B.rc <= 4)) { fail_stage = 4; finish_fail = true; break; }
+                set_center_norm(F, o, B.xfinal, c, n);
+                nimg = add_images(sc, o, row, nimg, c, n, scale);
+                if (nimg < 0) { fail_stage = 100; finish_fail = true; break; }
+                if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 5; finish_fail = true; break; }
+                op = OP_INCC; req_ref = 0; req_robust = 0; req_thr = o.NCC_ALPHA_2;
+                stage = S_F2;
+                break;
+            }
+            case S_F2: {  // filterImagesNCC(alpha2) -> filterImagesByAngle, assureImageAngles, setRefImage start
+                nimg = apply_keep_mask(row, nimg, res_mask);
+                if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 6; finish_fail = true; break; }
+                nimg = filter_images_by_angle(sc, o, row, nimg, c, n);
+                if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 7; finish_fail = true; break; }
+                if (!assure_image_angles(sc, o, row, nimg, c)) { fail_stage = 8; finish_fail = true; break; }
+                ii = 0; refindex = -1; refbest = 3.402823466e+38f;
+                op = OP_REFSUM; req_ref = 0; req_robust = 1;
+                stage = S_RS;
+                break;
+            }
+            case S_RS: {  // setRefImage (PatchOptimizer.cpp:154-181): one robust setINCCs per candidate
+                if (res_sum < refbest) { refbest = res_sum; refindex = ii; }
+                ii++;
+                if (ii < nimg) { op = OP_REFSUM; req_ref = ii; req_robust = 1; break; }
+                if (refindex > 0) {  // swap the chosen image into slot 0
+                    const uint16_t t = row[0];
+                    row[0] = row[refindex];
+                    row[refindex] = t;
+                }
+                op = OP_INCC; req_ref = 0; req_robust = 0; req_thr = o.NCC_ALPHA_2;
+                stage = S_F3;
+                break;
+            }
+            case S_F3: {
+                nimg = apply_keep_mask(row, nimg, res_mask);
+                if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 9; finish_fail = true; break; }
+                if (nimg > b.max_images) { fail_stage = 100; finish_fail = true; break; }
+                finish_ok = true;
+                break;
+            }
+            default: stage = S_IDLE; break;
+            }
+            if (finish_ok || finish_fail) {
+                b.ok[idx] = finish_ok ? 1 : 0;
+                if (finish_ok) {
+                    for (int k = 0; k < 3; k++) { b.center[4 * idx + k] = c[k]; b.normal[4 * idx + k] = n[k]; }
+                    b.center[4 * idx + 3] = 1.0f;
+                    b.normal[4 * idx + 3] = 0.0f;
+                    b.n_images[idx] = nimg;
+                    for (int k = 0; k < nimg && k < b.max_images; k++) b.images[(size_t)idx * b.max_images + k] = row[k];
+                    if (b.color) {
+                        float rgb[3];
+                        patch_colour(sc, row, nimg, c, scale, rgb);
+                        for (int k = 0; k < 3; k++) b.color[3 * idx + k] = rgb[k];
+                    }
+                    if (b.ncc) b.ncc[idx] = 1.4f;  // PatchOptimizer.cpp:95
+                }
+                if (b.stage) b.stage[idx] = finish_ok ? 0 : fail_stage;
+                if (b.fmin) b.fmin[idx] = B.minf;
+                if (b.x) for (int k = 0; k < 3; k++) b.x[3 * idx + k] = B.xfinal[k];
+                if (b.result) b.result[idx] = nl_result;
+                if (b.nevals) b.nevals[idx] = B.nevals;
+                if (b.ngrabs) b.ngrabs[idx] = ngrabs;
+                stage = S_FETCH;
+            }
+        }
+        // ================= phase B: the wave serves the posted requests one patch at a time
+        __syncthreads();  // single-wave workgroup: orders the lanes' LDS list updates before cross-lane reads
+        unsigned long long pending = __ballot(op != OP_NONE);
+        if (pending == 0ull) break;  // every lane idle and nothing posted: queue drained
+        while (pending) {
+            const int p = __ffsll((long long)pending) - 1;
+            pending &= pending - 1ull;
+            const int opp = bcast_i(op, p);
+            const float pc[3] = {bcast_f(c[0], p), bcast_f(c[1], p), bcast_f(c[2], p)};
+            const float pn[3] = {bcast_f(n[0], p), bcast_f(n[1], p), bcast_f(n[2], p)};
+            const float pscale = bcast_f(scale, p);
+            const int pnimg = bcast_i(nimg, p);
+            const int pref = (opp == OP_OBJ) ? 0 : bcast_i(req_ref, p);
+            const int prob = bcast_i(req_robust, p);
+            const uint16_t* prow = &lists[p * kRow];
+            const EvalResult r = wave_eval_rt(sc, o, prow, pnimg, pref, pc, pn, pscale, opp == OP_OBJ ? 1 : 0, prob);
+            const float thr = bcast_f(req_thr, p);
+            unsigned long long keep = __ballot(r.incc_lane < 1.0f - thr);
+            if (lane == p) {
+                res_f = r.obj;
+                res_mask = keep;
+                res_sum = r.incc_sum;
+                ngrabs += r.ngrabs;
+                op = OP_NONE;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* queue_counter, int n_cus,
+                     hipStream_t st) {
+    if (b.n <= 0) return;
+    // persistent single-wave workgroups; enough waves to cover the batch once, at most 8 per CU
+    int waves = (b.n + 63) / 64;
+    const int cap = n_cus * 8;
+    if (waves > cap) waves = cap;
+    hipLaunchKernelGGL(optimize_kernel, dim3(waves), dim3(64), 0, st, sc, o, b, queue_counter);
+}
+
+}  // namespace hpmvs

@@ -233,12 +233,13 @@ struct EvalResult {
 
 // One wavefront evaluates one patch.  Everything passed in is wave-uniform; `list` holds the
 // attached image ids (LDS uint16 rows in the refinement kernel, global int32 rows elsewhere).
-//   OBJ = true : objective_fn  (z axis of the angle gate = normalised normal, plateau 2.0)
-//   OBJ = false: setINCCs(ref_slot, robust) (z axis = the raw normal)
-template <bool OBJ, typename ListT>
-__device__ __forceinline__ EvalResult wave_eval(const DevScene& sc, const DevOptions& o, const ListT* list, int nimg,
-                                                int ref_slot, const float* c, const float* n, float scale,
-                                                int robust) {
+//   obj_mode != 0: objective_fn  (z axis of the angle gate = normalised normal, plateau 2.0)
+//   obj_mode == 0: setINCCs(ref_slot, robust) (z axis = the raw normal)
+// The reference texture is grabbed first, then the others in list order (one grab call site).
+template <typename ListT>
+__device__ __forceinline__ EvalResult wave_eval_rt(const DevScene& sc, const DevOptions& o, const ListT* list,
+                                                   int nimg, int ref_slot, const float* c, const float* n,
+                                                   float scale, int obj_mode, int robust) {
     EvalResult res;
     res.obj = 2.0; res.incc_lane = 2.0f; res.incc_sum = 0.0f; res.ngrabs = 0;
     const int lane = lane_id();
@@ -250,66 +251,68 @@ __device__ __forceinline__ EvalResult wave_eval(const DevScene& sc, const DevOpt
     const DevView& RV = sc.views[(int)list[ref_slot]];
     float px[3], py[3], pz[3];
     calc_patch_axes(RV.xaxis, RV.yaxis, n, scale, px, py, pz);
-    const float* zax = OBJ ? pz : n;
+    float zax[3];
+    for (int k = 0; k < 3; k++) zax[k] = obj_mode ? pz[k] : n[k];
 
     // lane v prepares image v
     Prep P;
     P.ok = 0; P.tlx = P.tly = P.dxx = P.dxy = P.dyx = P.dyy = 0.0f; P.pix = nullptr; P.W = 0;
     if (lane < nimg) P = prep_image(sc.views[(int)list[lane]], o, c, scale, px, py, zax);
 
-    // reference texture
     if (!bcast_i(P.ok, ref_slot)) {
         // objective: 2.0; setINCCs: every entry 2.0
-        if (!OBJ) {
+        if (!obj_mode) {
             float s = 0.0f;
             for (int k = 0; k < nimg; k++) s += 2.0f;
             res.incc_sum = s;
         }
         return res;
     }
-    float r0, r1, r2;
-    grab_normalized(bcast_f(P.tlx, ref_slot), bcast_f(P.tly, ref_slot), bcast_f(P.dxx, ref_slot),
-                    bcast_f(P.dxy, ref_slot), bcast_f(P.dyx, ref_slot), bcast_f(P.dyy, ref_slot),
-                    bcast_p(P.pix, ref_slot), bcast_i(P.W, ref_slot), fx, fy, active, r0, r1, r2);
-    int ngr = 1;
+    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+    int ngr = 0, nok = 0;
     double val = 0.0;
-    int nok = 0;
-    float fsum = 0.0f;
     float mine = 2.0f;
-    for (int v = 0; v < nimg; v++) {
-        float e;
-        if (v == ref_slot) {
-            e = 0.0f;
-            if (OBJ) continue;
-        } else if (!bcast_i(P.ok, v)) {
-            e = 2.0f;
-            if (OBJ) continue;
-        } else {
-            float c0, c1, c2;
-            grab_normalized(bcast_f(P.tlx, v), bcast_f(P.tly, v), bcast_f(P.dxx, v), bcast_f(P.dxy, v),
-                            bcast_f(P.dyx, v), bcast_f(P.dyy, v), bcast_p(P.pix, v), bcast_i(P.W, v), fx, fy,
-                            active, c0, c1, c2);
-            ngr++;
-            const float dot = wave_sum((r0 * c0 + r1 * c1) + r2 * c2) / 147.0f;
-            const float raw = 1.0f - dot;
-            if (OBJ) {
-                val += (double)robustincc(raw);
-                nok++;
-                continue;
-            }
-            e = robust ? robustincc(raw) : raw;
+    // per-image raw values, delivered to lane v; the sequential float sum is formed afterwards
+    for (int it = 0; it < nimg; it++) {
+        const int v = (it == 0) ? ref_slot : ((it - 1 < ref_slot) ? it - 1 : it);
+        if (!bcast_i(P.ok, v)) continue;  // entry stays 2.0 (setINCCs) / skipped (objective)
+        float c0, c1, c2;
+        grab_normalized(bcast_f(P.tlx, v), bcast_f(P.tly, v), bcast_f(P.dxx, v), bcast_f(P.dxy, v),
+                        bcast_f(P.dyx, v), bcast_f(P.dyy, v), bcast_p(P.pix, v), bcast_i(P.W, v), fx, fy,
+                        active, c0, c1, c2);
+        ngr++;
+        if (it == 0) {
+            r0 = c0; r1 = c1; r2 = c2;
+            if (lane == v) mine = 0.0f;
+            continue;
         }
-        fsum += e;
-        if (lane == v) mine = e;
+        const float dot = wave_sum((r0 * c0 + r1 * c1) + r2 * c2) / 147.0f;
+        const float raw = 1.0f - dot;
+        if (obj_mode) {
+            val += (double)robustincc(raw);
+            nok++;
+        } else if (lane == v) {
+            mine = robust ? robustincc(raw) : raw;
+        }
     }
     res.ngrabs = ngr;
-    if (OBJ) {
+    if (obj_mode) {
         res.obj = (nok < o.MIN_IMAGES_PER_PATCH - 1) ? 2.0 : val / (double)nok;
     } else {
         res.incc_lane = mine;
-        res.incc_sum = fsum;
+        // std::accumulate(incc.begin(), incc.end(), 0.0f) in index order (PatchOptimizer.cpp:165)
+        float s = 0.0f;
+        for (int k = 0; k < nimg; k++) s += bcast_f(mine, k);
+        res.incc_sum = s;
     }
     return res;
+}
+
+template <bool OBJ, typename ListT>
+__device__ __forceinline__ EvalResult wave_eval(const DevScene& sc, const DevOptions& o, const ListT* list, int nimg,
+                                                int ref_slot, const float* c, const float* n, float scale,
+                                                int robust) {
+    return wave_eval_rt(sc, o, list, nimg, ref_slot, c, n, scale, OBJ ? 1 : 0, robust);
 }
 
 // ------------------------------------------------------------------------------------------

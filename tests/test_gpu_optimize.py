@@ -1,0 +1,112 @@
+"""GPU parity of the full refinement (hpmvs_optimize_batch) against the CPU oracle, which runs the
+restated photometric path around the reference's GENUINE NLopt BOBYQA (oracle/_ref) when that
+library travelled, else the oracle's own port.
+
+Stated tolerances (float32 textures + float64 optimiser; GPU reductions are tree-shaped and use FMA,
+so objective values differ from the CPU's at the 1e-6 level and BOBYQA trajectories may part ways
+late in the run):
+  * success / failure decision and failing stage : identical for >= 97 % of patches
+  * on patches where both succeed:
+      NCC score  ncc = 1 - unrobust(f*)      : mean |d| <= 2e-3 (SURVEY 8d proposed 5e-3)
+      same basin (|d depth| < 0.25 scale and normal within 2 deg) : >= 80 %
+      attached image list after optimize()   : identical for >= 80 %
+    The basin figure is bounded by the reference algorithm itself, not by this implementation:
+    BOBYQA on this piecewise-smooth objective amplifies a 1e-9 RELATIVE perturbation of f into a
+    different basin for 7-8 % of patches on the CPU (tests/sensitivity_probe.py, DESIGN.md
+    "Parity"), so any objective that is not bit-identical tops out near 92 %.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def unrobust(f):
+    return f / (1.0 - 3.0 * f)
+
+
+def compare(seeds, oracle_scene, gpu_scene, tag):
+    from hpmvs_amd import api
+    from oracle import oracle as orc
+    batch = api.Batch.from_seeds(seeds)
+    api.optimize_batch(gpu_scene, batch)
+    P = orc.patches_from_seeds(seeds)
+    orc.optimize_batch(oracle_scene, P, n_threads=8)
+    n = batch.n
+    ok_cpu = np.array([P[k].stage == 0 for k in range(n)])
+    ok_gpu = batch.ok.astype(bool)
+    stage_cpu = np.array([P[k].stage for k in range(n)])
+    agree = (ok_cpu == ok_gpu) & (stage_cpu == batch.stage)
+    both = np.nonzero(ok_cpu & ok_gpu)[0]
+    assert ok_cpu.sum() >= 20, f"{tag}: scene too hard for the oracle ({ok_cpu.sum()} successes)"
+    dn, dd, same_imgs, dncc, dcol = [], [], [], [], []
+    for k in both:
+        p = P[k]
+        cc = np.array(p.center[:3]); cg = batch.center[k, :3]
+        nc = np.array(p.normal[:3]); ng = batch.normal[k, :3]
+        dd.append(np.linalg.norm(cc - cg) / float(seeds.scale[k]))
+        cosang = np.clip(np.dot(nc, ng) / (np.linalg.norm(nc) * np.linalg.norm(ng)), -1, 1)
+        dn.append(np.degrees(np.arccos(cosang)))
+        same_imgs.append(p.n_images == batch.n_images[k] and list(p.images[:p.n_images]) == list(batch.images[k, :p.n_images]))
+        dncc.append(abs(unrobust(p.fmin) - unrobust(batch.fmin[k])))
+        dcol.append(np.abs(np.array(p.color[:]) - batch.color[k]).max())
+    dd, dn = np.array(dd), np.array(dn)
+    basin = (dd < 0.25) & (dn < 2.0)
+    report = dict(tag=tag, n=n, ok_cpu=int(ok_cpu.sum()), ok_gpu=int(ok_gpu.sum()), agree=float(agree.mean()),
+                  same_basin=float(basin.mean()), mean_dncc=float(np.mean(dncc)), med_dd=float(np.median(dd)),
+                  p95_dd=float(np.percentile(dd, 95)), med_dn=float(np.median(dn)), same_imgs=float(np.mean(same_imgs)),
+                  identical_x=float(np.mean([np.array_equal(np.array(P[k].x[:]), batch.x[k]) for k in both])),
+                  nevals_cpu=float(np.mean([P[k].nevals for k in both])), nevals_gpu=float(batch.nevals[both].mean()),
+                  max_dcol_same=float(np.max(np.array(dcol)[np.array(same_imgs)])) if any(same_imgs) else -1.0)
+    print(report)
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_reports.jsonl", "a") as fh:
+        fh.write(json.dumps(report) + "\n")
+    assert agree.mean() >= 0.97, report
+    assert basin.mean() >= 0.80, report
+    assert np.mean(dncc) <= 2e-3, report
+    assert np.mean(same_imgs) >= 0.80, report
+    # scale_3dx_ is returned unchanged and ncc_ is the reference's constant
+    assert np.all(batch.ncc[ok_gpu] == np.float32(1.4))
+    return report
+
+
+def test_optimize_parity_tiny(tiny_seeds, oracle_scene, gpu_scene):
+    compare(tiny_seeds, oracle_scene, gpu_scene, "tiny/start_level2")
+
+
+def test_optimize_parity_level3(tiny_scene, oracle_scene, gpu_scene):
+    from hpmvs_amd import synth
+    seeds = synth.make_seeds(tiny_scene, 300, start_level=3, seed=synth.SEED + 7)
+    compare(seeds, oracle_scene, gpu_scene, "tiny/start_level3")
+
+
+def test_failures_leave_patch_untouched(tiny_scene, gpu_scene):
+    """optimize() returns false without touching the patch (reference PatchOptimizer.cpp:86-87)."""
+    from hpmvs_amd import api, synth
+    seeds = synth.make_seeds(tiny_scene, 64, start_level=4)  # level-4 seeds cannot attach enough images here
+    batch = api.Batch.from_seeds(seeds)
+    before = (batch.center.copy(), batch.normal.copy(), batch.n_images.copy(), batch.images.copy())
+    api.optimize_batch(gpu_scene, batch)
+    bad = ~batch.ok.astype(bool)
+    assert bad.sum() > 0
+    assert np.array_equal(batch.center[bad], before[0][bad])
+    assert np.array_equal(batch.normal[bad], before[1][bad])
+    assert np.array_equal(batch.n_images[bad], before[2][bad])
+    assert np.array_equal(batch.images[bad], before[3][bad])
+
+
+def test_empty_and_ragged_batches(tiny_seeds, gpu_scene):
+    from hpmvs_amd import api
+    empty = api.Batch(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32), np.zeros(0, np.float32),
+                      np.zeros(0, np.int32), np.zeros((0, 8), np.int32))
+    api.optimize_batch(gpu_scene, empty)
+    # patches with 0 or 1 attached images fail at stage 1, a single patch batch works
+    b = api.Batch.from_seeds(tiny_seeds, np.arange(1))
+    b.n_images[:] = 0
+    api.optimize_batch(gpu_scene, b)
+    assert b.ok[0] == 0 and b.stage[0] == 1
+    one = api.Batch.from_seeds(tiny_seeds, np.nonzero(tiny_seeds.n_images >= 3)[0][:1])
+    api.optimize_batch(gpu_scene, one)
+    assert one.stage[0] in (0, 2, 3, 4, 5, 6, 7, 8, 9)
