@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""bench.py -- refined patches/sec of the MI355X-native HPMVS refinement path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one expansion round: every rank runs the full optimize() (image selection, BOBYQA
+refinement of depth + normal against NCC over the attached views, reference-image selection) on
+its shard of synthetic seed patches, all inputs already resident in HBM, and -- for N > 1 -- one
+RCCL all-gather of the fixed-size refined-patch records (north_star's exchange step).  Scaling is
+weak: every rank refines `--patches` seeds of the same replicated scene.
+
+Workload (BASELINE.json configs[1]): 12 synthetic 1920x1080 views, 1e5 seed patches per GPU.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     : algorithmic image bytes of the refinement kernel (588 B per sampleTexture that
+                 passed its gates, counted by the kernel itself) / kernel time from HIP events on
+                 the launch stream, against the 8 TB/s HBM peak;
+  cpu_baseline : the CPU oracle (restated photometric path around the reference's genuine NLopt
+                 BOBYQA when oracle/_ref travelled) on a bounded sample of the same seeds, all
+                 host cores;
+  parity       : GPU vs that CPU run on the same sample (the metric's "mean NCC-score delta").
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from hpmvs_amd import api, synth  # noqa: E402
+
+WORKLOADS = {
+    # name: (views, width, height, seeds per GPU, start_level)
+    "c0_tiny": (3, 640, 480, 200, 2),
+    "c1_12v_1080p_1e5": (12, 1920, 1080, 100_000, 4),
+    "c2_50v_4k_1e6": (50, 3840, 2160, 1_000_000, 4),
+}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+RECORD_BYTES = 128     # all-gathered refined-patch record
+
+
+def device_batch(seeds, dev, max_images):
+    """SoA batch resident in HBM (torch tensors are just the allocation + stream plumbing)."""
+    t = {}
+    t["center"] = torch.from_numpy(seeds.center).to(dev)
+    t["normal"] = torch.from_numpy(seeds.normal).to(dev)
+    t["scale"] = torch.from_numpy(seeds.scale).to(dev)
+    t["n_images"] = torch.from_numpy(seeds.n_images).to(dev)
+    t["images"] = torch.from_numpy(np.ascontiguousarray(seeds.images[:, :max_images])).to(dev)
+    n = len(seeds.scale)
+    t["ok"] = torch.zeros(n, dtype=torch.uint8, device=dev)
+    t["color"] = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+    t["ncc"] = torch.zeros(n, dtype=torch.float32, device=dev)
+    t["fmin"] = torch.zeros(n, dtype=torch.float64, device=dev)
+    t["x"] = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    t["result"] = torch.zeros(n, dtype=torch.int32, device=dev)
+    t["nevals"] = torch.zeros(n, dtype=torch.int32, device=dev)
+    t["stage"] = torch.zeros(n, dtype=torch.int32, device=dev)
+    t["ngrabs"] = torch.zeros(n, dtype=torch.int32, device=dev)
+    return t
+
+
+def c_batch(t, n, max_images):
+    b = api.PatchBatch()
+    b.n, b.max_images = n, max_images
+    for k in ("center", "normal", "scale", "n_images", "images", "ok", "color", "ncc", "fmin", "x", "result",
+              "nevals", "stage", "ngrabs"):
+        setattr(b, k, t[k].data_ptr())
+    return b
+
+
+def pack_records(t):
+    """Fixed 128-byte refined-patch record per patch (what one expansion round exchanges)."""
+    n = t["scale"].shape[0]
+    rec = torch.zeros((n, RECORD_BYTES), dtype=torch.uint8, device=t["scale"].device)
+    rec[:, 0:16] = t["center"].view(torch.uint8).view(n, 16)
+    rec[:, 16:32] = t["normal"].view(torch.uint8).view(n, 16)
+    rec[:, 32:44] = t["color"].view(torch.uint8).view(n, 12)
+    rec[:, 44:48] = t["scale"].view(torch.uint8).view(n, 4)
+    rec[:, 48:56] = t["fmin"].view(torch.uint8).view(n, 8)
+    rec[:, 56] = t["ok"]
+    rec[:, 57] = t["n_images"].to(torch.uint8)
+    img16 = t["images"][:, :32].to(torch.int16).contiguous()
+    rec[:, 64:64 + 2 * img16.shape[1]] = img16.view(torch.uint8).view(n, -1)
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c1_12v_1080p_1e5", choices=list(WORKLOADS))
+    ap.add_argument("--patches", type=int, default=0, help="override seeds per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=1536, help="patches of the CPU-baseline / parity sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available() or api.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    views, W, H, n_seeds, start_level = WORKLOADS[args.workload]
+    if args.patches > 0:
+        n_seeds = args.patches
+    max_images = 32
+
+    # ---- scene: rendered on the GPU, replicated on every rank, resident in HBM
+    t0 = time.time()
+    scene = synth.make_scene(views, W, H, n_waves=24, device=dev)
+    gpu_scene = api.Scene(scene, device=local_rank)
+    torch.cuda.synchronize()
+    t_scene = time.time() - t0
+    seeds = synth.make_seeds(scene, n_seeds, start_level=start_level, max_images=max_images, seed=synth.SEED + 977 * rank)
+    pristine = device_batch(seeds, dev, max_images)
+    work = {k: v.clone() for k, v in pristine.items()}
+    opts = api.default_options()
+    L = api.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    gathered = torch.empty((world * n_seeds, RECORD_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
+
+    events = []
+
+    def step(timed=False):
+        for k in ("center", "normal", "n_images", "images"):
+            work[k].copy_(pristine[k])
+        b = c_batch(work, n_seeds, max_images)
+        # HIP events on the stream the kernel is launched on (torch's current stream is handed to the C ABI)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = L.hpmvs_optimize_batch(gpu_scene.h, C.byref(opts), C.byref(b), 1, C.c_void_p(stream))
+        e1.record()
+        if rc != 0:
+            raise RuntimeError(L.hpmvs_last_error().decode())
+        if timed:
+            events.append((e0, e1))
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, pack_records(work))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(timed=True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    # average launch duration of the refinement kernel over the timed region
+    last_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    lib_ms = gpu_scene.last_kernel_ms()  # the library's own event pair around the last launch (cross-check)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    ok = work["ok"].cpu().numpy().astype(bool)
+    ngrabs = work["ngrabs"].cpu().numpy().astype(np.int64)
+    nevals = work["nevals"].cpu().numpy()
+    nimg_out = work["n_images"].cpu().numpy()
+    stage = work["stage"].cpu().numpy()
+    # algorithmic bytes of one launch: 588 B per grab + 12 B per colour fetch + the record I/O
+    alg_bytes = 588.0 * float(ngrabs.sum()) + 12.0 * float(nimg_out[ok].sum()) + 2.0 * float((36 + 4 * max_images) * n_seeds)
+    achieved = alg_bytes / (last_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "refined_patches_per_sec",
+        "value": world * n_seeds * args.steps / elapsed,
+        "unit": "patches/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32 textures / f64 optimiser",
+        "data": "synthetic",
+        "config": {"workload": args.workload, "views": views, "image": f"{W}x{H}", "pyramid_levels": 6,
+                   "seeds_per_gpu": n_seeds, "start_level": start_level, "max_images": max_images,
+                   "parallelism": f"patch-shard x{world} + all-gather of {RECORD_BYTES} B records"},
+        "successes_per_sec": world * float(ok.sum()) * args.steps / elapsed,
+        "success_fraction": float(ok.mean()),
+        "mean_evals_per_refined_patch": float(nevals[nevals > 0].mean()) if (nevals > 0).any() else 0.0,
+        "mean_grabs_per_patch": float(ngrabs.mean()),
+        "scene_bytes_hbm": int(gpu_scene.bytes()),
+        "scene_setup_s": t_scene,
+        "roofline": {"bound": "hbm", "kernel": "optimize_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel_ms": last_ms, "kernel_ms_last_launch_library_events": lib_ms,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "grabs_per_launch": int(ngrabs.sum())},
+    }
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc)).get(args.workload)
+            if rec and rec.get("seeds_per_gpu") == n_seeds:
+                out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = rec.get("source")
+        except Exception:
+            pass
+
+    # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import oracle as orc
+        m = min(args.cpu_sample, n_seeds)
+        idx = np.arange(m)
+        osc = orc.OracleScene(scene)
+        P = orc.patches_from_seeds(seeds, idx)
+        cores = os.cpu_count() or 1
+        which = orc.best_optimizer()
+        tc = time.perf_counter()
+        orc.optimize_batch(osc, P, which=which, n_threads=cores)
+        tc = time.perf_counter() - tc
+        okc = np.array([p.stage == 0 for p in P])
+        okg = ok[:m]
+        both = np.nonzero(okc & okg)[0]
+        fmin_g = work["fmin"][:m].cpu().numpy()
+        cen_g = work["center"][:m].cpu().numpy()
+        nor_g = work["normal"][:m].cpu().numpy()
+        unrob = lambda f: f / (1.0 - 3.0 * f)
+        dncc, basin = [], []
+        for k in both:
+            p = P[k]
+            dncc.append(abs(unrob(p.fmin) - unrob(fmin_g[k])))
+            dd = np.linalg.norm(np.array(p.center[:3]) - cen_g[k, :3]) / float(seeds.scale[k])
+            cs = float(np.clip(np.dot(np.array(p.normal[:3]), nor_g[k, :3]), -1, 1))
+            basin.append(dd < 0.25 and np.degrees(np.arccos(cs)) < 2.0)
+        out["cpu_baseline"] = {
+            "value": m / tc, "unit": "patches/s", "cores": cores,
+            "kind": "port",
+            "sample": f"first {m} seeds of the same workload, OpenMP schedule(dynamic,64) over patches like "
+                      f"Scene::initPatches; photometric path = oracle/ C restatement, optimiser = "
+                      f"{'genuine NLopt 2.4.2 BOBYQA (oracle/_ref)' if which == orc.OPT_REF else 'oracle BOBYQA port'}",
+            "seconds": tc, "successes": int(okc.sum()),
+        }
+        out["parity"] = {
+            "sample": m, "decision_agreement": float((okc == okg).mean()),
+            "mean_abs_ncc_delta": float(np.mean(dncc)) if dncc else None,
+            "same_basin_fraction": float(np.mean(basin)) if basin else None,
+            "stage_agreement": float((np.array([p.stage for p in P]) == stage[:m]).mean()),
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,8 +35,12 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define BQ_HD __host__ __device__ inline
+// the big routines are real calls on the GPU: their register demand stays out of the caller's
+// wave-cooperative sampling loop (occupancy), and the code is shared by the call sites
+#define BQ_HD_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define BQ_HD inline
+#define BQ_HD_NOINLINE inline
 #endif
 #include <math.h>
 
@@ -193,7 +197,7 @@ BQ_HD void hess_mul(const Bobyqa3& B, const double* s, double* hs) {
 // Approximately minimise the model within ||d|| <= delta and the bounds: truncated conjugate
 // gradients with restarts on newly active bounds, then 2-D searches on the boundary.
 // Sets B.xnew, B.d, B.gnew, B.dsq, B.crvmin.
-BQ_HD void trsbox(Bobyqa3& B) {
+BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
     double xbdi[3], s[3] = {0, 0, 0}, hs[3], hred[3] = {0, 0, 0};
     double* d = B.d;
     double* gnew = B.gnew;
@@ -392,7 +396,7 @@ BQ_HD void trsbox(Bobyqa3& B) {
 // ---------------------------------------------------------------- altmov_ (bobyqa.c:744-1160)
 // Geometry-improving step for interpolation point knew: B.xnew (line through xopt and another
 // point), B.xalt (constrained Cauchy step), B.alpha, B.cauchy.
-BQ_HD void altmov(Bobyqa3& B) {
+BQ_HD_NOINLINE void altmov(Bobyqa3& B) {
     const double cst = 1.0 + sqrt(2.);
     double glag[3], hcol[7], w[3], wsave[3] = {0, 0, 0};
     const int knew = B.knew, kopt = B.kopt;
@@ -538,7 +542,7 @@ BQ_HD void altmov(Bobyqa3& B) {
 
 // ---------------------------------------------------------------- update_ (bobyqa.c:18-141)
 // Update BMAT and ZMAT for the move of interpolation point knew (uses vlag, beta, denom).
-BQ_HD void update(Bobyqa3& B) {
+BQ_HD_NOINLINE void update(Bobyqa3& B) {
     const int knew = B.knew;
     double w[10];
     double ztest = 0.0;
@@ -605,7 +609,7 @@ BQ_HD void pick_knew(Bobyqa3& B, const double* from, bool skip_kopt, double& sca
 // ---------------------------------------------------------------- bobyqb_ main loop (bobyqa.c:2143-3055)
 // Runs from `label` until the next objective evaluation is needed (returns BQ_CONTINUE with
 // B.xeval set) or the run ends (BQ_DONE).
-BQ_HD int run(Bobyqa3& B, int label) {
+BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
     double w[14];
     for (;;) {
         switch (label) {
@@ -860,7 +864,7 @@ BQ_HD int run(Bobyqa3& B, int label) {
 }
 
 // Code after an evaluation at xbase + xnew in the main loop (bobyqa.c:2583-2970)
-BQ_HD int after_eval(Bobyqa3& B, double f) {
+BQ_HD_NOINLINE int after_eval(Bobyqa3& B, double f) {
     double w[10];
     if (B.ntrits == -1) {
         B.fsave = f;
@@ -1029,7 +1033,7 @@ BQ_HD void bq_default_step(const double* x, const double* lb, const double* ub, 
 
 // bobyqa() front end (bobyqa.c:3073-3268) + the start of prelim_.  Returns BQ_CONTINUE with the
 // first point in B.xeval, or BQ_DONE with B.rc = BQ_INVALID_ARGS.
-BQ_HD int bq_start(Bobyqa3& B, const double* x0, const double* lb, const double* ub, const double* dx,
+BQ_HD_NOINLINE int bq_start(Bobyqa3& B, const double* x0, const double* lb, const double* ub, const double* dx,
                    double xtol_rel, int maxeval) {
     B.nevals = 0; B.rc = BQ_SUCCESS; B.minf = HUGE_VAL; B.maxeval = maxeval; B.phase = bq::PH_PRELIM;
     for (int i = 0; i < 3; i++) { B.xfinal[i] = x0[i]; B.xeval[i] = x0[i]; }
@@ -1075,7 +1079,7 @@ BQ_HD int bq_start(Bobyqa3& B, const double* x0, const double* lb, const double*
     return BQ_CONTINUE;
 }
 
-BQ_HD int bq_step(Bobyqa3& B, double f) {
+BQ_HD_NOINLINE int bq_step(Bobyqa3& B, double f) {
     if (B.phase == bq::PH_PRELIM) {
         bq::prelim_consume(B, f);
         // stopping tests after each prelim evaluation (bobyqa.c:1944-1947)

@@ -45,7 +45,7 @@ __device__ __forceinline__ void ray_to_cam(const DevView& V, const float* c, flo
 }
 
 // PatchOptimizer::addImages (PatchOptimizer.cpp:225-258).  Returns the new count, or -1 on overflow.
-__device__ int add_images(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg, const float* c,
+__device__ __noinline__ int add_images(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg, const float* c,
                           const float* n, float scale) {
     if (nimg <= 0) return 0;
     const int ref = row[0];
@@ -81,7 +81,7 @@ __device__ int add_images(const DevScene& sc, const DevOptions& o, uint16_t* row
 
 // PatchOptimizer::sortImages + getAngleWeightedScales (PatchOptimizer.cpp:183-223, 260-284).
 // Rewrites the row; returns the new count (the reference ignores the boolean result).
-__device__ int sort_images(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg, const float* c,
+__device__ __noinline__ int sort_images(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg, const float* c,
                            const float* n, float scale) {
     uint16_t idx[kMaxImages];
     float ws[kMaxImages];
@@ -139,7 +139,7 @@ __device__ int sort_images(const DevScene& sc, const DevOptions& o, uint16_t* ro
 }
 
 // PatchOptimizer::assureImageAngles (PatchOptimizer.cpp:105-123)
-__device__ bool assure_image_angles(const DevScene& sc, const DevOptions& o, const uint16_t* row, int nimg,
+__device__ __noinline__ bool assure_image_angles(const DevScene& sc, const DevOptions& o, const uint16_t* row, int nimg,
                                     const float* c) {
     for (int ii = 0; ii < nimg - 1; ii++) {
         float ri[3];
@@ -155,7 +155,7 @@ __device__ bool assure_image_angles(const DevScene& sc, const DevOptions& o, con
 }
 
 // PatchOptimizer::filterImagesByAngle (PatchOptimizer.cpp:125-136)
-__device__ int filter_images_by_angle(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg,
+__device__ __noinline__ int filter_images_by_angle(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg,
                                       const float* c, const float* n) {
     int m = 0;
     for (int k = 0; k < nimg; k++) {
@@ -200,7 +200,7 @@ __device__ void colour_at(const DevView& V, const float* c, float scale, float* 
     }
 }
 
-__device__ void patch_colour(const DevScene& sc, const uint16_t* row, int nimg, const float* c, float scale,
+__device__ __noinline__ void patch_colour(const DevScene& sc, const uint16_t* row, int nimg, const float* c, float scale,
                              float* out) {
     float norms[kMaxImages];
     for (int k = 0; k < nimg; k++) {
@@ -223,7 +223,7 @@ __device__ void patch_colour(const DevScene& sc, const uint16_t* row, int nimg, 
 
 }  // namespace
 
-__global__ void __launch_bounds__(64) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
+__global__ void __launch_bounds__(64, 4) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
     __shared__ uint16_t lists[64 * kRow];
     const int lane = lane_id();
     uint16_t* row = &lists[lane * kRow];
@@ -396,7 +396,7 @@ void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b,
     if (b.n <= 0) return;
     // persistent single-wave workgroups; enough waves to cover the batch once, at most 8 per CU
     int waves = (b.n + 63) / 64;
-    const int cap = n_cus * 8;
+    const int cap = n_cus * 16;  // 4 waves per SIMD at <= 128 VGPRs
     if (waves > cap) waves = cap;
     hipLaunchKernelGGL(optimize_kernel, dim3(waves), dim3(64), 0, st, sc, o, b, queue_counter);
 }
