@@ -38,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from hpmvs_amd import api, synth  # noqa: E402
+from hpmvs_amd import distributed as dd  # noqa: E402
 
 WORKLOADS = {
     # name: (views, width, height, seeds per GPU, start_level)
@@ -46,7 +47,7 @@ WORKLOADS = {
     "c2_50v_4k_1e6": (50, 3840, 2160, 1_000_000, 4),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-RECORD_BYTES = 128     # all-gathered refined-patch record
+RECORD_BYTES = dd.RECORD_BYTES  # all-gathered refined-patch record
 
 
 def device_batch(seeds, dev, max_images):
@@ -81,18 +82,8 @@ def c_batch(t, n, max_images):
 
 def pack_records(t):
     """Fixed 128-byte refined-patch record per patch (what one expansion round exchanges)."""
-    n = t["scale"].shape[0]
-    rec = torch.zeros((n, RECORD_BYTES), dtype=torch.uint8, device=t["scale"].device)
-    rec[:, 0:16] = t["center"].view(torch.uint8).view(n, 16)
-    rec[:, 16:32] = t["normal"].view(torch.uint8).view(n, 16)
-    rec[:, 32:44] = t["color"].view(torch.uint8).view(n, 12)
-    rec[:, 44:48] = t["scale"].view(torch.uint8).view(n, 4)
-    rec[:, 48:56] = t["fmin"].view(torch.uint8).view(n, 8)
-    rec[:, 56] = t["ok"]
-    rec[:, 57] = t["n_images"].to(torch.uint8)
-    img16 = t["images"][:, :32].to(torch.int16).contiguous()
-    rec[:, 64:64 + 2 * img16.shape[1]] = img16.view(torch.uint8).view(n, -1)
-    return rec
+    return dd.pack_records(t["center"], t["normal"], t["color"], t["scale"], t["fmin"], t["ok"], t["n_images"],
+                           t["images"])
 
 
 def main():
@@ -102,7 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c1_12v_1080p_1e5", choices=list(WORKLOADS))
     ap.add_argument("--patches", type=int, default=0, help="override seeds per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=1536, help="patches of the CPU-baseline / parity sample")
+    ap.add_argument("--cpu-sample", type=int, default=32768, help="patches of the CPU-baseline / parity sample")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -153,7 +144,7 @@ def main():
         if timed:
             events.append((e0, e1))
         if world > 1:
-            dist.all_gather_into_tensor(gathered, pack_records(work))
+            dist.all_gather_into_tensor(gathered, pack_records(work))  # == dd.all_gather_records (equal shards)
 
     def fence():
         torch.cuda.synchronize()

@@ -110,3 +110,35 @@ def test_empty_and_ragged_batches(tiny_seeds, gpu_scene):
     one = api.Batch.from_seeds(tiny_seeds, np.nonzero(tiny_seeds.n_images >= 3)[0][:1])
     api.optimize_batch(gpu_scene, one)
     assert one.stage[0] in (0, 2, 3, 4, 5, 6, 7, 8, 9)
+
+
+def test_gpu_against_committed_goldens():
+    """GPU path vs tests/golden (oracle + genuine NLopt, generated in the build container): does not
+    depend on oracle/_ref having travelled to the GPU box."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import golden_scene
+    from hpmvs_amd import api
+    scene, seeds, exp = golden_scene()
+    gpu = api.Scene(scene, device=0)
+    batch = api.Batch.from_seeds(seeds)
+    # objective probes (pins F12-F15 / A4-A10 without the optimiser)
+    by_patch = {}
+    for pr in exp["objective_probes"]:
+        by_patch.setdefault(pr["patch"], []).append(pr)
+    for j in range(4):
+        idx = np.array(sorted(by_patch))
+        x = np.array([by_patch[k][j]["x"] for k in idx])
+        want = np.array([by_patch[k][j]["f"] for k in idx])
+        got, _ = api.objective_batch(gpu, api.Batch.from_seeds(seeds, idx), x)
+        assert np.array_equal(got == 2.0, want == 2.0)
+        assert np.abs(got - want).max() <= 2e-5
+    api.optimize_batch(gpu, batch)
+    e = exp["patches"]
+    ok_cpu = np.array([bool(p["ok"]) for p in e])
+    assert (ok_cpu == batch.ok.astype(bool)).mean() >= 0.97
+    both = np.nonzero(ok_cpu & batch.ok.astype(bool))[0]
+    dncc = [abs(unrobust(e[k]["fmin"]) - unrobust(batch.fmin[k])) for k in both]
+    same = [e[k]["images"] == list(batch.images[k, :batch.n_images[k]]) for k in both]
+    assert np.mean(dncc) <= 2e-3 and np.mean(same) >= 0.8
+    gpu.close()
