@@ -1,0 +1,271 @@
+// hpmvs_host.cpp -- C++ mirror of the reference's public interface for the refinement path
+// (mo3d::Patch3d, Camera, Image, Scene view, PatchOptimizer) on top of the C ABI
+// (include/hpmvs_amd.h).  Host logic only: scene assembly and marshalling; every piece of the hot
+// path's arithmetic runs in the gfx950 kernels behind hpmvs_optimize_batch.
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+#include <hpmvs/Camera.h>
+#include <hpmvs/HpmvsOptions.h>
+#include <hpmvs/Image.h>
+#include <hpmvs/Patch3d.h>
+#include <hpmvs/PatchOptimizer.h>
+#include <hpmvs/Scene.h>
+
+#include "../../include/hpmvs_amd.h"
+
+namespace mo3d {
+
+// ---------------------------------------------------------------- Patch3d (reference src/hpmvs/Patch3d.cpp:28-74)
+std::atomic_uint_least32_t Patch3d::runningIdx(0);
+
+Patch3d::Patch3d() {
+    uid_ = generateUid();
+    center_ = Eigen::Vector4f::Zero();
+    normal_ = Eigen::Vector4f::Zero();
+    color_ = Eigen::Vector3f::Zero();
+    images_.clear();
+    scale_3dx_ = 0.0;
+    dscale_ = 0.0;
+    ncc_ = 0.0;
+    priorityReduction_ = 0;
+    expanded_ = false;
+    flatness_ = 0.0;
+    dirty_ = false;
+}
+Patch3d::Patch3d(const Patch3d& other) { uid_ = generateUid(); *this = other; }
+Patch3d::~Patch3d() {}
+Patch3d& Patch3d::operator=(const Patch3d& s) {
+    center_ = s.center_; normal_ = s.normal_; color_ = s.color_; images_ = s.images_;
+    scale_3dx_ = s.scale_3dx_; dscale_ = s.dscale_; ncc_ = s.ncc_;
+    priorityReduction_ = s.priorityReduction_; expanded_ = s.expanded_; flatness_ = s.flatness_; dirty_ = s.dirty_;
+    return *this;
+}
+
+// ---------------------------------------------------------------- Camera (reference src/hpmvs/Camera.cpp:34-99)
+void Camera::init(const mo3d::NVM_Camera* cam, int width, int height, const int maxLevel) {
+    hpmvs_camera hc;
+    const double q[4] = {cam->rq[0], cam->rq[1], cam->rq[2], cam->rq[3]};
+    const double c[3] = {cam->c[0], cam->c[1], cam->c[2]};
+    if (hpmvs_camera_from_nvm(cam->f, q, c, width, height, maxLevel, &hc) != HPMVS_OK) {
+        std::cerr << "Camera::init: " << hpmvs_last_error() << std::endl;
+        exit(1);
+    }
+    name_ = cam->filename;
+    projection_.resize(maxLevel + 1);
+    kMat_.resize(maxLevel + 1);
+    memcpy(projection_[0].m, hc.P0, sizeof(float) * 12);
+    const float K0[9] = {(float)cam->f, 0, (float)(width / 2.0), 0, (float)cam->f, (float)(height / 2.0), 0, 0, 1};
+    memcpy(kMat_[0].m, K0, sizeof(K0));
+    for (int l = 1; l < maxLevel + 1; l++) {  // rows 0,1 halved per level (Camera.cpp:55-63)
+        projection_[l] = projection_[l - 1];
+        kMat_[l] = kMat_[l - 1];
+        for (int k = 0; k < 8; k++) projection_[l].m[k] /= 2.0;
+        for (int k = 0; k < 6; k++) kMat_[l].m[k] /= 2.0;
+    }
+    center_ = Eigen::Vector4f(hc.center[0], hc.center[1], hc.center[2], hc.center[3]);
+    const float* r2 = &hc.P0[8];
+    const float nrm = std::sqrt((r2[0] * r2[0] + r2[1] * r2[1]) + r2[2] * r2[2]);
+    oAxis_ = Eigen::Vector4f(r2[0] / nrm, r2[1] / nrm, r2[2] / nrm, r2[3] / nrm);
+    xAxis_ = Eigen::Vector3f(hc.xaxis[0], hc.xaxis[1], hc.xaxis[2]);
+    yAxis_ = Eigen::Vector3f(hc.yaxis[0], hc.yaxis[1], hc.yaxis[2]);
+    zAxis_ = Eigen::Vector3f(hc.zaxis[0], hc.zaxis[1], hc.zaxis[2]);
+    const float* r0 = &hc.P0[0];
+    const float* r1 = &hc.P0[4];
+    ipscale_ = (std::sqrt((r0[0] * r0[0] + r0[1] * r0[1]) + r0[2] * r0[2]) +
+                std::sqrt((r1[0] * r1[0] + r1[1] * r1[1]) + r1[2] * r1[2])) / 2.0;
+}
+
+Eigen::Vector3f Camera::project(const Eigen::Vector4f& X, const int level) const {  // Camera.h:45-62
+    if (level >= (int)projection_.size()) { std::cerr << "Illegal level access in Camera"; exit(1); }
+    const float* P = projection_[level].m;
+    float r[3];
+    for (int k = 0; k < 3; k++) r[k] = ((P[k * 4] * X[0] + P[k * 4 + 1] * X[1]) + P[k * 4 + 2] * X[2]) + P[k * 4 + 3] * X[3];
+    if (r[2] <= 0.0f) return Eigen::Vector3f(-0xffff, -0xffff, -1.0f);
+    const float lo = (float)(INT_MIN + 3.0f), hi = (float)(INT_MAX - 3.0f);
+    return Eigen::Vector3f(std::max(lo, std::min(hi, r[0] / r[2])), std::max(lo, std::min(hi, r[1] / r[2])), 1.0f);
+}
+float Camera::getScale(const Eigen::Vector4f& coord, const int level) const {
+    const float fz = (coord - center_).norm();
+    const float ftmp = kMat_[0](0, 0) + kMat_[0](1, 1);
+    if (ftmp == 0.0) return 1.0;
+    return 2.0 * fz * (0x0001 << level) / ftmp;
+}
+float Camera::getLevel(const Eigen::Vector4f& coord, const float scale) const {
+    const float fz = (coord - center_).norm();
+    return std::log2(scale * (float)(kMat_[0](0, 0) + kMat_[0](1, 1)) / (2.0 * fz));
+}
+int Camera::getLeveli(const Eigen::Vector4f& coord, const float scale, const int maxLevel) const {
+    return std::max(0, std::min(maxLevel, (int)std::round(getLevel(coord, scale))));
+}
+
+// ---------------------------------------------------------------- Image (reference src/hpmvs/Image.cpp:33-66)
+void Image::init(const mo3d::NVM_Camera* cam, const int maxLevel) {
+    path_ = cam->filename;
+    f_ = cam->f;
+    k1_ = cam->r;
+    maxLevel_ = std::max(1, maxLevel);
+}
+void Image::setPixels(int width, int height, const uint8_t* rgb) {
+    width_ = width; height_ = height;
+    rgb_.assign(rgb, rgb + (size_t)width * height * 3);
+}
+bool Image::load() {
+    if (!rgb_.empty()) return true;  // pixels were handed over with setPixels
+    if (k1_ != 0) { std::cerr << "Image::load: radial undistortion (k1 != 0) is outside this path\n"; return false; }
+    std::ifstream in(path_.c_str(), std::ios::binary);
+    std::string magic;
+    int w = 0, h = 0, maxv = 0;
+    in >> magic >> w >> h >> maxv;
+    if (!in || magic != "P6" || maxv != 255 || w <= 0 || h <= 0) return false;
+    in.get();
+    rgb_.resize((size_t)w * h * 3);
+    in.read((char*)rgb_.data(), rgb_.size());
+    if (!in) return false;
+    width_ = w; height_ = h;
+    return true;
+}
+
+// ---------------------------------------------------------------- Scene view
+Scene::Scene() : dev_(nullptr), device_(0), maxLevel_(5) {
+    if (const char* e = getenv("HPMVS_DEVICE")) device_ = atoi(e);
+}
+Scene::~Scene() { if (dev_) hpmvs_scene_destroy(dev_); }
+
+bool Scene::addCameras(const NVM_Model& model, const HpmvsOptions& options) {
+    maxLevel_ = options.MAXLEVEL;
+    for (const NVM_Camera& cam : model.cameras) {
+        const int id = (int)cameras_.size();
+        cameras_.emplace_back();
+        images_.emplace_back();
+        dict_[cam.filename] = id;
+    }
+    for (size_t ii = 0; ii < model.cameras.size(); ii++) {
+        const int camId = dict_[model.cameras[ii].filename];
+        images_[camId].init(&model.cameras[ii], options.MAXLEVEL);
+        if (!images_[camId].load()) return false;
+        cameras_[camId].init(&model.cameras[ii], images_[camId].getWidth(), images_[camId].getHeight(), options.MAXLEVEL);
+    }
+    return true;
+}
+
+bool Scene::extractCoVisiblilty(const NVM_Model& model, const HpmvsOptions&) {
+    const int nCams = (int)model.cameras.size();
+    if (nCams != (int)cameras_.size()) return false;
+    std::vector<int> vis((size_t)nCams * nCams, 0);
+    for (const NVM_Point& p : model.points) {
+        const int m = (int)p.measurements.size();
+        // the reference counts by measurement POSITION, not camera id (Scene.cpp:260-264); kept
+        for (int ii = 0; ii < m; ii++)
+            for (int jj = 0; jj < m; jj++)
+                if (ii != jj && ii < nCams && jj < nCams) vis[(size_t)ii * nCams + jj]++;
+    }
+    covis_.clear();
+    covis_.resize(nCams);
+    for (int ii = 0; ii < nCams; ii++)
+        for (int jj = 0; jj < nCams; jj++)
+            if (vis[(size_t)ii * nCams + jj] >= 50) covis_[ii].emplace_back(jj);
+    return true;
+}
+
+hpmvs_scene* Scene::deviceScene() const {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (dev_) return dev_;
+    hpmvs_scene* s = nullptr;
+    if (hpmvs_scene_create((int)cameras_.size(), device_, &s) != HPMVS_OK) {
+        std::cerr << "hpmvs: " << hpmvs_last_error() << std::endl;
+        return nullptr;
+    }
+    for (size_t i = 0; i < cameras_.size(); i++) {
+        const Camera& c = cameras_[i];
+        hpmvs_camera hc;
+        memcpy(hc.P0, c.projection_[0].m, sizeof(float) * 12);
+        for (int k = 0; k < 4; k++) hc.center[k] = c.center_[k];
+        for (int k = 0; k < 3; k++) { hc.xaxis[k] = c.xAxis_[k]; hc.yaxis[k] = c.yAxis_[k]; hc.zaxis[k] = c.zAxis_[k]; }
+        hc.fsum = c.kMat_[0](0, 0) + c.kMat_[0](1, 1);
+        hc.n_levels = c.getLevels();
+        if (hpmvs_scene_set_view(s, (int)i, images_[i].getWidth(), images_[i].getHeight(), images_[i].pixels().data(), 0,
+                                 &hc) != HPMVS_OK ||
+            hpmvs_scene_set_covis(s, (int)i, covis_[i].data(), (int)covis_[i].size()) != HPMVS_OK) {
+            std::cerr << "hpmvs: " << hpmvs_last_error() << std::endl;
+            hpmvs_scene_destroy(s);
+            return nullptr;
+        }
+    }
+    if (hpmvs_scene_commit(s) != HPMVS_OK) {
+        std::cerr << "hpmvs: " << hpmvs_last_error() << std::endl;
+        hpmvs_scene_destroy(s);
+        return nullptr;
+    }
+    dev_ = s;
+    return dev_;
+}
+
+// ---------------------------------------------------------------- PatchOptimizer
+PatchOptimizer::PatchOptimizer(const mo3d::HpmvsOptions& options, const mo3d::Scene* scene)
+    : options_p(&options), scene_p(scene) {}
+
+bool PatchOptimizer::optimize(mo3d::Patch3d& patch) {
+    mo3d::Patch3d* p = &patch;
+    uint8_t ok = 0;
+    optimizeBatch(&p, 1, &ok);
+    return ok != 0;
+}
+
+size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, uint8_t* ok) {
+    lastF_.assign(n, 0.0);
+    lastEvals_.assign(n, 0);
+    for (size_t i = 0; i < n; i++) ok[i] = 0;
+    if (n == 0) return 0;
+    hpmvs_scene* dev = scene_p->deviceScene();
+    if (!dev) return 0;
+    const int stride = HPMVS_MAX_IMAGES;
+    std::vector<float> center(4 * n), normal(4 * n), scale(n), color(3 * n), ncc(n);
+    std::vector<int32_t> nimg(n), images(n * stride, -1), evals(n);
+    std::vector<double> fmin(n);
+    for (size_t i = 0; i < n; i++) {
+        const Patch3d& p = *patches[i];
+        for (int k = 0; k < 4; k++) { center[4 * i + k] = p.center_[k]; normal[4 * i + k] = p.normal_[k]; }
+        scale[i] = p.scale_3dx_;
+        // more attached images than the device cap: reported as a failed patch (stage 100)
+        nimg[i] = (int32_t)p.images_.size();
+        for (size_t k = 0; k < p.images_.size() && k < (size_t)stride; k++) images[i * stride + k] = p.images_[k];
+    }
+    hpmvs_options o;
+    o.MAXLEVEL = options_p->MAXLEVEL; o.MINLEVEL = options_p->MINLEVEL;
+    o.MAX_ANGLE = options_p->MAX_ANGLE; o.MIN_ANGLE = options_p->MIN_ANGLE;
+    o.MAX_IMAGES_PER_PATCH = options_p->MAX_IMAGES_PER_PATCH; o.MIN_IMAGES_PER_PATCH = options_p->MIN_IMAGES_PER_PATCH;
+    o.NCC_ALPHA_1 = options_p->NCC_ALPHA_1; o.NCC_ALPHA_2 = options_p->NCC_ALPHA_2;
+    hpmvs_patch_batch b;
+    memset(&b, 0, sizeof(b));
+    b.n = (int32_t)n; b.max_images = stride;
+    b.center = center.data(); b.normal = normal.data(); b.scale = scale.data();
+    b.n_images = nimg.data(); b.images = images.data();
+    b.ok = ok; b.color = color.data(); b.ncc = ncc.data(); b.fmin = fmin.data(); b.nevals = evals.data();
+    if (hpmvs_optimize_batch(dev, &o, &b, 0, nullptr) != HPMVS_OK) {
+        std::cerr << "patch optimization failed: <" << hpmvs_last_error() << ">" << std::endl;
+        for (size_t i = 0; i < n; i++) ok[i] = 0;
+        return 0;
+    }
+    size_t good = 0;
+    for (size_t i = 0; i < n; i++) {
+        lastF_[i] = fmin[i];
+        lastEvals_[i] = evals[i];
+        if (!ok[i]) continue;  // patch untouched on failure (reference PatchOptimizer.cpp:86-87)
+        Patch3d& p = *patches[i];
+        for (int k = 0; k < 4; k++) { p.center_[k] = center[4 * i + k]; p.normal_[k] = normal[4 * i + k]; }
+        p.scale_3dx_ = scale[i];
+        p.images_.assign(images.begin() + i * stride, images.begin() + i * stride + nimg[i]);
+        p.ncc_ = ncc[i];
+        p.color_ = Eigen::Vector3f(color[3 * i], color[3 * i + 1], color[3 * i + 2]);
+        good++;
+    }
+    return good;
+}
+
+}  // namespace mo3d

@@ -1,0 +1,35 @@
+// mo3d::PatchOptimizer -- the drop-in boundary.  Same class name, namespace, constructor and
+// optimize() as the reference (include/hpmvs/PatchOptimizer.h:39-43); copyable and cheap to
+// construct (the reference holds one per thread in a std::vector: src/hpmvs/Scene.cpp:94-96,
+// src/main.cpp:123-125).  optimize() is a batch of one through the C ABI; optimizeBatch() is the
+// additive entry for callers that can hand over many independent patches at once (the seed loop of
+// Scene::initPatches, Scene.cpp:114-167).
+#ifndef HPMVS_PATCHOPTIMIZER_H
+#define HPMVS_PATCHOPTIMIZER_H
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+#include <hpmvs/Patch3d.h>
+namespace mo3d {
+class HpmvsOptions;
+class Scene;
+class PatchOptimizer {
+public:
+    PatchOptimizer(const mo3d::HpmvsOptions& options, const mo3d::Scene* scene);
+    // false = drop this patch (patch untouched), exactly the reference's convention; infrastructure
+    // errors (HIP failure, no device) also return false after logging to stderr.
+    bool optimize(mo3d::Patch3d& patch);
+    // ok[i] = result of optimize(*patches[i]); returns the number of successes
+    size_t optimizeBatch(mo3d::Patch3d* const* patches, size_t n, uint8_t* ok);
+    // diagnostics of the last optimize()/optimizeBatch() call that the reference computes and drops
+    // (final mean robust INCC f*, PatchOptimizer.cpp:365,376): one entry per patch
+    const std::vector<double>& lastObjective() const { return lastF_; }
+    const std::vector<int>& lastEvaluations() const { return lastEvals_; }
+private:
+    const mo3d::HpmvsOptions* options_p;
+    const mo3d::Scene* scene_p;
+    std::vector<double> lastF_;
+    std::vector<int> lastEvals_;
+};
+}  // namespace mo3d
+#endif

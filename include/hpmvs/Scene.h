@@ -1,0 +1,44 @@
+// mo3d::Scene -- the part of the reference's Scene the refinement path reads (reference
+// include/hpmvs/Scene.h:69-71: cameras_, images_, covis_; cached by PatchOptimizer at
+// src/hpmvs/PatchOptimizer.cpp:38-41).  The octree, depth maps and the scheduler stay with the host
+// application.  The scene must be complete before the first PatchOptimizer is constructed and is
+// immutable afterwards, exactly as in the reference; at that point it is uploaded to HBM once and
+// shared by every optimizer instance.
+#ifndef HPMVS_SCENE_H_
+#define HPMVS_SCENE_H_
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <hpmvs/Camera.h>
+#include <hpmvs/HpmvsOptions.h>
+#include <hpmvs/Image.h>
+#include <hpmvs/NVMReader.h>
+#include <hpmvs/Patch3d.h>
+struct hpmvs_scene;
+namespace mo3d {
+class Scene {
+public:
+    Scene();
+    virtual ~Scene();
+    // Scene::addCameras (src/hpmvs/Scene.cpp:42-88) minus the depth maps: Image::load + Camera::init
+    bool addCameras(const NVM_Model& model, const HpmvsOptions& options);
+    // Scene::extractCoVisiblilty (src/hpmvs/Scene.cpp:241-298), including its positional-index quirk
+    bool extractCoVisiblilty(const NVM_Model& model, const HpmvsOptions& options);
+    std::map<std::string, int> dict_;
+    std::vector<Camera> cameras_;
+    std::vector<Image> images_;
+    std::vector<std::vector<int> > covis_;
+    // HBM-resident copy, created on first use (thread-safe), device = HPMVS_DEVICE env or 0
+    hpmvs_scene* deviceScene() const;
+    int device() const { return device_; }
+    void setDevice(int d) { device_ = d; }
+private:
+    mutable hpmvs_scene* dev_;
+    mutable std::mutex mu_;
+    int device_;
+    int maxLevel_;
+};
+}  // namespace mo3d
+#endif

@@ -1,0 +1,91 @@
+// A caller written the way the reference's own callers are (Scene::initPatches, src/hpmvs/Scene.cpp:94-178;
+// CellProcessor::extend, src/hpmvs/CellProcessor.cpp:129): build the scene, construct
+// mo3d::PatchOptimizer(options, &scene), call optimize(patch) and read the patch back.
+// Input: a binary dump written by tests/test_gpu_cpp_interface.py.  Output: one text line per patch.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include <hpmvs/HpmvsOptions.h>
+#include <hpmvs/PatchOptimizer.h>
+#include <hpmvs/Scene.h>
+
+template <typename T> static T rd(FILE* f) { T v; if (fread(&v, sizeof(T), 1, f) != 1) { perror("read"); exit(2); } return v; }
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    mo3d::HpmvsOptions options;
+    mo3d::Scene scene;
+    mo3d::NVM_Model model;
+    const int nv = rd<int>(f);
+    std::vector<std::vector<unsigned char> > pix(nv);
+    std::vector<int> W(nv), H(nv);
+    for (int i = 0; i < nv; i++) {
+        mo3d::NVM_Camera cam;
+        cam.filename = "view" + std::to_string(i);
+        W[i] = rd<int>(f); H[i] = rd<int>(f);
+        cam.f = rd<double>(f);
+        for (int k = 0; k < 4; k++) cam.rq[k] = rd<double>(f);
+        for (int k = 0; k < 3; k++) cam.c[k] = rd<double>(f);
+        cam.r = 0.0;
+        pix[i].resize((size_t)W[i] * H[i] * 3);
+        if (fread(pix[i].data(), 1, pix[i].size(), f) != pix[i].size()) return 2;
+        model.cameras.push_back(cam);
+    }
+    // what Scene::addCameras does, with the pixels handed over instead of decoded from JPEG files
+    for (int i = 0; i < nv; i++) {
+        scene.cameras_.emplace_back();
+        scene.images_.emplace_back();
+        scene.dict_[model.cameras[i].filename] = i;
+        scene.images_[i].init(&model.cameras[i], options.MAXLEVEL);
+        scene.images_[i].setPixels(W[i], H[i], pix[i].data());
+        scene.cameras_[i].init(&model.cameras[i], scene.images_[i].getWidth(), scene.images_[i].getHeight(), options.MAXLEVEL);
+    }
+    scene.covis_.resize(nv);
+    for (int i = 0; i < nv; i++) {
+        const int m = rd<int>(f);
+        for (int k = 0; k < m; k++) scene.covis_[i].push_back(rd<int>(f));
+    }
+    const int np = rd<int>(f);
+    std::vector<mo3d::Ppatch3d> patches;
+    for (int i = 0; i < np; i++) {
+        mo3d::Ppatch3d p(new mo3d::Patch3d);
+        for (int k = 0; k < 4; k++) p->center_[k] = rd<float>(f);
+        for (int k = 0; k < 4; k++) p->normal_[k] = rd<float>(f);
+        p->scale_3dx_ = rd<float>(f);
+        const int m = rd<int>(f);
+        for (int k = 0; k < m; k++) p->images_.push_back(rd<int>(f));
+        patches.push_back(p);
+    }
+    fclose(f);
+
+    // one optimizer per "thread", held by value like the reference does
+    std::vector<mo3d::PatchOptimizer> optimizers;
+    for (int i = 0; i < 2; i++) optimizers.emplace_back(options, &scene);
+
+    // (1) the unchanged-caller form: one patch at a time on copies
+    const int nsingle = np < 8 ? np : 8;
+    for (int i = 0; i < nsingle; i++) {
+        mo3d::Patch3d copy(*patches[i]);
+        const bool ok = optimizers[i % 2].optimize(copy);
+        printf("single %d %d %.9g %.9g %.9g %.9g %.9g %.9g %zu\n", i, ok ? 1 : 0, copy.center_[0], copy.center_[1],
+               copy.center_[2], copy.normal_[0], copy.normal_[1], copy.normal_[2], copy.images_.size());
+    }
+    // (2) the additive batch entry
+    std::vector<mo3d::Patch3d*> raw;
+    for (auto& p : patches) raw.push_back(p.get());
+    std::vector<unsigned char> ok(np);
+    const size_t good = optimizers[0].optimizeBatch(raw.data(), raw.size(), ok.data());
+    for (int i = 0; i < np; i++) {
+        const mo3d::Patch3d& p = *patches[i];
+        printf("batch %d %d %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %zu", i, (int)ok[i], p.center_[0], p.center_[1],
+               p.center_[2], p.normal_[0], p.normal_[1], p.normal_[2], p.color_[0], p.color_[1], p.color_[2], p.ncc_,
+               p.images_.size());
+        for (int id : p.images_) printf(" %d", id);
+        printf("\n");
+    }
+    printf("good %zu\n", good);
+    return 0;
+}

@@ -1,0 +1,57 @@
+"""The drop-in C++ interface (mo3d::PatchOptimizer::optimize / optimizeBatch, include/hpmvs/*.h) driven by a
+reference-style caller (tests/native/test_patchoptimizer.cpp) must give exactly what the C ABI gives."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_patchoptimizer_equals_c_abi(tiny_scene, tiny_seeds, gpu_scene, tmp_path):
+    from hpmvs_amd import api
+    exe = os.path.join(ROOT, "tests", "native", "test_patchoptimizer")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe), "all"], check=True, capture_output=True)
+    n = 96
+    dump = tmp_path / "scene.bin"
+    with open(dump, "wb") as f:
+        f.write(struct.pack("i", tiny_scene.n_views))
+        for v in tiny_scene.views:
+            f.write(struct.pack("iid4d3d", v.width, v.height, v.f, *v.q, *v.c))
+            f.write(np.ascontiguousarray(v.rgb, dtype=np.uint8).tobytes())
+        for lst in tiny_scene.covis:
+            f.write(struct.pack("i", len(lst)) + struct.pack(f"{len(lst)}i", *lst))
+        f.write(struct.pack("i", n))
+        for k in range(n):
+            m = int(tiny_seeds.n_images[k])
+            f.write(tiny_seeds.center[k].astype(np.float32).tobytes() + tiny_seeds.normal[k].astype(np.float32).tobytes())
+            f.write(struct.pack("fi", float(tiny_seeds.scale[k]), m) + struct.pack(f"{m}i", *tiny_seeds.images[k, :m]))
+    out = subprocess.run([exe, str(dump)], check=True, capture_output=True, text=True).stdout.splitlines()
+    batch = api.Batch.from_seeds(tiny_seeds, np.arange(n))
+    api.optimize_batch(gpu_scene, batch)
+    rows = [l.split() for l in out if l.startswith("batch")]
+    assert len(rows) == n
+    for r in rows:
+        k, ok = int(r[1]), int(r[2])
+        assert ok == batch.ok[k]
+        if ok:
+            vals = np.array([float(t) for t in r[3:13]], dtype=np.float32)
+            want = np.concatenate([batch.center[k, :3], batch.normal[k, :3], batch.color[k], [batch.ncc[k]]]).astype(np.float32)
+            assert np.array_equal(vals, want), (k, vals, want)
+            m = int(r[13])
+            assert m == batch.n_images[k] and [int(t) for t in r[14:14 + m]] == list(batch.images[k, :m])
+        else:  # untouched
+            vals = np.array([float(t) for t in r[3:9]], dtype=np.float32)
+            assert np.array_equal(vals, np.concatenate([tiny_seeds.center[k, :3], tiny_seeds.normal[k, :3]]).astype(np.float32))
+    # single-patch optimize() == the same patch inside the batch
+    for r in [l.split() for l in out if l.startswith("single")]:
+        k, ok = int(r[1]), int(r[2])
+        assert ok == batch.ok[k]
+        if ok:
+            vals = np.array([float(t) for t in r[3:9]], dtype=np.float32)
+            assert np.array_equal(vals, np.concatenate([batch.center[k, :3], batch.normal[k, :3]]).astype(np.float32))
+    assert int(out[-1].split()[1]) == int(batch.ok.sum())
