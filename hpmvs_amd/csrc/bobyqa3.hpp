@@ -54,42 +54,104 @@ enum {
     BQ_NEED_RESCUE = -100
 };
 
-struct Bobyqa3 {
-    static constexpr int N = 3, NPT = 7, NP = 4, NPTM = 3, NDIM = 10;
-    // ---- outputs / interface
-    double xeval[N];   // point to evaluate (original, unscaled variables)
-    double xfinal[N];
-    double minf;
-    int rc;
-    int nevals;
-    // ---- problem
-    double sc[N];          // variable scaling (dx_i / dx_0)
-    double xl[N], xu[N];   // bounds in scaled variables
-    double rhobeg, rhoend;
-    int maxeval;
-    // ---- model + geometry state (names as in Powell's paper / bobyqb_)
-    double x[N];
-    double xbase[N], xopt[N], gopt[N], sl[N], su[N], xnew[N], xalt[N], d[N], gnew[N];
-    double xpt[NPT * N];
-    double fval[NPT], pq[NPT];
-    double hq[6];
-    double bmat[NDIM * N];
-    double zmat[NPT * NPTM];
-    double vlag[NDIM];
-    double wsuma[NPT];     // w(npt+k) of bobyqb_: (xpt_k . d), needed after the evaluation
-    // ---- scalars that live across evaluations
-    double rho, delta, diffa, diffb, diffc, dsq, crvmin, dnorm, xoptsq, ratio, adelt, alpha, cauchy, beta,
-        denom, fsave, distsq, fbeg, stepa, stepb;
-    int kopt, knew, kbase, ntrits, itest, nresc, nfsav, nf, phase;
+// ---- state storage ------------------------------------------------------------------------
+// All optimiser state is addressed through BQ_D(index) / BQ_I(index):
+//   host build : a plain struct of two arrays;
+//   device build (BQ_STATE_LDS defined before inclusion, BQ_P = patches per wavefront): the state of
+//   the BQ_P patches a wavefront owns lives in LDS as [index][slot], so that the lanes of a wave
+//   touch consecutive 8-byte words (conflict-free ds_read_b64 / ds_write_b64) and nothing of the
+//   ~1.4 KB per patch goes through scratch / HBM.
+enum {  // float64 slots: arrays first (names as in Powell's paper / bobyqb_), then scalars
+    O_xeval = 0,
+    O_xfinal = 3,
+    O_sc = 6,
+    O_xl = 9,
+    O_xu = 12,
+    O_x = 15,
+    O_xbase = 18,
+    O_xopt = 21,
+    O_gopt = 24,
+    O_sl = 27,
+    O_su = 30,
+    O_xnew = 33,
+    O_xalt = 36,
+    O_d = 39,
+    O_gnew = 42,
+    O_xpt = 45,
+    O_fval = 66,
+    O_pq = 73,
+    O_hq = 80,
+    O_bmat = 86,
+    O_zmat = 116,
+    O_vlag = 137,
+    O_wsuma = 147,
+    O_minf = 154,
+    O_rhobeg = 155,
+    O_rhoend = 156,
+    O_rho = 157,
+    O_delta = 158,
+    O_diffa = 159,
+    O_diffb = 160,
+    O_diffc = 161,
+    O_dsq = 162,
+    O_crvmin = 163,
+    O_dnorm = 164,
+    O_xoptsq = 165,
+    O_ratio = 166,
+    O_adelt = 167,
+    O_alpha = 168,
+    O_cauchy = 169,
+    O_beta = 170,
+    O_denom = 171,
+    O_fsave = 172,
+    O_distsq = 173,
+    O_fbeg = 174,
+    O_stepa = 175,
+    O_stepb = 176,
+    BQ_ND = 177
+};
+enum {  // int32 slots
+    I_rc = 0,
+    I_nevals = 1,
+    I_maxeval = 2,
+    I_kopt = 3,
+    I_knew = 4,
+    I_kbase = 5,
+    I_ntrits = 6,
+    I_itest = 7,
+    I_nresc = 8,
+    I_nfsav = 9,
+    I_nf = 10,
+    I_phase = 11,
+    BQ_NI = 12
 };
 
-#define BQ_XPT(k, i) B.xpt[((k) - 1) * 3 + ((i) - 1)]
-#define BQ_BMAT(k, i) B.bmat[((k) - 1) * 3 + ((i) - 1)]
-#define BQ_ZMAT(k, j) B.zmat[((k) - 1) * 3 + ((j) - 1)]
-#define BQ_FVAL(k) B.fval[(k) - 1]
-#define BQ_PQ(k) B.pq[(k) - 1]
-#define BQ_HQ(ih) B.hq[(ih) - 1]
-#define BQ_V(a, i) B.a[(i) - 1]
+#if defined(BQ_STATE_LDS)
+#ifndef BQ_P
+#error "define BQ_P (patches per wavefront) together with BQ_STATE_LDS"
+#endif
+__shared__ double bq_lds_d[BQ_ND * BQ_P];
+__shared__ int bq_lds_i[BQ_NI * BQ_P];
+struct Bobyqa3 { int slot; };
+#define BQ_D(i) bq_lds_d[(i) * BQ_P + B.slot]
+#define BQ_I(i) bq_lds_i[(i) * BQ_P + B.slot]
+#else
+struct Bobyqa3 { double dd[BQ_ND]; int ii[BQ_NI]; };
+#define BQ_D(i) B.dd[(i)]
+#define BQ_I(i) B.ii[(i)]
+#endif
+
+#define BQA(name, idx) BQ_D(O_##name + (idx))   // 0-based element of a named array
+#define BQS(name) BQ_D(O_##name)                // float64 scalar
+#define BQN(name) BQ_I(I_##name)                // int scalar
+// 1-based accessors like the mathematics
+#define BQ_XPT(k, i) BQ_D(O_xpt + ((k) - 1) * 3 + ((i) - 1))
+#define BQ_BMAT(k, i) BQ_D(O_bmat + ((k) - 1) * 3 + ((i) - 1))
+#define BQ_ZMAT(k, j) BQ_D(O_zmat + ((k) - 1) * 3 + ((j) - 1))
+#define BQ_FVAL(k) BQ_D(O_fval + (k) - 1)
+#define BQ_PQ(k) BQ_D(O_pq + (k) - 1)
+#define BQ_HQ(ih) BQ_D(O_hq + (ih) - 1)
+#define BQ_V(a, i) BQ_D(O_##a + (i) - 1)
 
 namespace bq {
 
@@ -102,71 +164,72 @@ enum { L20 = 0, L60, L90, L210, L230, L360, L650, L680, L720 };
 
 // x (scaled) for the interpolation point / trial step `p` (relative to xbase), bounds respected
 // exactly as bobyqb_ does before each calfun (bobyqa.c:2560-2575, 1871-1883)
-BQ_HD void set_x_from(Bobyqa3& B, const double* p) {
+BQ_HD void set_x_from(Bobyqa3& B, int p_off) {  // p_off: state offset of the 3-vector p
     for (int i = 1; i <= 3; i++) {
-        double v = mn(mx(BQ_V(xl, i), BQ_V(xbase, i) + p[i - 1]), BQ_V(xu, i));
-        if (p[i - 1] == BQ_V(sl, i)) v = BQ_V(xl, i);
-        if (p[i - 1] == BQ_V(su, i)) v = BQ_V(xu, i);
+        const double pi = BQ_D(p_off + i - 1);
+        double v = mn(mx(BQ_V(xl, i), BQ_V(xbase, i) + pi), BQ_V(xu, i));
+        if (pi == BQ_V(sl, i)) v = BQ_V(xl, i);
+        if (pi == BQ_V(su, i)) v = BQ_V(xu, i);
         BQ_V(x, i) = v;
     }
-    for (int i = 0; i < 3; i++) B.xeval[i] = B.x[i] * B.sc[i];  // nlopt_unscale (util/rescale.c:55-60)
+    for (int i = 0; i < 3; i++) BQA(xeval, i) = BQA(x, i) * BQA(sc, i);  // nlopt_unscale (util/rescale.c:55-60)
 }
 
 // ---------------------------------------------------------------- prelim_ (bobyqa.c:1713-1952)
 // Choose interpolation point nf+1 (1-based after the increment) and put it in B.x / B.xeval.
 BQ_HD void prelim_next_point(Bobyqa3& B) {
-    const int nfm = B.nf;
-    const int nfx = B.nf - 3;
-    B.nf++;
-    const int nf = B.nf;
+    const int nfm = BQN(nf);
+    const int nfx = BQN(nf) - 3;
+    BQN(nf)++;
+    const int nf = BQN(nf);
     // with npt = 2n+1 only the first two families of points occur (nfm <= 2n)
     if (nfm >= 1 && nfm <= 3) {
-        B.stepa = B.rhobeg;
-        if (BQ_V(su, nfm) == 0.0) B.stepa = -B.stepa;
-        BQ_XPT(nf, nfm) = B.stepa;
+        BQS(stepa) = BQS(rhobeg);
+        if (BQ_V(su, nfm) == 0.0) BQS(stepa) = -BQS(stepa);
+        BQ_XPT(nf, nfm) = BQS(stepa);
     } else if (nfm > 3) {
-        B.stepa = BQ_XPT(nf - 3, nfx);
-        B.stepb = -B.rhobeg;
-        if (BQ_V(sl, nfx) == 0.0) B.stepb = mn(2.0 * B.rhobeg, BQ_V(su, nfx));
-        if (BQ_V(su, nfx) == 0.0) B.stepb = mx(-2.0 * B.rhobeg, BQ_V(sl, nfx));
-        BQ_XPT(nf, nfx) = B.stepb;
+        BQS(stepa) = BQ_XPT(nf - 3, nfx);
+        BQS(stepb) = -BQS(rhobeg);
+        if (BQ_V(sl, nfx) == 0.0) BQS(stepb) = mn(2.0 * BQS(rhobeg), BQ_V(su, nfx));
+        if (BQ_V(su, nfx) == 0.0) BQS(stepb) = mx(-2.0 * BQS(rhobeg), BQ_V(sl, nfx));
+        BQ_XPT(nf, nfx) = BQS(stepb);
     }
-    set_x_from(B, &BQ_XPT(nf, 1));
+    set_x_from(B, O_xpt + (nf - 1) * 3);
 }
 
 // Absorb f at point nf into the initial model.
 BQ_HD void prelim_consume(Bobyqa3& B, double f) {
-    const int nf = B.nf, nfm = nf - 1, nfx = nf - 1 - 3;
-    const double rhosq = B.rhobeg * B.rhobeg;
+    const int nf = BQN(nf), nfm = nf - 1, nfx = nf - 1 - 3;
+    const double rhosq = BQS(rhobeg) * BQS(rhobeg);
     BQ_FVAL(nf) = f;
     if (nf == 1) {
-        B.fbeg = f;
-        B.kopt = 1;
-    } else if (f < BQ_FVAL(B.kopt)) {
-        B.kopt = nf;
+        BQS(fbeg) = f;
+        BQN(kopt) = 1;
+    } else if (f < BQ_FVAL(BQN(kopt))) {
+        BQN(kopt) = nf;
     }
     if (nf >= 2 && nf <= 4) {
-        BQ_V(gopt, nfm) = (f - B.fbeg) / B.stepa;
+        BQ_V(gopt, nfm) = (f - BQS(fbeg)) / BQS(stepa);
         // (npt < nf + n never holds for npt = 2n+1)
     } else if (nf >= 5) {
         const int ih = nfx * (nfx + 1) / 2;
-        const double temp = (f - B.fbeg) / B.stepb;
-        const double diff = B.stepb - B.stepa;
+        const double temp = (f - BQS(fbeg)) / BQS(stepb);
+        const double diff = BQS(stepb) - BQS(stepa);
         BQ_HQ(ih) = 2.0 * (temp - BQ_V(gopt, nfx)) / diff;
-        BQ_V(gopt, nfx) = (BQ_V(gopt, nfx) * B.stepb - temp * B.stepa) / diff;
-        if (B.stepa * B.stepb < 0.0) {
+        BQ_V(gopt, nfx) = (BQ_V(gopt, nfx) * BQS(stepb) - temp * BQS(stepa)) / diff;
+        if (BQS(stepa) * BQS(stepb) < 0.0) {
             if (f < BQ_FVAL(nf - 3)) {
                 BQ_FVAL(nf) = BQ_FVAL(nf - 3);
                 BQ_FVAL(nf - 3) = f;
-                if (B.kopt == nf) B.kopt = nf - 3;
-                BQ_XPT(nf - 3, nfx) = B.stepb;
-                BQ_XPT(nf, nfx) = B.stepa;
+                if (BQN(kopt) == nf) BQN(kopt) = nf - 3;
+                BQ_XPT(nf - 3, nfx) = BQS(stepb);
+                BQ_XPT(nf, nfx) = BQS(stepa);
             }
         }
-        BQ_BMAT(1, nfx) = -(B.stepa + B.stepb) / (B.stepa * B.stepb);
+        BQ_BMAT(1, nfx) = -(BQS(stepa) + BQS(stepb)) / (BQS(stepa) * BQS(stepb));
         BQ_BMAT(nf, nfx) = -0.5 / BQ_XPT(nf - 3, nfx);
         BQ_BMAT(nf - 3, nfx) = -BQ_BMAT(1, nfx) - BQ_BMAT(nf, nfx);
-        BQ_ZMAT(1, nfx) = sqrt(2.0) / (B.stepa * B.stepb);
+        BQ_ZMAT(1, nfx) = sqrt(2.0) / (BQS(stepa) * BQS(stepb));
         BQ_ZMAT(nf, nfx) = sqrt(0.5) / rhosq;
         BQ_ZMAT(nf - 3, nfx) = -BQ_ZMAT(1, nfx) - BQ_ZMAT(nf, nfx);
     }
@@ -179,16 +242,16 @@ BQ_HD void hess_mul(const Bobyqa3& B, const double* s, double* hs) {
         hs[j - 1] = 0.0;
         for (int i = 1; i <= j; i++) {
             ++ih;
-            if (i < j) hs[j - 1] += B.hq[ih - 1] * s[i - 1];
-            hs[i - 1] += B.hq[ih - 1] * s[j - 1];
+            if (i < j) hs[j - 1] += BQA(hq, ih - 1) * s[i - 1];
+            hs[i - 1] += BQA(hq, ih - 1) * s[j - 1];
         }
     }
     for (int k = 1; k <= 7; k++) {
-        if (B.pq[k - 1] != 0.0) {
+        if (BQA(pq, k - 1) != 0.0) {
             double temp = 0.0;
-            for (int j = 1; j <= 3; j++) temp += B.xpt[(k - 1) * 3 + j - 1] * s[j - 1];
-            temp *= B.pq[k - 1];
-            for (int i = 1; i <= 3; i++) hs[i - 1] += temp * B.xpt[(k - 1) * 3 + i - 1];
+            for (int j = 1; j <= 3; j++) temp += BQA(xpt, (k - 1) * 3 + j - 1) * s[j - 1];
+            temp *= BQA(pq, k - 1);
+            for (int i = 1; i <= 3; i++) hs[i - 1] += temp * BQA(xpt, (k - 1) * 3 + i - 1);
         }
     }
 }
@@ -196,30 +259,25 @@ BQ_HD void hess_mul(const Bobyqa3& B, const double* s, double* hs) {
 // ---------------------------------------------------------------- trsbox_ (bobyqa.c:1162-1711)
 // Approximately minimise the model within ||d|| <= delta and the bounds: truncated conjugate
 // gradients with restarts on newly active bounds, then 2-D searches on the boundary.
-// Sets B.xnew, B.d, B.gnew, B.dsq, B.crvmin.
+// Sets B.xnew, B.d, B.gnew, BQS(dsq), BQS(crvmin).
 BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
     double xbdi[3], s[3] = {0, 0, 0}, hs[3], hred[3] = {0, 0, 0};
-    double* d = B.d;
-    double* gnew = B.gnew;
-    const double* xopt = B.xopt;
-    const double* sl = B.sl;
-    const double* su = B.su;
     int iterc = 0, nact = 0, itermax = 0, iact = 0, itcsav = 0, isav, iu;
     double delsq, qred = 0.0, crvmin = -1.0, beta = 0.0, stepsq, gredsq = 0.0, resid, ds, shs, temp, blen, stplen,
                   sdec, ggsav = 0.0, dredsq = 0.0, dredg = 0.0, sredg = 0.0, angbd = 0.0, xsav = 0.0, ssq, tempa,
                   tempb, dhs, dhd, redmax, redsav, angt = 0.0, sth, cth, rednew, rdprev = 0.0, rdnext = 0.0;
     for (int i = 0; i < 3; i++) {
         xbdi[i] = 0.0;
-        if (xopt[i] <= sl[i]) {
-            if (B.gopt[i] >= 0.0) xbdi[i] = -1.0;
-        } else if (xopt[i] >= su[i]) {
-            if (B.gopt[i] <= 0.0) xbdi[i] = 1.0;
+        if (BQA(xopt, i) <= BQA(sl, i)) {
+            if (BQA(gopt, i) >= 0.0) xbdi[i] = -1.0;
+        } else if (BQA(xopt, i) >= BQA(su, i)) {
+            if (BQA(gopt, i) <= 0.0) xbdi[i] = 1.0;
         }
         if (xbdi[i] != 0.0) ++nact;
-        d[i] = 0.0;
-        gnew[i] = B.gopt[i];
+        BQA(d, i) = 0.0;
+        BQA(gnew, i) = BQA(gopt, i);
     }
-    delsq = B.delta * B.delta;
+    delsq = BQS(delta) * BQS(delta);
 
     enum { CG_RESTART, CG_NEXT, BOUNDARY, ALT_SETUP, ALT_ITER, FINISH };
     int st = CG_RESTART;
@@ -229,8 +287,8 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             stepsq = 0.0;
             for (int i = 0; i < 3; i++) {
                 if (xbdi[i] != 0.0) s[i] = 0.0;
-                else if (beta == 0.0) s[i] = -gnew[i];
-                else s[i] = beta * s[i] - gnew[i];
+                else if (beta == 0.0) s[i] = -BQA(gnew, i);
+                else s[i] = beta * s[i] - BQA(gnew, i);
                 stepsq += s[i] * s[i];
             }
             if (stepsq == 0.0) { st = FINISH; continue; }
@@ -239,7 +297,7 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             hess_mul(B, s, hs);
             resid = delsq; ds = 0.0; shs = 0.0;
             for (int i = 0; i < 3; i++)
-                if (xbdi[i] == 0.0) { resid -= d[i] * d[i]; ds += s[i] * d[i]; shs += s[i] * hs[i]; }
+                if (xbdi[i] == 0.0) { resid -= BQA(d, i) * BQA(d, i); ds += s[i] * BQA(d, i); shs += s[i] * hs[i]; }
             if (resid <= 0.0) { st = BOUNDARY; continue; }
             temp = sqrt(stepsq * resid + ds * ds);
             if (ds < 0.0) blen = (temp - ds) / stepsq;
@@ -249,9 +307,9 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             iact = 0;
             for (int i = 0; i < 3; i++)
                 if (s[i] != 0.0) {
-                    const double xsum = xopt[i] + d[i];
-                    if (s[i] > 0.0) temp = (su[i] - xsum) / s[i];
-                    else temp = (sl[i] - xsum) / s[i];
+                    const double xsum = BQA(xopt, i) + BQA(d, i);
+                    if (s[i] > 0.0) temp = (BQA(su, i) - xsum) / s[i];
+                    else temp = (BQA(sl, i) - xsum) / s[i];
                     if (temp < stplen) { stplen = temp; iact = i + 1; }
                 }
             sdec = 0.0;
@@ -265,9 +323,9 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
                 ggsav = gredsq;
                 gredsq = 0.0;
                 for (int i = 0; i < 3; i++) {
-                    gnew[i] += stplen * hs[i];
-                    if (xbdi[i] == 0.0) gredsq += gnew[i] * gnew[i];
-                    d[i] += stplen * s[i];
+                    BQA(gnew, i) += stplen * hs[i];
+                    if (xbdi[i] == 0.0) gredsq += BQA(gnew, i) * BQA(gnew, i);
+                    BQA(d, i) += stplen * s[i];
                 }
                 sdec = mx(stplen * (ggsav - 0.5 * stplen * shs), 0.0);
                 qred += sdec;
@@ -276,7 +334,7 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
                 ++nact;
                 xbdi[iact - 1] = 1.0;
                 if (s[iact - 1] < 0.0) xbdi[iact - 1] = -1.0;
-                delsq -= d[iact - 1] * d[iact - 1];
+                delsq -= BQA(d, iact - 1) * BQA(d, iact - 1);
                 if (delsq <= 0.0) { st = BOUNDARY; continue; }
                 st = CG_RESTART;
                 continue;
@@ -296,10 +354,10 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             dredsq = 0.0; dredg = 0.0; gredsq = 0.0;
             for (int i = 0; i < 3; i++) {
                 if (xbdi[i] == 0.0) {
-                    dredsq += d[i] * d[i];
-                    dredg += d[i] * gnew[i];
-                    gredsq += gnew[i] * gnew[i];
-                    s[i] = d[i];
+                    dredsq += BQA(d, i) * BQA(d, i);
+                    dredg += BQA(d, i) * BQA(gnew, i);
+                    gredsq += BQA(gnew, i) * BQA(gnew, i);
+                    s[i] = BQA(d, i);
                 } else s[i] = 0.0;
             }
             itcsav = iterc;
@@ -313,7 +371,7 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             if (temp <= qred * 1e-4 * qred) { st = FINISH; continue; }
             temp = sqrt(temp);
             for (int i = 0; i < 3; i++) {
-                if (xbdi[i] == 0.0) s[i] = (dredg * d[i] - dredsq * gnew[i]) / temp;
+                if (xbdi[i] == 0.0) s[i] = (dredg * BQA(d, i) - dredsq * BQA(gnew, i)) / temp;
                 else s[i] = 0.0;
             }
             sredg = -temp;
@@ -322,17 +380,17 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             bool refix = false;
             for (int i = 0; i < 3; i++) {
                 if (xbdi[i] == 0.0) {
-                    tempa = xopt[i] + d[i] - sl[i];
-                    tempb = su[i] - xopt[i] - d[i];
+                    tempa = BQA(xopt, i) + BQA(d, i) - BQA(sl, i);
+                    tempb = BQA(su, i) - BQA(xopt, i) - BQA(d, i);
                     if (tempa <= 0.0) { ++nact; xbdi[i] = -1.0; refix = true; break; }
                     else if (tempb <= 0.0) { ++nact; xbdi[i] = 1.0; refix = true; break; }
-                    ssq = d[i] * d[i] + s[i] * s[i];
-                    temp = ssq - (xopt[i] - sl[i]) * (xopt[i] - sl[i]);
+                    ssq = BQA(d, i) * BQA(d, i) + s[i] * s[i];
+                    temp = ssq - (BQA(xopt, i) - BQA(sl, i)) * (BQA(xopt, i) - BQA(sl, i));
                     if (temp > 0.0) {
                         temp = sqrt(temp) - s[i];
                         if (angbd * temp > tempa) { angbd = tempa / temp; iact = i + 1; xsav = -1.0; }
                     }
-                    temp = ssq - (su[i] - xopt[i]) * (su[i] - xopt[i]);
+                    temp = ssq - (BQA(su, i) - BQA(xopt, i)) * (BQA(su, i) - BQA(xopt, i));
                     if (temp > 0.0) {
                         temp = sqrt(temp) + s[i];
                         if (angbd * temp > tempb) { angbd = tempb / temp; iact = i + 1; xsav = 1.0; }
@@ -343,7 +401,7 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             hess_mul(B, s, hs);
             shs = 0.0; dhs = 0.0; dhd = 0.0;
             for (int i = 0; i < 3; i++)
-                if (xbdi[i] == 0.0) { shs += s[i] * hs[i]; dhs += d[i] * hs[i]; dhd += d[i] * hred[i]; }
+                if (xbdi[i] == 0.0) { shs += s[i] * hs[i]; dhs += BQA(d, i) * hs[i]; dhd += BQA(d, i) * hred[i]; }
             redmax = 0.0; isav = 0; redsav = 0.0;
             iu = (int)(angbd * 17. + 3.1);
             for (int i = 1; i <= iu; i++) {
@@ -367,11 +425,11 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             if (sdec <= 0.0) { st = FINISH; continue; }
             dredg = 0.0; gredsq = 0.0;
             for (int i = 0; i < 3; i++) {
-                gnew[i] = gnew[i] + (cth - 1.0) * hred[i] + sth * hs[i];
+                BQA(gnew, i) = BQA(gnew, i) + (cth - 1.0) * hred[i] + sth * hs[i];
                 if (xbdi[i] == 0.0) {
-                    d[i] = cth * d[i] + sth * s[i];
-                    dredg += d[i] * gnew[i];
-                    gredsq += gnew[i] * gnew[i];
+                    BQA(d, i) = cth * BQA(d, i) + sth * s[i];
+                    dredg += BQA(d, i) * BQA(gnew, i);
+                    gredsq += BQA(gnew, i) * BQA(gnew, i);
                 }
                 hred[i] = cth * hred[i] + sth * hs[i];
             }
@@ -382,32 +440,32 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
         }
         if (st == FINISH) break;
     }
-    B.dsq = 0.0;
+    BQS(dsq) = 0.0;
     for (int i = 0; i < 3; i++) {
-        B.xnew[i] = mx(mn(xopt[i] + d[i], su[i]), sl[i]);
-        if (xbdi[i] == -1.0) B.xnew[i] = sl[i];
-        if (xbdi[i] == 1.0) B.xnew[i] = su[i];
-        d[i] = B.xnew[i] - xopt[i];
-        B.dsq += d[i] * d[i];
+        BQA(xnew, i) = mx(mn(BQA(xopt, i) + BQA(d, i), BQA(su, i)), BQA(sl, i));
+        if (xbdi[i] == -1.0) BQA(xnew, i) = BQA(sl, i);
+        if (xbdi[i] == 1.0) BQA(xnew, i) = BQA(su, i);
+        BQA(d, i) = BQA(xnew, i) - BQA(xopt, i);
+        BQS(dsq) += BQA(d, i) * BQA(d, i);
     }
-    B.crvmin = crvmin;
+    BQS(crvmin) = crvmin;
 }
 
 // ---------------------------------------------------------------- altmov_ (bobyqa.c:744-1160)
 // Geometry-improving step for interpolation point knew: B.xnew (line through xopt and another
-// point), B.xalt (constrained Cauchy step), B.alpha, B.cauchy.
+// point), B.xalt (constrained Cauchy step), BQS(alpha), BQS(cauchy).
 BQ_HD_NOINLINE void altmov(Bobyqa3& B) {
     const double cst = 1.0 + sqrt(2.);
     double glag[3], hcol[7], w[3], wsave[3] = {0, 0, 0};
-    const int knew = B.knew, kopt = B.kopt;
-    const double adelt = B.adelt;
+    const int knew = BQN(knew), kopt = BQN(kopt);
+    const double adelt = BQS(adelt);
     for (int k = 1; k <= 7; k++) hcol[k - 1] = 0.0;
     for (int j = 1; j <= 3; j++) {
         const double temp = BQ_ZMAT(knew, j);
         for (int k = 1; k <= 7; k++) hcol[k - 1] += temp * BQ_ZMAT(k, j);
     }
-    B.alpha = hcol[knew - 1];
-    const double ha = 0.5 * B.alpha;
+    BQS(alpha) = hcol[knew - 1];
+    const double ha = 0.5 * BQS(alpha);
     for (int i = 1; i <= 3; i++) glag[i - 1] = BQ_BMAT(knew, i);
     for (int k = 1; k <= 7; k++) {
         double temp = 0.0;
@@ -485,7 +543,7 @@ BQ_HD_NOINLINE void altmov(Bobyqa3& B) {
             tempb = mx(BQ_V(xopt, i) - BQ_V(su, i), glag[i - 1]);
             if (tempa > 0.0 || tempb < 0.0) { w[i - 1] = bigstp; ggfree += glag[i - 1] * glag[i - 1]; }
         }
-        if (ggfree == 0.0) { B.cauchy = 0.0; return; }
+        if (ggfree == 0.0) { BQS(cauchy) = 0.0; return; }
         for (;;) {
             temp = adelt * adelt - wfixsq;
             if (!(temp > 0.0)) break;
@@ -525,25 +583,25 @@ BQ_HD_NOINLINE void altmov(Bobyqa3& B) {
                 temp = BQ_V(xopt, i) + scale * w[i - 1];
                 BQ_V(xalt, i) = mx(BQ_V(sl, i), mn(BQ_V(su, i), temp));
             }
-            B.cauchy = (0.5 * gw * scale) * (0.5 * gw * scale);
+            BQS(cauchy) = (0.5 * gw * scale) * (0.5 * gw * scale);
         } else {
-            B.cauchy = (gw + 0.5 * curv) * (gw + 0.5 * curv);
+            BQS(cauchy) = (gw + 0.5 * curv) * (gw + 0.5 * curv);
         }
         if (iflag == 0) {
-            for (int i = 0; i < 3; i++) { glag[i] = -glag[i]; wsave[i] = B.xalt[i]; }
-            csave = B.cauchy;
+            for (int i = 0; i < 3; i++) { glag[i] = -glag[i]; wsave[i] = BQA(xalt, i); }
+            csave = BQS(cauchy);
         }
     }
-    if (csave > B.cauchy) {
-        for (int i = 0; i < 3; i++) B.xalt[i] = wsave[i];
-        B.cauchy = csave;
+    if (csave > BQS(cauchy)) {
+        for (int i = 0; i < 3; i++) BQA(xalt, i) = wsave[i];
+        BQS(cauchy) = csave;
     }
 }
 
 // ---------------------------------------------------------------- update_ (bobyqa.c:18-141)
 // Update BMAT and ZMAT for the move of interpolation point knew (uses vlag, beta, denom).
 BQ_HD_NOINLINE void update(Bobyqa3& B) {
-    const int knew = B.knew;
+    const int knew = BQN(knew);
     double w[10];
     double ztest = 0.0;
     for (int k = 1; k <= 7; k++)
@@ -566,15 +624,15 @@ BQ_HD_NOINLINE void update(Bobyqa3& B) {
     const double alpha = w[knew - 1];
     const double tau = BQ_V(vlag, knew);
     BQ_V(vlag, knew) -= 1.0;
-    double temp = sqrt(B.denom);
+    double temp = sqrt(BQS(denom));
     double tempb = BQ_ZMAT(knew, 1) / temp;
     double tempa = tau / temp;
     for (int i = 1; i <= 7; i++) BQ_ZMAT(i, 1) = tempa * BQ_ZMAT(i, 1) - tempb * BQ_V(vlag, i);
     for (int j = 1; j <= 3; j++) {
         const int jp = 7 + j;
         w[jp - 1] = BQ_BMAT(knew, j);
-        tempa = (alpha * BQ_V(vlag, jp) - tau * w[jp - 1]) / B.denom;
-        tempb = (-B.beta * w[jp - 1] - tau * BQ_V(vlag, jp)) / B.denom;
+        tempa = (alpha * BQ_V(vlag, jp) - tau * w[jp - 1]) / BQS(denom);
+        tempb = (-BQS(beta) * w[jp - 1] - tau * BQ_V(vlag, jp)) / BQS(denom);
         for (int i = 1; i <= jp; i++) {
             BQ_BMAT(i, j) = BQ_BMAT(i, j) + tempa * BQ_V(vlag, i) + tempb * w[i - 1];
             if (i > 7) BQ_BMAT(jp, i - 7) = BQ_BMAT(i, j);
@@ -585,23 +643,23 @@ BQ_HD_NOINLINE void update(Bobyqa3& B) {
 // Select the interpolation point to drop for a trust-region step (bobyqa.c:2497-2545, 2648-2690):
 // maximise max(1, (dist/delta)^4) * |denominator|.  `from` is xopt before the evaluation and
 // xnew after an improving one.
-BQ_HD void pick_knew(Bobyqa3& B, const double* from, bool skip_kopt, double& scaden, double& biglsq) {
-    const double delsq = B.delta * B.delta;
+BQ_HD void pick_knew(Bobyqa3& B, int from_off, bool skip_kopt, double& scaden, double& biglsq) {
+    const double delsq = BQS(delta) * BQS(delta);
     scaden = 0.0; biglsq = 0.0;
-    B.knew = 0;
+    BQN(knew) = 0;
     for (int k = 1; k <= 7; k++) {
-        if (skip_kopt && k == B.kopt) continue;
+        if (skip_kopt && k == BQN(kopt)) continue;
         double hdiag = 0.0;
         for (int jj = 1; jj <= 3; jj++) hdiag += BQ_ZMAT(k, jj) * BQ_ZMAT(k, jj);
-        const double den = B.beta * hdiag + BQ_V(vlag, k) * BQ_V(vlag, k);
+        const double den = BQS(beta) * hdiag + BQ_V(vlag, k) * BQ_V(vlag, k);
         double distsq = 0.0;
         for (int j = 1; j <= 3; j++) {
-            const double t = BQ_XPT(k, j) - from[j - 1];
+            const double t = BQ_XPT(k, j) - BQ_D(from_off + j - 1);
             distsq += t * t;
         }
         const double q = distsq / delsq;
         const double temp = mx(1.0, q * q);
-        if (temp * den > scaden) { scaden = temp * den; B.knew = k; B.denom = den; }
+        if (temp * den > scaden) { scaden = temp * den; BQN(knew) = k; BQS(denom) = den; }
         biglsq = mx(biglsq, temp * (BQ_V(vlag, k) * BQ_V(vlag, k)));
     }
 }
@@ -614,7 +672,7 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
     for (;;) {
         switch (label) {
         case L20: {  // model gradient at xopt when kopt moved away from kbase (bobyqa.c:2149-2182)
-            if (B.kopt != B.kbase) {
+            if (BQN(kopt) != BQN(kbase)) {
                 int ih = 0;
                 for (int j = 1; j <= 3; j++)
                     for (int i = 1; i <= j; i++) {
@@ -622,7 +680,7 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
                         if (i < j) BQ_V(gopt, j) += BQ_HQ(ih) * BQ_V(xopt, i);
                         BQ_V(gopt, i) += BQ_HQ(ih) * BQ_V(xopt, j);
                     }
-                if (B.nevals > 7) {
+                if (BQN(nevals) > 7) {
                     for (int k = 1; k <= 7; k++) {
                         double temp = 0.0;
                         for (int j = 1; j <= 3; j++) temp += BQ_XPT(k, j) * BQ_V(xopt, j);
@@ -636,15 +694,15 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
         }
         case L60: {  // trust-region step (bobyqa.c:2190-2240)
             trsbox(B);
-            B.dnorm = mn(B.delta, sqrt(B.dsq));
-            if (B.dnorm < 0.5 * B.rho) {
-                B.ntrits = -1;
-                B.distsq = (10.0 * B.rho) * (10.0 * B.rho);
-                if (B.nevals <= B.nfsav + 2) { label = L650; break; }
-                const double errbig = mx(mx(B.diffa, B.diffb), B.diffc);
-                const double frhosq = B.rho * .125 * B.rho;
-                if (B.crvmin > 0.0 && errbig > frhosq * B.crvmin) { label = L650; break; }
-                const double bdtol = errbig / B.rho;
+            BQS(dnorm) = mn(BQS(delta), sqrt(BQS(dsq)));
+            if (BQS(dnorm) < 0.5 * BQS(rho)) {
+                BQN(ntrits) = -1;
+                BQS(distsq) = (10.0 * BQS(rho)) * (10.0 * BQS(rho));
+                if (BQN(nevals) <= BQN(nfsav) + 2) { label = L650; break; }
+                const double errbig = mx(mx(BQS(diffa), BQS(diffb)), BQS(diffc));
+                const double frhosq = BQS(rho) * .125 * BQS(rho);
+                if (BQS(crvmin) > 0.0 && errbig > frhosq * BQS(crvmin)) { label = L650; break; }
+                const double bdtol = errbig / BQS(rho);
                 bool to650 = false;
                 for (int j = 1; j <= 3; j++) {
                     double bdtest = bdtol;
@@ -653,26 +711,26 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
                     if (bdtest < bdtol) {
                         double curv = BQ_HQ((j + j * j) / 2);
                         for (int k = 1; k <= 7; k++) curv += BQ_PQ(k) * (BQ_XPT(k, j) * BQ_XPT(k, j));
-                        bdtest += 0.5 * curv * B.rho;
+                        bdtest += 0.5 * curv * BQS(rho);
                         if (bdtest < bdtol) { to650 = true; break; }
                     }
                 }
                 label = to650 ? L650 : L680;
                 break;
             }
-            ++B.ntrits;
+            ++BQN(ntrits);
             label = L90;
             break;
         }
         case L90: {  // shift xbase to xopt when the step is small relative to |xopt| (bobyqa.c:2246-2322)
-            if (B.dsq <= B.xoptsq * .001) {
-                const double fracsq = B.xoptsq * .25;
+            if (BQS(dsq) <= BQS(xoptsq) * .001) {
+                const double fracsq = BQS(xoptsq) * .25;
                 double sumpq = 0.0;
                 double wn[7];  // w(npt+k)
                 double vl[7];
                 for (int k = 1; k <= 7; k++) {
                     sumpq += BQ_PQ(k);
-                    double sum = -0.5 * B.xoptsq;
+                    double sum = -0.5 * BQS(xoptsq);
                     for (int i = 1; i <= 3; i++) sum += BQ_XPT(k, i) * BQ_V(xopt, i);
                     wn[k - 1] = sum;
                     const double temp = fracsq - 0.5 * sum;
@@ -723,14 +781,14 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
                     BQ_V(su, i) -= BQ_V(xopt, i);
                     BQ_V(xopt, i) = 0.0;
                 }
-                B.xoptsq = 0.0;
+                BQS(xoptsq) = 0.0;
             }
-            label = (B.ntrits == 0) ? L210 : L230;
+            label = (BQN(ntrits) == 0) ? L210 : L230;
             break;
         }
         case L210: {  // geometry step (bobyqa.c:2376-2384)
             altmov(B);
-            for (int i = 0; i < 3; i++) B.d[i] = B.xnew[i] - B.xopt[i];
+            for (int i = 0; i < 3; i++) BQA(d, i) = BQA(xnew, i) - BQA(xopt, i);
             label = L230;
             break;
         }
@@ -744,19 +802,19 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
                 }
                 w[k - 1] = suma * (0.5 * suma + sumb);
                 BQ_V(vlag, k) = sum;
-                B.wsuma[k - 1] = suma;
+                BQA(wsuma, k - 1) = suma;
             }
-            B.beta = 0.0;
+            BQS(beta) = 0.0;
             for (int jj = 1; jj <= 3; jj++) {
                 double sum = 0.0;
                 for (int k = 1; k <= 7; k++) sum += BQ_ZMAT(k, jj) * w[k - 1];
-                B.beta -= sum * sum;
+                BQS(beta) -= sum * sum;
                 for (int k = 1; k <= 7; k++) BQ_V(vlag, k) += sum * BQ_ZMAT(k, jj);
             }
-            B.dsq = 0.0;
+            BQS(dsq) = 0.0;
             double bsum = 0.0, dx = 0.0;
             for (int j = 1; j <= 3; j++) {
-                B.dsq += BQ_V(d, j) * BQ_V(d, j);
+                BQS(dsq) += BQ_V(d, j) * BQ_V(d, j);
                 double sum = 0.0;
                 for (int k = 1; k <= 7; k++) sum += w[k - 1] * BQ_BMAT(k, j);
                 bsum += sum * BQ_V(d, j);
@@ -766,27 +824,27 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
                 bsum += sum * BQ_V(d, j);
                 dx += BQ_V(d, j) * BQ_V(xopt, j);
             }
-            B.beta = dx * dx + B.dsq * (B.xoptsq + dx + dx + 0.5 * B.dsq) + B.beta - bsum;
-            BQ_V(vlag, B.kopt) += 1.0;
-            if (B.ntrits == 0) {
-                const double vk = BQ_V(vlag, B.knew);
-                B.denom = vk * vk + B.alpha * B.beta;
-                if (B.denom < B.cauchy && B.cauchy > 0.0) {
-                    for (int i = 0; i < 3; i++) { B.xnew[i] = B.xalt[i]; B.d[i] = B.xnew[i] - B.xopt[i]; }
-                    B.cauchy = 0.0;
+            BQS(beta) = dx * dx + BQS(dsq) * (BQS(xoptsq) + dx + dx + 0.5 * BQS(dsq)) + BQS(beta) - bsum;
+            BQ_V(vlag, BQN(kopt)) += 1.0;
+            if (BQN(ntrits) == 0) {
+                const double vk = BQ_V(vlag, BQN(knew));
+                BQS(denom) = vk * vk + BQS(alpha) * BQS(beta);
+                if (BQS(denom) < BQS(cauchy) && BQS(cauchy) > 0.0) {
+                    for (int i = 0; i < 3; i++) { BQA(xnew, i) = BQA(xalt, i); BQA(d, i) = BQA(xnew, i) - BQA(xopt, i); }
+                    BQS(cauchy) = 0.0;
                     label = L230;
                     break;
                 }
-                if (B.denom <= 0.5 * (vk * vk)) {
-                    B.rc = (B.nevals > B.nresc) ? BQ_NEED_RESCUE : BQ_ROUNDOFF_LIMITED;
+                if (BQS(denom) <= 0.5 * (vk * vk)) {
+                    BQN(rc) = (BQN(nevals) > BQN(nresc)) ? BQ_NEED_RESCUE : BQ_ROUNDOFF_LIMITED;
                     label = L720;
                     break;
                 }
             } else {
                 double scaden, biglsq;
-                pick_knew(B, B.xopt, true, scaden, biglsq);
+                pick_knew(B, O_xopt, true, scaden, biglsq);
                 if (scaden <= 0.5 * biglsq) {
-                    B.rc = (B.nevals > B.nresc) ? BQ_NEED_RESCUE : BQ_ROUNDOFF_LIMITED;
+                    BQN(rc) = (BQN(nevals) > BQN(nresc)) ? BQ_NEED_RESCUE : BQ_ROUNDOFF_LIMITED;
                     label = L720;
                     break;
                 }
@@ -795,54 +853,54 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
             break;
         }
         case L360: {  // next objective evaluation (bobyqa.c:2560-2583)
-            if (B.maxeval > 0 && B.nevals >= B.maxeval) { B.rc = BQ_MAXEVAL_REACHED; label = L720; break; }
-            set_x_from(B, B.xnew);
-            B.nevals++;
-            B.phase = PH_MAIN;
+            if (BQN(maxeval) > 0 && BQN(nevals) >= BQN(maxeval)) { BQN(rc) = BQ_MAXEVAL_REACHED; label = L720; break; }
+            set_x_from(B, O_xnew);
+            BQN(nevals)++;
+            BQN(phase) = PH_MAIN;
             return BQ_CONTINUE;
         }
         case L650: {  // is some interpolation point too far from xopt? (bobyqa.c:2972-3013)
-            B.knew = 0;
+            BQN(knew) = 0;
             for (int k = 1; k <= 7; k++) {
                 double sum = 0.0;
                 for (int j = 1; j <= 3; j++) {
                     const double t = BQ_XPT(k, j) - BQ_V(xopt, j);
                     sum += t * t;
                 }
-                if (sum > B.distsq) { B.knew = k; B.distsq = sum; }
+                if (sum > BQS(distsq)) { BQN(knew) = k; BQS(distsq) = sum; }
             }
-            if (B.knew > 0) {
-                const double dist = sqrt(B.distsq);
-                if (B.ntrits == -1) {
-                    B.delta = mn(0.1 * B.delta, 0.5 * dist);
-                    if (B.delta <= B.rho * 1.5) B.delta = B.rho;
+            if (BQN(knew) > 0) {
+                const double dist = sqrt(BQS(distsq));
+                if (BQN(ntrits) == -1) {
+                    BQS(delta) = mn(0.1 * BQS(delta), 0.5 * dist);
+                    if (BQS(delta) <= BQS(rho) * 1.5) BQS(delta) = BQS(rho);
                 }
-                B.ntrits = 0;
-                B.adelt = mx(mn(0.1 * dist, B.delta), B.rho);
-                B.dsq = B.adelt * B.adelt;
+                BQN(ntrits) = 0;
+                BQS(adelt) = mx(mn(0.1 * dist, BQS(delta)), BQS(rho));
+                BQS(dsq) = BQS(adelt) * BQS(adelt);
                 label = L90;
                 break;
             }
-            if (B.ntrits == -1) { label = L680; break; }
-            if (B.ratio > 0.0) { label = L60; break; }
-            if (mx(B.delta, B.dnorm) > B.rho) { label = L60; break; }
+            if (BQN(ntrits) == -1) { label = L680; break; }
+            if (BQS(ratio) > 0.0) { label = L60; break; }
+            if (mx(BQS(delta), BQS(dnorm)) > BQS(rho)) { label = L60; break; }
             label = L680;
             break;
         }
         case L680: {  // reduce rho, or finish (bobyqa.c:3019-3041)
-            if (B.rho > B.rhoend) {
-                B.delta = 0.5 * B.rho;
-                B.ratio = B.rho / B.rhoend;
-                if (B.ratio <= 16.) B.rho = B.rhoend;
-                else if (B.ratio <= 250.) B.rho = sqrt(B.ratio) * B.rhoend;
-                else B.rho = 0.1 * B.rho;
-                B.delta = mx(B.delta, B.rho);
-                B.ntrits = 0;
-                B.nfsav = B.nevals;
+            if (BQS(rho) > BQS(rhoend)) {
+                BQS(delta) = 0.5 * BQS(rho);
+                BQS(ratio) = BQS(rho) / BQS(rhoend);
+                if (BQS(ratio) <= 16.) BQS(rho) = BQS(rhoend);
+                else if (BQS(ratio) <= 250.) BQS(rho) = sqrt(BQS(ratio)) * BQS(rhoend);
+                else BQS(rho) = 0.1 * BQS(rho);
+                BQS(delta) = mx(BQS(delta), BQS(rho));
+                BQN(ntrits) = 0;
+                BQN(nfsav) = BQN(nevals);
                 label = L60;
                 break;
             }
-            if (B.ntrits == -1) { label = L360; break; }
+            if (BQN(ntrits) == -1) { label = L360; break; }
             label = L720;
             break;
         }
@@ -854,9 +912,9 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
                 if (BQ_V(xopt, i) == BQ_V(su, i)) v = BQ_V(xu, i);
                 BQ_V(x, i) = v;
             }
-            B.minf = BQ_FVAL(B.kopt);
-            for (int i = 0; i < 3; i++) B.xfinal[i] = B.x[i] * B.sc[i];
-            B.phase = PH_DONE;
+            BQS(minf) = BQ_FVAL(BQN(kopt));
+            for (int i = 0; i < 3; i++) BQA(xfinal, i) = BQA(x, i) * BQA(sc, i);
+            BQN(phase) = PH_DONE;
             return BQ_DONE;
         }
         }
@@ -866,18 +924,18 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
 // Code after an evaluation at xbase + xnew in the main loop (bobyqa.c:2583-2970)
 BQ_HD_NOINLINE int after_eval(Bobyqa3& B, double f) {
     double w[10];
-    if (B.ntrits == -1) {
-        B.fsave = f;
-        B.rc = BQ_XTOL_REACHED;
-        if (B.fsave < BQ_FVAL(B.kopt)) {
-            B.minf = f;
-            for (int i = 0; i < 3; i++) B.xfinal[i] = B.x[i] * B.sc[i];
-            B.phase = PH_DONE;
+    if (BQN(ntrits) == -1) {
+        BQS(fsave) = f;
+        BQN(rc) = BQ_XTOL_REACHED;
+        if (BQS(fsave) < BQ_FVAL(BQN(kopt))) {
+            BQS(minf) = f;
+            for (int i = 0; i < 3; i++) BQA(xfinal, i) = BQA(x, i) * BQA(sc, i);
+            BQN(phase) = PH_DONE;
             return BQ_DONE;
         }
         return run(B, L720);
     }
-    const double fopt = BQ_FVAL(B.kopt);
+    const double fopt = BQ_FVAL(BQN(kopt));
     double vquad = 0.0;
     int ih = 0;
     for (int j = 1; j <= 3; j++) {
@@ -889,30 +947,30 @@ BQ_HD_NOINLINE int after_eval(Bobyqa3& B, double f) {
             vquad += BQ_HQ(ih) * temp;
         }
     }
-    for (int k = 1; k <= 7; k++) vquad += 0.5 * BQ_PQ(k) * (B.wsuma[k - 1] * B.wsuma[k - 1]);
+    for (int k = 1; k <= 7; k++) vquad += 0.5 * BQ_PQ(k) * (BQA(wsuma, k - 1) * BQA(wsuma, k - 1));
     const double diff = f - fopt - vquad;
-    B.diffc = B.diffb;
-    B.diffb = B.diffa;
-    B.diffa = fabs(diff);
-    if (B.dnorm > B.rho) B.nfsav = B.nevals;
+    BQS(diffc) = BQS(diffb);
+    BQS(diffb) = BQS(diffa);
+    BQS(diffa) = fabs(diff);
+    if (BQS(dnorm) > BQS(rho)) BQN(nfsav) = BQN(nevals);
 
-    if (B.ntrits > 0) {
-        if (vquad >= 0.0) { B.rc = BQ_ROUNDOFF_LIMITED; return run(B, L720); }
-        B.ratio = (f - fopt) / vquad;
-        if (B.ratio <= 0.1) B.delta = mn(0.5 * B.delta, B.dnorm);
-        else if (B.ratio <= .7) B.delta = mx(0.5 * B.delta, B.dnorm);
-        else B.delta = mx(0.5 * B.delta, B.dnorm + B.dnorm);
-        if (B.delta <= B.rho * 1.5) B.delta = B.rho;
+    if (BQN(ntrits) > 0) {
+        if (vquad >= 0.0) { BQN(rc) = BQ_ROUNDOFF_LIMITED; return run(B, L720); }
+        BQS(ratio) = (f - fopt) / vquad;
+        if (BQS(ratio) <= 0.1) BQS(delta) = mn(0.5 * BQS(delta), BQS(dnorm));
+        else if (BQS(ratio) <= .7) BQS(delta) = mx(0.5 * BQS(delta), BQS(dnorm));
+        else BQS(delta) = mx(0.5 * BQS(delta), BQS(dnorm) + BQS(dnorm));
+        if (BQS(delta) <= BQS(rho) * 1.5) BQS(delta) = BQS(rho);
         if (f < fopt) {
-            const int ksav = B.knew;
-            const double densav = B.denom;
+            const int ksav = BQN(knew);
+            const double densav = BQS(denom);
             double scaden, biglsq;
-            pick_knew(B, B.xnew, false, scaden, biglsq);
-            if (scaden <= 0.5 * biglsq) { B.knew = ksav; B.denom = densav; }
+            pick_knew(B, O_xnew, false, scaden, biglsq);
+            if (scaden <= 0.5 * biglsq) { BQN(knew) = ksav; BQS(denom) = densav; }
         }
     }
     update(B);
-    const int knew = B.knew;
+    const int knew = BQN(knew);
     ih = 0;
     const double pqold = BQ_PQ(knew);
     BQ_PQ(knew) = 0.0;
@@ -929,7 +987,7 @@ BQ_HD_NOINLINE int after_eval(Bobyqa3& B, double f) {
     for (int k = 1; k <= 7; k++) {
         double suma = 0.0;
         for (int jj = 1; jj <= 3; jj++) suma += BQ_ZMAT(knew, jj) * BQ_ZMAT(k, jj);
-        if (is_inf(suma)) { B.rc = BQ_ROUNDOFF_LIMITED; return run(B, L720); }
+        if (is_inf(suma)) { BQN(rc) = BQ_ROUNDOFF_LIMITED; return run(B, L720); }
         double sumb = 0.0;
         for (int j = 1; j <= 3; j++) sumb += BQ_XPT(k, j) * BQ_V(xopt, j);
         const double temp = suma * sumb;
@@ -938,12 +996,12 @@ BQ_HD_NOINLINE int after_eval(Bobyqa3& B, double f) {
     for (int i = 1; i <= 3; i++) BQ_V(gopt, i) += diff * w[i - 1];
 
     if (f < fopt) {
-        B.kopt = knew;
-        B.xoptsq = 0.0;
+        BQN(kopt) = knew;
+        BQS(xoptsq) = 0.0;
         ih = 0;
         for (int j = 1; j <= 3; j++) {
             BQ_V(xopt, j) = BQ_V(xnew, j);
-            B.xoptsq += BQ_V(xopt, j) * BQ_V(xopt, j);
+            BQS(xoptsq) += BQ_V(xopt, j) * BQ_V(xopt, j);
             for (int i = 1; i <= j; i++) {
                 ++ih;
                 if (i < j) BQ_V(gopt, j) += BQ_HQ(ih) * BQ_V(d, i);
@@ -959,9 +1017,9 @@ BQ_HD_NOINLINE int after_eval(Bobyqa3& B, double f) {
         // nlopt_stop_ftol with ftol_rel = ftol_abs = 0 (PatchOptimizer.cpp sets only xtol_rel) never fires
     }
 
-    if (B.ntrits > 0) {  // least-Frobenius-norm interpolant test (bobyqa.c:2845-2944)
+    if (BQN(ntrits) > 0) {  // least-Frobenius-norm interpolant test (bobyqa.c:2845-2944)
         double vl[10], wk[14];
-        for (int k = 1; k <= 7; k++) { vl[k - 1] = BQ_FVAL(k) - BQ_FVAL(B.kopt); wk[k - 1] = 0.0; }
+        for (int k = 1; k <= 7; k++) { vl[k - 1] = BQ_FVAL(k) - BQ_FVAL(BQN(kopt)); wk[k - 1] = 0.0; }
         for (int j = 1; j <= 3; j++) {
             double sum = 0.0;
             for (int k = 1; k <= 7; k++) sum += BQ_ZMAT(k, j) * vl[k - 1];
@@ -993,21 +1051,21 @@ BQ_HD_NOINLINE int after_eval(Bobyqa3& B, double f) {
             }
             vl[7 + i - 1] = sum;
         }
-        ++B.itest;
-        if (gqsq < 10.0 * gisq) B.itest = 0;
-        if (B.itest >= 3) {
+        ++BQN(itest);
+        if (gqsq < 10.0 * gisq) BQN(itest) = 0;
+        if (BQN(itest) >= 3) {
             for (int i = 1; i <= 7; i++) {  // max(npt, nh) = 7
                 if (i <= 3) BQ_V(gopt, i) = vl[7 + i - 1];
                 if (i <= 7) BQ_PQ(i) = wk[7 + i - 1];
                 if (i <= 6) BQ_HQ(i) = 0.0;
-                B.itest = 0;
+                BQN(itest) = 0;
             }
         }
     }
-    if (B.ntrits == 0) return run(B, L60);
+    if (BQN(ntrits) == 0) return run(B, L60);
     if (f <= fopt + 0.1 * vquad) return run(B, L60);
-    const double a = 2.0 * B.delta, b = 10.0 * B.rho;
-    B.distsq = mx(a * a, b * b);
+    const double a = 2.0 * BQS(delta), b = 10.0 * BQS(rho);
+    BQS(distsq) = mx(a * a, b * b);
     return run(B, L650);
 }
 
@@ -1032,82 +1090,82 @@ BQ_HD void bq_default_step(const double* x, const double* lb, const double* ub, 
 }
 
 // bobyqa() front end (bobyqa.c:3073-3268) + the start of prelim_.  Returns BQ_CONTINUE with the
-// first point in B.xeval, or BQ_DONE with B.rc = BQ_INVALID_ARGS.
+// first point in B.xeval, or BQ_DONE with BQN(rc) = BQ_INVALID_ARGS.
 BQ_HD_NOINLINE int bq_start(Bobyqa3& B, const double* x0, const double* lb, const double* ub, const double* dx,
                    double xtol_rel, int maxeval) {
-    B.nevals = 0; B.rc = BQ_SUCCESS; B.minf = HUGE_VAL; B.maxeval = maxeval; B.phase = bq::PH_PRELIM;
-    for (int i = 0; i < 3; i++) { B.xfinal[i] = x0[i]; B.xeval[i] = x0[i]; }
+    BQN(nevals) = 0; BQN(rc) = BQ_SUCCESS; BQS(minf) = HUGE_VAL; BQN(maxeval) = maxeval; BQN(phase) = bq::PH_PRELIM;
+    for (int i = 0; i < 3; i++) { BQA(xfinal, i) = x0[i]; BQA(xeval, i) = x0[i]; }
     for (int i = 0; i < 3; i++)
-        if (lb[i] > ub[i] || x0[i] < lb[i] || x0[i] > ub[i]) { B.rc = BQ_INVALID_ARGS; B.phase = bq::PH_DONE; return BQ_DONE; }
+        if (lb[i] > ub[i] || x0[i] < lb[i] || x0[i] > ub[i]) { BQN(rc) = BQ_INVALID_ARGS; BQN(phase) = bq::PH_DONE; return BQ_DONE; }
     // nlopt_compute_rescaling (util/rescale.c:29-44)
-    for (int i = 0; i < 3; i++) B.sc[i] = 1.0;
+    for (int i = 0; i < 3; i++) BQA(sc, i) = 1.0;
     if (!(dx[1] == dx[0] && dx[2] == dx[1]))
-        for (int i = 1; i < 3; i++) B.sc[i] = dx[i] / dx[0];
+        for (int i = 1; i < 3; i++) BQA(sc, i) = dx[i] / dx[0];
     for (int i = 0; i < 3; i++) {
-        B.x[i] = x0[i] / B.sc[i];
-        B.xl[i] = lb[i] / B.sc[i];
-        B.xu[i] = ub[i] / B.sc[i];
-        if (B.xl[i] > B.xu[i]) { const double t = B.xl[i]; B.xl[i] = B.xu[i]; B.xu[i] = t; }
+        BQA(x, i) = x0[i] / BQA(sc, i);
+        BQA(xl, i) = lb[i] / BQA(sc, i);
+        BQA(xu, i) = ub[i] / BQA(sc, i);
+        if (BQA(xl, i) > BQA(xu, i)) { const double t = BQA(xl, i); BQA(xl, i) = BQA(xu, i); BQA(xu, i) = t; }
     }
-    B.rhobeg = fabs(dx[0] / B.sc[0]);
-    B.rhoend = xtol_rel * B.rhobeg;  // xtol_abs = 0
+    BQS(rhobeg) = fabs(dx[0] / BQA(sc, 0));
+    BQS(rhoend) = xtol_rel * BQS(rhobeg);  // xtol_abs = 0
     for (int j = 0; j < 3; j++) {
-        const double temp = B.xu[j] - B.xl[j];
-        if (temp < B.rhobeg + B.rhobeg) { B.rc = BQ_INVALID_ARGS; B.phase = bq::PH_DONE; return BQ_DONE; }
-        B.sl[j] = B.xl[j] - B.x[j];
-        B.su[j] = B.xu[j] - B.x[j];
-        if (B.sl[j] >= -B.rhobeg) {
-            if (B.sl[j] >= 0.0) { B.x[j] = B.xl[j]; B.sl[j] = 0.0; B.su[j] = temp; }
-            else { B.x[j] = B.xl[j] + B.rhobeg; B.sl[j] = -B.rhobeg; B.su[j] = bq::mx(B.xu[j] - B.x[j], B.rhobeg); }
-        } else if (B.su[j] <= B.rhobeg) {
-            if (B.su[j] <= 0.0) { B.x[j] = B.xu[j]; B.sl[j] = -temp; B.su[j] = 0.0; }
-            else { B.x[j] = B.xu[j] - B.rhobeg; B.sl[j] = bq::mn(B.xl[j] - B.x[j], -B.rhobeg); B.su[j] = B.rhobeg; }
+        const double temp = BQA(xu, j) - BQA(xl, j);
+        if (temp < BQS(rhobeg) + BQS(rhobeg)) { BQN(rc) = BQ_INVALID_ARGS; BQN(phase) = bq::PH_DONE; return BQ_DONE; }
+        BQA(sl, j) = BQA(xl, j) - BQA(x, j);
+        BQA(su, j) = BQA(xu, j) - BQA(x, j);
+        if (BQA(sl, j) >= -BQS(rhobeg)) {
+            if (BQA(sl, j) >= 0.0) { BQA(x, j) = BQA(xl, j); BQA(sl, j) = 0.0; BQA(su, j) = temp; }
+            else { BQA(x, j) = BQA(xl, j) + BQS(rhobeg); BQA(sl, j) = -BQS(rhobeg); BQA(su, j) = bq::mx(BQA(xu, j) - BQA(x, j), BQS(rhobeg)); }
+        } else if (BQA(su, j) <= BQS(rhobeg)) {
+            if (BQA(su, j) <= 0.0) { BQA(x, j) = BQA(xu, j); BQA(sl, j) = -temp; BQA(su, j) = 0.0; }
+            else { BQA(x, j) = BQA(xu, j) - BQS(rhobeg); BQA(sl, j) = bq::mn(BQA(xl, j) - BQA(x, j), -BQS(rhobeg)); BQA(su, j) = BQS(rhobeg); }
         }
     }
     // prelim_ initialisation (bobyqa.c:1790-1822)
-    for (int j = 0; j < 3; j++) { B.xbase[j] = B.x[j]; B.xopt[j] = 0; B.gopt[j] = 0; B.xnew[j] = 0; B.xalt[j] = 0; B.d[j] = 0; B.gnew[j] = 0; }
-    for (int k = 0; k < 21; k++) { B.xpt[k] = 0.0; B.zmat[k] = 0.0; }
-    for (int k = 0; k < 30; k++) B.bmat[k] = 0.0;
-    for (int k = 0; k < 6; k++) B.hq[k] = 0.0;
-    for (int k = 0; k < 7; k++) { B.pq[k] = 0.0; B.fval[k] = 0.0; B.wsuma[k] = 0.0; }
-    for (int k = 0; k < 10; k++) B.vlag[k] = 0.0;
-    B.rho = B.delta = B.diffa = B.diffb = B.diffc = B.dsq = B.crvmin = B.dnorm = B.xoptsq = B.ratio = B.adelt = 0.0;
-    B.alpha = B.cauchy = B.beta = B.denom = B.fsave = B.distsq = B.fbeg = B.stepa = B.stepb = 0.0;
-    B.kopt = 1; B.knew = 0; B.kbase = 1; B.ntrits = 0; B.itest = 0; B.nresc = 0; B.nfsav = 0; B.nf = 0;
+    for (int j = 0; j < 3; j++) { BQA(xbase, j) = BQA(x, j); BQA(xopt, j) = 0; BQA(gopt, j) = 0; BQA(xnew, j) = 0; BQA(xalt, j) = 0; BQA(d, j) = 0; BQA(gnew, j) = 0; }
+    for (int k = 0; k < 21; k++) { BQA(xpt, k) = 0.0; BQA(zmat, k) = 0.0; }
+    for (int k = 0; k < 30; k++) BQA(bmat, k) = 0.0;
+    for (int k = 0; k < 6; k++) BQA(hq, k) = 0.0;
+    for (int k = 0; k < 7; k++) { BQA(pq, k) = 0.0; BQA(fval, k) = 0.0; BQA(wsuma, k) = 0.0; }
+    for (int k = 0; k < 10; k++) BQA(vlag, k) = 0.0;
+    BQS(rho) = BQS(delta) = BQS(diffa) = BQS(diffb) = BQS(diffc) = BQS(dsq) = BQS(crvmin) = BQS(dnorm) = BQS(xoptsq) = BQS(ratio) = BQS(adelt) = 0.0;
+    BQS(alpha) = BQS(cauchy) = BQS(beta) = BQS(denom) = BQS(fsave) = BQS(distsq) = BQS(fbeg) = BQS(stepa) = BQS(stepb) = 0.0;
+    BQN(kopt) = 1; BQN(knew) = 0; BQN(kbase) = 1; BQN(ntrits) = 0; BQN(itest) = 0; BQN(nresc) = 0; BQN(nfsav) = 0; BQN(nf) = 0;
     bq::prelim_next_point(B);
-    B.nevals++;
+    BQN(nevals)++;
     return BQ_CONTINUE;
 }
 
 BQ_HD_NOINLINE int bq_step(Bobyqa3& B, double f) {
-    if (B.phase == bq::PH_PRELIM) {
+    if (BQN(phase) == bq::PH_PRELIM) {
         bq::prelim_consume(B, f);
         // stopping tests after each prelim evaluation (bobyqa.c:1944-1947)
-        const bool maxed = (B.maxeval > 0 && B.nevals >= B.maxeval);
-        if (!maxed && B.nf < 7) {
+        const bool maxed = (BQN(maxeval) > 0 && BQN(nevals) >= BQN(maxeval));
+        if (!maxed && BQN(nf) < 7) {
             bq::prelim_next_point(B);
-            B.nevals++;
+            BQN(nevals)++;
             return BQ_CONTINUE;
         }
         // bobyqb_ set-up after prelim_ (bobyqa.c:2117-2143)
-        B.xoptsq = 0.0;
+        BQS(xoptsq) = 0.0;
         for (int i = 1; i <= 3; i++) {
-            BQ_V(xopt, i) = BQ_XPT(B.kopt, i);
-            B.xoptsq += BQ_V(xopt, i) * BQ_V(xopt, i);
+            BQ_V(xopt, i) = BQ_XPT(BQN(kopt), i);
+            BQS(xoptsq) += BQ_V(xopt, i) * BQ_V(xopt, i);
         }
-        B.fsave = BQ_FVAL(1);
-        if (maxed) { B.rc = BQ_MAXEVAL_REACHED; return bq::run(B, bq::L720); }
-        B.kbase = 1;
-        B.rho = B.rhobeg;
-        B.delta = B.rho;
-        B.nresc = B.nevals;
-        B.ntrits = 0;
-        B.diffa = 0.0; B.diffb = 0.0; B.diffc = 0.0;
-        B.itest = 0;
-        B.nfsav = B.nevals;
+        BQS(fsave) = BQ_FVAL(1);
+        if (maxed) { BQN(rc) = BQ_MAXEVAL_REACHED; return bq::run(B, bq::L720); }
+        BQN(kbase) = 1;
+        BQS(rho) = BQS(rhobeg);
+        BQS(delta) = BQS(rho);
+        BQN(nresc) = BQN(nevals);
+        BQN(ntrits) = 0;
+        BQS(diffa) = 0.0; BQS(diffb) = 0.0; BQS(diffc) = 0.0;
+        BQN(itest) = 0;
+        BQN(nfsav) = BQN(nevals);
         return bq::run(B, bq::L20);
     }
-    if (B.phase == bq::PH_MAIN) return bq::after_eval(B, f);
+    if (BQN(phase) == bq::PH_MAIN) return bq::after_eval(B, f);
     return BQ_DONE;
 }
 

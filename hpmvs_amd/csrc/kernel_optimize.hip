@@ -3,7 +3,7 @@
 // Mapping (MI355X-first, not a translation of the reference's one-thread-per-patch OpenMP loop):
 //
 //   * A persistent grid of single-wave workgroups pulls patches from a global work queue.
-//   * Each of the 64 LANES of a wave owns one patch ("slot") and runs that patch's control
+//   * Lanes 0..kP-1 of a wave each own one patch ("slot") and run that patch's control
 //     logic as plain SIMT code: the optimize() pipeline of the reference
 //     (src/hpmvs/PatchOptimizer.cpp:48-103: addImages / filterImagesNCC / sortImages /
 //     assureImageAngles / optimizePatch / ... / setRefImage) and the BOBYQA state machine
@@ -19,10 +19,16 @@
 //   8-byte taps.  Patches finish at different times (40-1000 evaluations); a finished lane
 //   immediately pulls the next patch from the queue, so lanes stay busy until the queue drains.
 //
-//   Per-lane optimiser state lives in private memory (the compiler's scratch, lane-interleaved
-//   and therefore coalesced); per-lane image lists live in LDS (uint16 ids, padded rows).
+//   The per-patch optimiser state (177 float64 + 12 int32) and image lists (uint16 ids, padded
+//   rows) live in LDS as [index][slot], so the kP lanes touch consecutive words and none of it goes
+//   through scratch / HBM.  (A first version kept the state in per-lane scratch for 64 patches per
+//   wave: PMC showed 2.1 G scratch/flat instructions and 157 GB of HBM traffic per 1e5-patch launch
+//   against 13 GB of algorithmic image bytes -- profiles/r01a_scratch_state.)
 #include <hip/hip_runtime.h>
 
+// optimiser state of the kP patches a wavefront owns lives in LDS (see bobyqa3.hpp)
+#define BQ_STATE_LDS 1
+#define BQ_P 16
 #include "bobyqa3.hpp"
 #include "launch.h"
 #include "photometric.hpp"
@@ -31,6 +37,7 @@ namespace hpmvs {
 
 namespace {
 
+constexpr int kP = BQ_P;  // patches ("slots") per wavefront: lanes 0..kP-1 own one each
 constexpr int kRow = 66;  // uint16 per LDS row: 64 ids + 2 pad -> row stride 33 dwords, conflict-free per lane
 
 enum Op { OP_NONE = 0, OP_OBJ = 1, OP_INCC = 2, OP_REFSUM = 3 };
@@ -224,19 +231,19 @@ __device__ __noinline__ void patch_colour(const DevScene& sc, const uint16_t* ro
 }  // namespace
 
 __global__ void __launch_bounds__(64, 4) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
-    __shared__ uint16_t lists[64 * kRow];
+    __shared__ uint16_t lists[kP * kRow];
     const int lane = lane_id();
     uint16_t* row = &lists[lane * kRow];
 
     // ---- per-lane slot state
-    int stage = S_FETCH;
+    int stage = (lane < kP) ? S_FETCH : S_IDLE;  // lanes >= kP only help in phase B
     int idx = -1, nimg = 0, ii = 0, refindex = -1, ngrabs = 0, fail_stage = 0, nl_result = 0;
     float c0[3] = {0, 0, 0}, n0[3] = {0, 0, 0};  // optimize() input (kept for "patch untouched")
     float c[3] = {0, 0, 0}, n[3] = {0, 0, 1};    // pCenter_, pNormal_
     float scale = 1.0f, refbest = 0.0f;
     OptFields F;
     Bobyqa3 B;
-    B.nevals = 0; B.minf = 0.0; B.rc = 0; B.xfinal[0] = B.xfinal[1] = B.xfinal[2] = 0.0;
+    B.slot = lane < kP ? lane : 0;
     // request posted to phase B
     int op = OP_NONE, req_ref = 0, req_robust = 0;
     float req_thr = 0.0f;
@@ -258,8 +265,8 @@ __global__ void __launch_bounds__(64, 4) optimize_kernel(DevScene sc, DevOptions
                 for (int k = 0; k < 3; k++) { c0[k] = b.center[4 * idx + k]; n0[k] = b.normal[4 * idx + k]; c[k] = c0[k]; n[k] = n0[k]; }
                 scale = b.scale[idx];
                 nimg = b.n_images[idx];
-                ngrabs = 0; nl_result = 0; B.nevals = 0; B.minf = 0.0;
-                B.xfinal[0] = B.xfinal[1] = B.xfinal[2] = 0.0;
+                ngrabs = 0; nl_result = 0; BQN(nevals) = 0; BQS(minf) = 0.0;
+                BQA(xfinal, 0) = 0.0; BQA(xfinal, 1) = 0.0; BQA(xfinal, 2) = 0.0;
                 if (nimg > kMaxImages || nimg > b.max_images) { fail_stage = 100; finish_fail = true; break; }
                 for (int k = 0; k < nimg; k++) row[k] = (uint16_t)b.images[(size_t)idx * b.max_images + k];
                 nimg = add_images(sc, o, row, nimg, c, n, scale);
@@ -280,23 +287,24 @@ __global__ void __launch_bounds__(64, 4) optimize_kernel(DevScene sc, DevOptions
                 parameters_from_center_norm(F, o, n, lbv, ubv, x0);
                 bq_default_step(x0, lbv, ubv, dx);
                 if (bq_start(B, x0, lbv, ubv, dx, 1.e-7, 1000) != BQ_CONTINUE) {
-                    nl_result = B.rc; fail_stage = 4; finish_fail = true; break;
+                    nl_result = BQN(rc); fail_stage = 4; finish_fail = true; break;
                 }
-                set_center_norm(F, o, B.xeval, c, n);
+                { const double xe[3] = {BQA(xeval, 0), BQA(xeval, 1), BQA(xeval, 2)}; set_center_norm(F, o, xe, c, n); }
                 op = OP_OBJ;
                 stage = S_BQ;
                 break;
             }
             case S_BQ: {  // objective value arrived: advance BOBYQA
                 if (bq_step(B, res_f) == BQ_CONTINUE) {
-                    set_center_norm(F, o, B.xeval, c, n);
+                    const double xe[3] = {BQA(xeval, 0), BQA(xeval, 1), BQA(xeval, 2)};
+                    set_center_norm(F, o, xe, c, n);
                     op = OP_OBJ;
                     break;
                 }
-                nl_result = B.rc;
+                nl_result = BQN(rc);
                 // SUCCESS / STOPVAL / FTOL / XTOL only (PatchOptimizer.cpp:367-368); negative codes throw
-                if (!(B.rc >= 1 && B.rc <= 4)) { fail_stage = 4; finish_fail = true; break; }
-                set_center_norm(F, o, B.xfinal, c, n);
+                if (!(nl_result >= 1 && nl_result <= 4)) { fail_stage = 4; finish_fail = true; break; }
+                { const double xf[3] = {BQA(xfinal, 0), BQA(xfinal, 1), BQA(xfinal, 2)}; set_center_norm(F, o, xf, c, n); }
                 nimg = add_images(sc, o, row, nimg, c, n, scale);
                 if (nimg < 0) { fail_stage = 100; finish_fail = true; break; }
                 if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 5; finish_fail = true; break; }
@@ -353,10 +361,10 @@ __global__ void __launch_bounds__(64, 4) optimize_kernel(DevScene sc, DevOptions
                     if (b.ncc) b.ncc[idx] = 1.4f;  // PatchOptimizer.cpp:95
                 }
                 if (b.stage) b.stage[idx] = finish_ok ? 0 : fail_stage;
-                if (b.fmin) b.fmin[idx] = B.minf;
-                if (b.x) for (int k = 0; k < 3; k++) b.x[3 * idx + k] = B.xfinal[k];
+                if (b.fmin) b.fmin[idx] = BQS(minf);
+                if (b.x) for (int k = 0; k < 3; k++) b.x[3 * idx + k] = BQA(xfinal, k);
                 if (b.result) b.result[idx] = nl_result;
-                if (b.nevals) b.nevals[idx] = B.nevals;
+                if (b.nevals) b.nevals[idx] = BQN(nevals);
                 if (b.ngrabs) b.ngrabs[idx] = ngrabs;
                 stage = S_FETCH;
             }
@@ -394,9 +402,10 @@ __global__ void __launch_bounds__(64, 4) optimize_kernel(DevScene sc, DevOptions
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* queue_counter, int n_cus,
                      hipStream_t st) {
     if (b.n <= 0) return;
-    // persistent single-wave workgroups; enough waves to cover the batch once, at most 8 per CU
-    int waves = (b.n + 63) / 64;
-    const int cap = n_cus * 16;  // 4 waves per SIMD at <= 128 VGPRs
+    // persistent single-wave workgroups, kP patches in flight per wave; LDS (~25.5 KB per wave: optimiser
+    // state + image lists) admits 6 waves per CU
+    int waves = (b.n + kP - 1) / kP;
+    const int cap = n_cus * 6;
     if (waves > cap) waves = cap;
     hipLaunchKernelGGL(optimize_kernel, dim3(waves), dim3(64), 0, st, sc, o, b, queue_counter);
 }

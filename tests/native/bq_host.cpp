@@ -15,12 +15,13 @@ extern "C" int bq3_minimize(obj_fn f, void* data, double* x, const double* lb, c
     int st = bq_start(B, x, lb, ub, dx, xtol_rel, maxeval);
     int nt = 0;
     while (st == BQ_CONTINUE) {
-        const double fv = f(3, B.xeval, nullptr, data);
-        if (trace && nt < trace_cap) { std::memcpy(trace + 4 * nt, B.xeval, 24); trace[4 * nt + 3] = fv; nt++; }
+        const double xe[3] = {BQA(xeval, 0), BQA(xeval, 1), BQA(xeval, 2)};
+        const double fv = f(3, xe, nullptr, data);
+        if (trace && nt < trace_cap) { std::memcpy(trace + 4 * nt, xe, 24); trace[4 * nt + 3] = fv; nt++; }
         st = bq_step(B, fv);
     }
-    for (int i = 0; i < 3; i++) x[i] = B.xfinal[i];
-    *minf = B.minf;
-    *nevals = B.nevals;
-    return B.rc;
+    for (int i = 0; i < 3; i++) x[i] = BQA(xfinal, i);
+    *minf = BQS(minf);
+    *nevals = BQN(nevals);
+    return BQN(rc);
 }
