@@ -44,6 +44,16 @@
 #endif
 #include <math.h>
 
+// optional region timers (only in -DHPMVS_PROFILE_PHASES device builds; see tools/phase_profile.py)
+#if defined(HPMVS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+extern __device__ unsigned long long g_bqprof[32];
+#define BQ_PROF_BEGIN(v) const long long v = clock64()
+#define BQ_PROF_END(v, i) do { atomicAdd(&g_bqprof[2 * (i)], (unsigned long long)(clock64() - v)); atomicAdd(&g_bqprof[2 * (i) + 1], 1ull); } while (0)
+#else
+#define BQ_PROF_BEGIN(v) do { } while (0)
+#define BQ_PROF_END(v, i) do { } while (0)
+#endif
+
 namespace hpmvs {
 
 enum { BQ_CONTINUE = 0, BQ_DONE = 1 };
@@ -160,7 +170,7 @@ BQ_HD double mx(double a, double b) { return a >= b ? a : b; }
 BQ_HD bool is_inf(double v) { return fabs(v) >= HUGE_VAL * 0.99; }
 
 enum { PH_PRELIM = 0, PH_MAIN = 1, PH_DONE = 2 };
-enum { L20 = 0, L60, L90, L210, L230, L360, L650, L680, L720 };
+enum { L20 = 0, L60, L90, L210, L230, L360, L650, L680, L720, LRET_CONT, LRET_DONE };
 
 // x (scaled) for the interpolation point / trial step `p` (relative to xbase), bounds respected
 // exactly as bobyqb_ does before each calfun (bobyqa.c:2560-2575, 1871-1883)
@@ -667,9 +677,9 @@ BQ_HD void pick_knew(Bobyqa3& B, int from_off, bool skip_kopt, double& scaden, d
 // ---------------------------------------------------------------- bobyqb_ main loop (bobyqa.c:2143-3055)
 // Runs from `label` until the next objective evaluation is needed (returns BQ_CONTINUE with
 // B.xeval set) or the run ends (BQ_DONE).
-BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
+BQ_HD_NOINLINE int step_label(Bobyqa3& B, int label) {
     double w[14];
-    for (;;) {
+    {
         switch (label) {
         case L20: {  // model gradient at xopt when kopt moved away from kbase (bobyqa.c:2149-2182)
             if (BQN(kopt) != BQN(kbase)) {
@@ -689,19 +699,20 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
                     }
                 }
             }
-            label = L60;
-            break;
+            return L60;
         }
         case L60: {  // trust-region step (bobyqa.c:2190-2240)
+            BQ_PROF_BEGIN(t_);
             trsbox(B);
+            BQ_PROF_END(t_, 0);
             BQS(dnorm) = mn(BQS(delta), sqrt(BQS(dsq)));
             if (BQS(dnorm) < 0.5 * BQS(rho)) {
                 BQN(ntrits) = -1;
                 BQS(distsq) = (10.0 * BQS(rho)) * (10.0 * BQS(rho));
-                if (BQN(nevals) <= BQN(nfsav) + 2) { label = L650; break; }
+                if (BQN(nevals) <= BQN(nfsav) + 2) { return L650; }
                 const double errbig = mx(mx(BQS(diffa), BQS(diffb)), BQS(diffc));
                 const double frhosq = BQS(rho) * .125 * BQS(rho);
-                if (BQS(crvmin) > 0.0 && errbig > frhosq * BQS(crvmin)) { label = L650; break; }
+                if (BQS(crvmin) > 0.0 && errbig > frhosq * BQS(crvmin)) { return L650; }
                 const double bdtol = errbig / BQS(rho);
                 bool to650 = false;
                 for (int j = 1; j <= 3; j++) {
@@ -715,12 +726,10 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
                         if (bdtest < bdtol) { to650 = true; break; }
                     }
                 }
-                label = to650 ? L650 : L680;
-                break;
+                return to650 ? L650 : L680;
             }
             ++BQN(ntrits);
-            label = L90;
-            break;
+            return L90;
         }
         case L90: {  // shift xbase to xopt when the step is small relative to |xopt| (bobyqa.c:2246-2322)
             if (BQS(dsq) <= BQS(xoptsq) * .001) {
@@ -783,14 +792,14 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
                 }
                 BQS(xoptsq) = 0.0;
             }
-            label = (BQN(ntrits) == 0) ? L210 : L230;
-            break;
+            return (BQN(ntrits) == 0) ? L210 : L230;
         }
         case L210: {  // geometry step (bobyqa.c:2376-2384)
+            BQ_PROF_BEGIN(t_);
             altmov(B);
+            BQ_PROF_END(t_, 1);
             for (int i = 0; i < 3; i++) BQA(d, i) = BQA(xnew, i) - BQA(xopt, i);
-            label = L230;
-            break;
+            return L230;
         }
         case L230: {  // vlag, beta for the step d (bobyqa.c:2390-2440), then knew / denominators
             for (int k = 1; k <= 7; k++) {
@@ -832,32 +841,28 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
                 if (BQS(denom) < BQS(cauchy) && BQS(cauchy) > 0.0) {
                     for (int i = 0; i < 3; i++) { BQA(xnew, i) = BQA(xalt, i); BQA(d, i) = BQA(xnew, i) - BQA(xopt, i); }
                     BQS(cauchy) = 0.0;
-                    label = L230;
-                    break;
+                    return L230;
                 }
                 if (BQS(denom) <= 0.5 * (vk * vk)) {
                     BQN(rc) = (BQN(nevals) > BQN(nresc)) ? BQ_NEED_RESCUE : BQ_ROUNDOFF_LIMITED;
-                    label = L720;
-                    break;
+                    return L720;
                 }
             } else {
                 double scaden, biglsq;
                 pick_knew(B, O_xopt, true, scaden, biglsq);
                 if (scaden <= 0.5 * biglsq) {
                     BQN(rc) = (BQN(nevals) > BQN(nresc)) ? BQ_NEED_RESCUE : BQ_ROUNDOFF_LIMITED;
-                    label = L720;
-                    break;
+                    return L720;
                 }
             }
-            label = L360;
-            break;
+            return L360;
         }
         case L360: {  // next objective evaluation (bobyqa.c:2560-2583)
-            if (BQN(maxeval) > 0 && BQN(nevals) >= BQN(maxeval)) { BQN(rc) = BQ_MAXEVAL_REACHED; label = L720; break; }
+            if (BQN(maxeval) > 0 && BQN(nevals) >= BQN(maxeval)) { BQN(rc) = BQ_MAXEVAL_REACHED; return L720; }
             set_x_from(B, O_xnew);
             BQN(nevals)++;
             BQN(phase) = PH_MAIN;
-            return BQ_CONTINUE;
+            return LRET_CONT;
         }
         case L650: {  // is some interpolation point too far from xopt? (bobyqa.c:2972-3013)
             BQN(knew) = 0;
@@ -878,14 +883,12 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
                 BQN(ntrits) = 0;
                 BQS(adelt) = mx(mn(0.1 * dist, BQS(delta)), BQS(rho));
                 BQS(dsq) = BQS(adelt) * BQS(adelt);
-                label = L90;
-                break;
+                return L90;
             }
-            if (BQN(ntrits) == -1) { label = L680; break; }
-            if (BQS(ratio) > 0.0) { label = L60; break; }
-            if (mx(BQS(delta), BQS(dnorm)) > BQS(rho)) { label = L60; break; }
-            label = L680;
-            break;
+            if (BQN(ntrits) == -1) { return L680; }
+            if (BQS(ratio) > 0.0) { return L60; }
+            if (mx(BQS(delta), BQS(dnorm)) > BQS(rho)) { return L60; }
+            return L680;
         }
         case L680: {  // reduce rho, or finish (bobyqa.c:3019-3041)
             if (BQS(rho) > BQS(rhoend)) {
@@ -897,12 +900,10 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
                 BQS(delta) = mx(BQS(delta), BQS(rho));
                 BQN(ntrits) = 0;
                 BQN(nfsav) = BQN(nevals);
-                label = L60;
-                break;
+                return L60;
             }
-            if (BQN(ntrits) == -1) { label = L360; break; }
-            label = L720;
-            break;
+            if (BQN(ntrits) == -1) { return L360; }
+            return L720;
         }
         case L720:
         default: {  // return the best point (bobyqa.c:3042-3054)
@@ -915,13 +916,44 @@ BQ_HD_NOINLINE int run(Bobyqa3& B, int label) {
             BQS(minf) = BQ_FVAL(BQN(kopt));
             for (int i = 0; i < 3; i++) BQA(xfinal, i) = BQA(x, i) * BQA(sc, i);
             BQN(phase) = PH_DONE;
-            return BQ_DONE;
+            return LRET_DONE;
         }
         }
     }
 }
 
+// Drive the labels until the next evaluation (BQ_CONTINUE) or the end of the run (BQ_DONE).
+// On the GPU the lanes of a wavefront that are inside this function run DIFFERENT patches; a plain
+// per-lane loop lets them drift out of phase, and SIMT execution then repeats the expensive blocks
+// (trsbox, altmov) once per straggler.  The wave-aware scheduler below executes ONE label per
+// iteration for all lanes waiting on it, cheap transition labels first and the expensive ones only
+// when nobody can advance otherwise, so each expensive block runs ~once per round for all lanes.
+BQ_HD int run(Bobyqa3& B, int label) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (;;) {
+        const bool live = (label != LRET_CONT && label != LRET_DONE);
+        if (!__any(live)) break;
+        int pick = LRET_DONE;
+        if (__any(live && label == L20)) pick = L20;
+        else if (__any(live && label == L90)) pick = L90;
+        else if (__any(live && label == L650)) pick = L650;
+        else if (__any(live && label == L680)) pick = L680;
+        else if (__any(live && label == L720)) pick = L720;
+        else if (__any(live && label == L360)) pick = L360;
+        else if (__any(live && label == L60)) pick = L60;
+        else if (__any(live && label == L210)) pick = L210;
+        else if (__any(live && label == L230)) pick = L230;
+        if (live && label == pick) label = step_label(B, label);
+    }
+#else
+    while (label != LRET_CONT && label != LRET_DONE) label = step_label(B, label);
+#endif
+    return label == LRET_CONT ? BQ_CONTINUE : BQ_DONE;
+}
+
+
 // Code after an evaluation at xbase + xnew in the main loop (bobyqa.c:2583-2970)
+// returns the label to continue at (or LRET_DONE)
 BQ_HD_NOINLINE int after_eval(Bobyqa3& B, double f) {
     double w[10];
     if (BQN(ntrits) == -1) {
@@ -931,9 +963,9 @@ BQ_HD_NOINLINE int after_eval(Bobyqa3& B, double f) {
             BQS(minf) = f;
             for (int i = 0; i < 3; i++) BQA(xfinal, i) = BQA(x, i) * BQA(sc, i);
             BQN(phase) = PH_DONE;
-            return BQ_DONE;
+            return LRET_DONE;
         }
-        return run(B, L720);
+        return L720;
     }
     const double fopt = BQ_FVAL(BQN(kopt));
     double vquad = 0.0;
@@ -955,7 +987,7 @@ BQ_HD_NOINLINE int after_eval(Bobyqa3& B, double f) {
     if (BQS(dnorm) > BQS(rho)) BQN(nfsav) = BQN(nevals);
 
     if (BQN(ntrits) > 0) {
-        if (vquad >= 0.0) { BQN(rc) = BQ_ROUNDOFF_LIMITED; return run(B, L720); }
+        if (vquad >= 0.0) { BQN(rc) = BQ_ROUNDOFF_LIMITED; return L720; }
         BQS(ratio) = (f - fopt) / vquad;
         if (BQS(ratio) <= 0.1) BQS(delta) = mn(0.5 * BQS(delta), BQS(dnorm));
         else if (BQS(ratio) <= .7) BQS(delta) = mx(0.5 * BQS(delta), BQS(dnorm));
@@ -969,7 +1001,7 @@ BQ_HD_NOINLINE int after_eval(Bobyqa3& B, double f) {
             if (scaden <= 0.5 * biglsq) { BQN(knew) = ksav; BQS(denom) = densav; }
         }
     }
-    update(B);
+    { BQ_PROF_BEGIN(t_); update(B); BQ_PROF_END(t_, 2); }
     const int knew = BQN(knew);
     ih = 0;
     const double pqold = BQ_PQ(knew);
@@ -987,7 +1019,7 @@ BQ_HD_NOINLINE int after_eval(Bobyqa3& B, double f) {
     for (int k = 1; k <= 7; k++) {
         double suma = 0.0;
         for (int jj = 1; jj <= 3; jj++) suma += BQ_ZMAT(knew, jj) * BQ_ZMAT(k, jj);
-        if (is_inf(suma)) { BQN(rc) = BQ_ROUNDOFF_LIMITED; return run(B, L720); }
+        if (is_inf(suma)) { BQN(rc) = BQ_ROUNDOFF_LIMITED; return L720; }
         double sumb = 0.0;
         for (int j = 1; j <= 3; j++) sumb += BQ_XPT(k, j) * BQ_V(xopt, j);
         const double temp = suma * sumb;
@@ -1062,11 +1094,11 @@ BQ_HD_NOINLINE int after_eval(Bobyqa3& B, double f) {
             }
         }
     }
-    if (BQN(ntrits) == 0) return run(B, L60);
-    if (f <= fopt + 0.1 * vquad) return run(B, L60);
+    if (BQN(ntrits) == 0) return L60;
+    if (f <= fopt + 0.1 * vquad) return L60;
     const double a = 2.0 * BQS(delta), b = 10.0 * BQS(rho);
     BQS(distsq) = mx(a * a, b * b);
-    return run(B, L650);
+    return L650;
 }
 
 }  // namespace bq
@@ -1137,7 +1169,15 @@ BQ_HD_NOINLINE int bq_start(Bobyqa3& B, const double* x0, const double* lb, cons
     return BQ_CONTINUE;
 }
 
-BQ_HD_NOINLINE int bq_step(Bobyqa3& B, double f) {
+BQ_HD_NOINLINE int bq_step_(Bobyqa3& B, double f);
+BQ_HD int bq_step(Bobyqa3& B, double f) {
+    BQ_PROF_BEGIN(t_);
+    const int r = bq_step_(B, f);
+    BQ_PROF_END(t_, 3);
+    return r;
+}
+BQ_HD_NOINLINE int bq_step_(Bobyqa3& B, double f) {
+    int label = bq::LRET_DONE;
     if (BQN(phase) == bq::PH_PRELIM) {
         bq::prelim_consume(B, f);
         // stopping tests after each prelim evaluation (bobyqa.c:1944-1947)
@@ -1145,28 +1185,32 @@ BQ_HD_NOINLINE int bq_step(Bobyqa3& B, double f) {
         if (!maxed && BQN(nf) < 7) {
             bq::prelim_next_point(B);
             BQN(nevals)++;
-            return BQ_CONTINUE;
+            label = bq::LRET_CONT;
+        } else {
+            // bobyqb_ set-up after prelim_ (bobyqa.c:2117-2143)
+            BQS(xoptsq) = 0.0;
+            for (int i = 1; i <= 3; i++) {
+                BQ_V(xopt, i) = BQ_XPT(BQN(kopt), i);
+                BQS(xoptsq) += BQ_V(xopt, i) * BQ_V(xopt, i);
+            }
+            BQS(fsave) = BQ_FVAL(1);
+            if (maxed) { BQN(rc) = BQ_MAXEVAL_REACHED; label = bq::L720; }
+            else {
+                BQN(kbase) = 1;
+                BQS(rho) = BQS(rhobeg);
+                BQS(delta) = BQS(rho);
+                BQN(nresc) = BQN(nevals);
+                BQN(ntrits) = 0;
+                BQS(diffa) = 0.0; BQS(diffb) = 0.0; BQS(diffc) = 0.0;
+                BQN(itest) = 0;
+                BQN(nfsav) = BQN(nevals);
+                label = bq::L20;
+            }
         }
-        // bobyqb_ set-up after prelim_ (bobyqa.c:2117-2143)
-        BQS(xoptsq) = 0.0;
-        for (int i = 1; i <= 3; i++) {
-            BQ_V(xopt, i) = BQ_XPT(BQN(kopt), i);
-            BQS(xoptsq) += BQ_V(xopt, i) * BQ_V(xopt, i);
-        }
-        BQS(fsave) = BQ_FVAL(1);
-        if (maxed) { BQN(rc) = BQ_MAXEVAL_REACHED; return bq::run(B, bq::L720); }
-        BQN(kbase) = 1;
-        BQS(rho) = BQS(rhobeg);
-        BQS(delta) = BQS(rho);
-        BQN(nresc) = BQN(nevals);
-        BQN(ntrits) = 0;
-        BQS(diffa) = 0.0; BQS(diffb) = 0.0; BQS(diffc) = 0.0;
-        BQN(itest) = 0;
-        BQN(nfsav) = BQN(nevals);
-        return bq::run(B, bq::L20);
+    } else if (BQN(phase) == bq::PH_MAIN) {
+        label = bq::after_eval(B, f);
     }
-    if (BQN(phase) == bq::PH_MAIN) return bq::after_eval(B, f);
-    return BQ_DONE;
+    return bq::run(B, label);
 }
 
 }  // namespace hpmvs

@@ -467,6 +467,15 @@ int hpmvs_inccs_batch(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_
     return stage_out(out, dout, n * b->max_images);
 }
 
+// debug: phase counters of the last optimize launch (only meaningful in -DHPMVS_PROFILE_PHASES builds)
+int hpmvs_debug_counters(const hpmvs_scene* s, unsigned long long* out4) {
+    if (!s || !out4) return fail(HPMVS_ERR_ARG, "debug_counters: null argument");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out4, (char*)s->dqueue + 16, 160, hipMemcpyDeviceToHost));
+    return HPMVS_OK;
+}
+
 int hpmvs_last_kernel_ms(const hpmvs_scene* s, float* ms) {
     if (!s || !ms) return fail(HPMVS_ERR_ARG, "last_kernel_ms: null argument");
     if (!s->timed) return fail(HPMVS_ERR_STATE, "last_kernel_ms: no optimize launch yet");

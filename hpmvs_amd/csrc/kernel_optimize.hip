@@ -27,8 +27,13 @@
 #include <hip/hip_runtime.h>
 
 // optimiser state of the kP patches a wavefront owns lives in LDS (see bobyqa3.hpp)
+#ifdef HPMVS_PROFILE_PHASES
+__device__ unsigned long long g_bqprof[32];
+#endif
 #define BQ_STATE_LDS 1
+#ifndef BQ_P
 #define BQ_P 16
+#endif
 #include "bobyqa3.hpp"
 #include "launch.h"
 #include "photometric.hpp"
@@ -230,7 +235,7 @@ __device__ __noinline__ void patch_colour(const DevScene& sc, const uint16_t* ro
 
 }  // namespace
 
-__global__ void __launch_bounds__(64, 4) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
+__global__ void __launch_bounds__(64, 2) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
     __shared__ uint16_t lists[kP * kRow];
     const int lane = lane_id();
     uint16_t* row = &lists[lane * kRow];
@@ -254,6 +259,9 @@ __global__ void __launch_bounds__(64, 4) optimize_kernel(DevScene sc, DevOptions
     const double lbv[3] = {-HUGE_VAL, -23.99999, -23.99999};  // PatchOptimizer.cpp:326-336
     const double ubv[3] = {HUGE_VAL, 23.99999, 23.99999};
 
+#ifdef HPMVS_PROFILE_PHASES
+    long long tA = 0, tB = 0, nrounds = 0, nreq = 0, t0 = clock64();
+#endif
     for (;;) {
         // ================= phase A: every lane advances its own patch until it needs the wave
         while (op == OP_NONE && stage != S_IDLE) {
@@ -372,6 +380,9 @@ __global__ void __launch_bounds__(64, 4) optimize_kernel(DevScene sc, DevOptions
         // ================= phase B: the wave serves the posted requests one patch at a time
         __syncthreads();  // single-wave workgroup: orders the lanes' LDS list updates before cross-lane reads
         unsigned long long pending = __ballot(op != OP_NONE);
+#ifdef HPMVS_PROFILE_PHASES
+        { const long long t1 = clock64(); tA += t1 - t0; t0 = t1; nrounds++; nreq += __popcll(pending); }
+#endif
         if (pending == 0ull) break;  // every lane idle and nothing posted: queue drained
         while (pending) {
             const int p = __ffsll((long long)pending) - 1;
@@ -396,7 +407,20 @@ __global__ void __launch_bounds__(64, 4) optimize_kernel(DevScene sc, DevOptions
             }
         }
         __syncthreads();
+#ifdef HPMVS_PROFILE_PHASES
+        { const long long t1 = clock64(); tB += t1 - t0; t0 = t1; }
+#endif
     }
+#ifdef HPMVS_PROFILE_PHASES
+    if (lane == 0) {
+        unsigned long long* dbg = (unsigned long long*)(queue + 4);
+        atomicAdd(&dbg[0], (unsigned long long)tA);
+        atomicAdd(&dbg[1], (unsigned long long)tB);
+        atomicAdd(&dbg[2], (unsigned long long)nrounds);
+        atomicAdd(&dbg[3], (unsigned long long)nreq);
+        if (blockIdx.x == 0) for (int k = 0; k < 16; k++) dbg[4 + k] = g_bqprof[k];  // (approximate: read while others run)
+    }
+#endif
 }
 
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* queue_counter, int n_cus,
@@ -405,7 +429,11 @@ void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b,
     // persistent single-wave workgroups, kP patches in flight per wave; LDS (~25.5 KB per wave: optimiser
     // state + image lists) admits 6 waves per CU
     int waves = (b.n + kP - 1) / kP;
-    const int cap = n_cus * 6;
+    // waves per CU: LDS (optimiser state + lists) and the 32-waves-per-CU limit
+    const int lds_per_wave = (int)(sizeof(double) * BQ_ND * kP + sizeof(int) * BQ_NI * kP + sizeof(uint16_t) * kP * kRow);
+    int per_cu = (160 * 1024) / lds_per_wave;
+    if (per_cu > 16) per_cu = 16;
+    const int cap = n_cus * per_cu;
     if (waves > cap) waves = cap;
     hipLaunchKernelGGL(optimize_kernel, dim3(waves), dim3(64), 0, st, sc, o, b, queue_counter);
 }

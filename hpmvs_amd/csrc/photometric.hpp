@@ -333,6 +333,37 @@ __device__ __forceinline__ void set_optimization_fields(const DevView& V0, const
     normalized3f(d, F.refRay);
 }
 
+// sin and cos of a float64 angle in [-pi/2 - eps, pi/2 + eps] (the optimiser bounds the angles to
+// +-23.99999 * pi/48), Taylor series in Horner form: truncation < 2e-18, a couple of ulp of rounding.
+// The reference calls the C library's double sin/cos on the float angle (unqualified sin(float) with
+// only <cmath> in scope) and rounds the products to float, which absorbs the last-ulp differences.
+__device__ __forceinline__ void sincos_halfpi(double a, double& s, double& c) {
+    const double z = a * a;
+    double ps = -1.0 / 51090942171709440000.0;                 // -1/21!
+    ps = ps * z + 1.0 / 121645100408832000.0;                  //  1/19!
+    ps = ps * z - 1.0 / 355687428096000.0;                     // -1/17!
+    ps = ps * z + 1.0 / 1307674368000.0;                       //  1/15!
+    ps = ps * z - 1.0 / 6227020800.0;                          // -1/13!
+    ps = ps * z + 1.0 / 39916800.0;                            //  1/11!
+    ps = ps * z - 1.0 / 362880.0;                              // -1/9!
+    ps = ps * z + 1.0 / 5040.0;                                //  1/7!
+    ps = ps * z - 1.0 / 120.0;                                 // -1/5!
+    ps = ps * z + 1.0 / 6.0;                                   //  1/3!  (sign folded below)
+    s = a - a * z * ps;
+    double pc = 1.0 / 1124000727777607680000.0;                //  1/22!
+    pc = pc * z - 1.0 / 2432902008176640000.0;                 // -1/20!
+    pc = pc * z + 1.0 / 6402373705728000.0;                    //  1/18!
+    pc = pc * z - 1.0 / 20922789888000.0;                      // -1/16!
+    pc = pc * z + 1.0 / 87178291200.0;                         //  1/14!
+    pc = pc * z - 1.0 / 479001600.0;                           // -1/12!
+    pc = pc * z + 1.0 / 3628800.0;                             //  1/10!
+    pc = pc * z - 1.0 / 40320.0;                               // -1/8!
+    pc = pc * z + 1.0 / 720.0;                                 //  1/6!
+    pc = pc * z - 1.0 / 24.0;                                  // -1/4!
+    pc = pc * z + 0.5;                                         //  1/2!  (sign folded below)
+    c = 1.0 - z * pc;
+}
+
 // setCenterNorm (PatchOptimizer.cpp:401-414); depthScale_ = 1
 __device__ __forceinline__ void set_center_norm(const OptFields& F, const DevOptions& o, const double* x, float* c,
                                                 float* n) {
@@ -340,8 +371,9 @@ __device__ __forceinline__ void set_center_norm(const OptFields& F, const DevOpt
     for (int k = 0; k < 3; k++) c[k] = F.refCenter[k] + (x0 * F.refRay[k]) * 1.0f;
     const float angle1 = (float)(x[1] * (double)o.angle_scale);
     const float angle2 = (float)(x[2] * (double)o.angle_scale);
-    const double s1 = sin((double)angle1), c1 = cos((double)angle1);
-    const double s2 = sin((double)angle2), c2 = cos((double)angle2);
+    double s1, c1, s2, c2;
+    sincos_halfpi((double)angle1, s1, c1);
+    sincos_halfpi((double)angle2, s2, c2);
     const float fx = (float)(s1 * c2);
     const float fy = (float)s2;
     const float fz = (float)(-c1 * c2);

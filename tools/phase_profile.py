@@ -1,0 +1,24 @@
+import sys, ctypes as C, numpy as np, torch
+sys.path.insert(0,'.')
+from hpmvs_amd import api, synth
+api.LIB_PATH='/tmp/libhpmvs_prof.so' if len(sys.argv)<2 else sys.argv[1]
+L=api.lib()
+dev=torch.device('cuda',0)
+scene=synth.make_scene(12,1920,1080,n_waves=24,device=dev)
+g=api.Scene(scene)
+seeds=synth.make_seeds(scene,100000,start_level=4,max_images=32)
+b=api.Batch.from_seeds(seeds)
+api.optimize_batch(g,b)
+b=api.Batch.from_seeds(seeds)
+api.optimize_batch(g,b)
+out=(C.c_ulonglong*20)()
+L.hpmvs_debug_counters.argtypes=[C.c_void_p,C.POINTER(C.c_ulonglong)]
+L.hpmvs_debug_counters(g.h,out)
+tA,tB,nr,nq=[int(v) for v in out[:4]]
+names=['trsbox','altmov','update','bq_step']
+for i,nm in enumerate(names):
+    tot,cnt=int(out[4+2*i]),int(out[5+2*i])
+    print(nm,'lane-calls',cnt,'avg cycles per call %.0f'%(tot/max(cnt,1)))
+print('kernel ms',g.last_kernel_ms(),'phaseA cycles',tA,'phaseB cycles',tB,'rounds',nr,'requests',nq)
+print('A share %.2f  cycles/round A %.0f  B per request %.0f  req/round %.2f'%(tA/(tA+tB), tA/nr, tB/max(nq,1), nq/nr))
+print('evals mean', b.nevals[b.nevals>0].mean(), 'ok', b.ok.mean(), 'nevals hist', np.percentile(b.nevals,[50,90,99,100]))
