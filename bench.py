@@ -234,9 +234,17 @@ def main():
         cen_g = work["center"][:m].cpu().numpy()
         nor_g = work["normal"][:m].cpu().numpy()
         unrob = lambda f: f / (1.0 - 3.0 * f)
-        dncc, basin = [], []
+        dncc, basin, ident = [], [], []
+        col_g = work["color"][:m].cpu().numpy()
+        nim_g = work["n_images"][:m].cpu().numpy()
+        img_g = work["images"][:m].cpu().numpy()
+        nev_g = nevals[:m]
         for k in both:
             p = P[k]
+            ident.append(np.array_equal(np.array(p.center[:], dtype=np.float32), cen_g[k]) and
+                         np.array_equal(np.array(p.normal[:], dtype=np.float32), nor_g[k]) and
+                         np.array_equal(np.array(p.color[:], dtype=np.float32), col_g[k]) and
+                         p.nevals == nev_g[k] and list(p.images[:p.n_images]) == list(img_g[k, :nim_g[k]]))
             dncc.append(abs(unrob(p.fmin) - unrob(fmin_g[k])))
             dd = np.linalg.norm(np.array(p.center[:3]) - cen_g[k, :3]) / float(seeds.scale[k])
             cs = float(np.clip(np.dot(np.array(p.normal[:3]), nor_g[k, :3]), -1, 1))
@@ -253,6 +261,7 @@ def main():
             "sample": m, "decision_agreement": float((okc == okg).mean()),
             "mean_abs_ncc_delta": float(np.mean(dncc)) if dncc else None,
             "same_basin_fraction": float(np.mean(basin)) if basin else None,
+            "bit_identical_patch_fraction": float(np.mean(ident)) if ident else None,
             "stage_agreement": float((np.array([p.stage for p in P]) == stage[:m]).mean()),
         }
     if rank == 0:

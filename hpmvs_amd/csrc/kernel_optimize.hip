@@ -237,6 +237,7 @@ __device__ __noinline__ void patch_colour(const DevScene& sc, const uint16_t* ro
 
 __global__ void __launch_bounds__(64, 2) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
     __shared__ uint16_t lists[kP * kRow];
+    __shared__ EvalLds evlds;
     const int lane = lane_id();
     uint16_t* row = &lists[lane * kRow];
 
@@ -395,7 +396,7 @@ __global__ void __launch_bounds__(64, 2) optimize_kernel(DevScene sc, DevOptions
             const int pref = (opp == OP_OBJ) ? 0 : bcast_i(req_ref, p);
             const int prob = bcast_i(req_robust, p);
             const uint16_t* prow = &lists[p * kRow];
-            const EvalResult r = wave_eval_rt(sc, o, prow, pnimg, pref, pc, pn, pscale, opp == OP_OBJ ? 1 : 0, prob);
+            const EvalResult r = wave_eval_exact(sc, o, prow, pnimg, pref, pc, pn, pscale, opp == OP_OBJ ? 1 : 0, prob, evlds);
             const float thr = bcast_f(req_thr, p);
             unsigned long long keep = __ballot(r.incc_lane < 1.0f - thr);
             if (lane == p) {
@@ -430,7 +431,7 @@ void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b,
     // state + image lists) admits 6 waves per CU
     int waves = (b.n + kP - 1) / kP;
     // waves per CU: LDS (optimiser state + lists) and the 32-waves-per-CU limit
-    const int lds_per_wave = (int)(sizeof(double) * BQ_ND * kP + sizeof(int) * BQ_NI * kP + sizeof(uint16_t) * kP * kRow);
+    const int lds_per_wave = (int)(sizeof(double) * BQ_ND * kP + sizeof(int) * BQ_NI * kP + sizeof(uint16_t) * kP * kRow + sizeof(EvalLds));
     int per_cu = (160 * 1024) / lds_per_wave;
     if (per_cu > 16) per_cu = 16;
     const int cap = n_cus * per_cu;

@@ -54,6 +54,8 @@ void launch_half_resize(const uint8_t* src, int w, int h, uint8_t* dst, hipStrea
 __global__ void __launch_bounds__(256) objective_kernel(DevScene sc, DevOptions o, DevBatch b,
                                                         const double* __restrict__ xs, double* __restrict__ f_out,
                                                         int32_t* __restrict__ ngrabs_out) {
+    __shared__ EvalLds lds[4];
+    EvalLds& L = lds[threadIdx.x >> 6];
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int p = wave; p < b.n; p += nwaves) {
@@ -68,7 +70,7 @@ __global__ void __launch_bounds__(256) objective_kernel(DevScene sc, DevOptions 
             const double x[3] = {xs[3 * p], xs[3 * p + 1], xs[3 * p + 2]};
             float c[3], n[3];
             set_center_norm(F, o, x, c, n);
-            const EvalResult r = wave_eval<true>(sc, o, list, nimg, 0, c, n, b.scale[p], 0);
+            const EvalResult r = wave_eval_exact(sc, o, list, nimg, 0, c, n, b.scale[p], 1, 0, L);
             f = r.obj;
             ngr = r.ngrabs;
         }
@@ -92,6 +94,8 @@ void launch_objective(const DevScene& sc, const DevOptions& o, const DevBatch& b
 // setINCCs(ref_idx, robust) for a batch
 __global__ void __launch_bounds__(256) inccs_kernel(DevScene sc, DevOptions o, DevBatch b, int ref_idx, int robust,
                                                     float* __restrict__ out) {
+    __shared__ EvalLds lds[4];
+    EvalLds& L = lds[threadIdx.x >> 6];
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int p = wave; p < b.n; p += nwaves) {
@@ -102,7 +106,7 @@ __global__ void __launch_bounds__(256) inccs_kernel(DevScene sc, DevOptions o, D
         if (nimg > 0 && nimg <= kMaxImages && ref_idx < nimg) {
             const float c[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
             const float n[3] = {b.normal[4 * p], b.normal[4 * p + 1], b.normal[4 * p + 2]};
-            const EvalResult r = wave_eval<false>(sc, o, list, nimg, ref_idx, c, n, b.scale[p], robust);
+            const EvalResult r = wave_eval_exact(sc, o, list, nimg, ref_idx, c, n, b.scale[p], 0, robust, L);
             mine = r.incc_lane;
         }
         if (lane < b.max_images) out[(size_t)p * b.max_images + lane] = (lane < nimg) ? mine : 0.0f;

@@ -316,6 +316,207 @@ __device__ __forceinline__ EvalResult wave_eval(const DevScene& sc, const DevOpt
 }
 
 // ------------------------------------------------------------------------------------------
+// EXACT-ORDER evaluator.
+//
+// BOBYQA on this objective amplifies a 1e-9 relative perturbation of f into a different basin for
+// 7-8 % of patches (tests/sensitivity_probe.py), so "close" objective values are not good enough
+// for parity: the objective has to be the reference's float32 arithmetic bit for bit, including
+// the SEQUENTIAL summation order of Patch2d::normalize / dot (Patch2d.hpp:37-84) and the
+// incremental sample stepping of sampleTexture (PatchOptimizer.cpp:511-526).  A wave reduction
+// cannot do that, but the sums of DIFFERENT images are independent, so:
+//   1. lanes 0..48 fetch the raw texels of up to kChunk images (all tap loads of a chunk are issued
+//      before any is consumed) and stage them in LDS in the reference's data[(y*7+x)*3+c] layout;
+//   2. lane (m*3+c) forms the channel mean of image m sequentially over the 49 pixels;
+//   3. lane m forms the variance sum sequentially; 4. lanes 0..48 normalise in place;
+//   5. lane m forms the 147-term dot product with the reference texture sequentially.
+// Built with -ffp-contract=off, every float operation is the one the CPU executes.
+constexpr int kChunk = 7;            // images per chunk besides the reference texture
+constexpr int kTexStride = 148;      // floats per staged texture (147 + 1: 16-byte rows, distinct banks)
+struct EvalLds {
+    float tex[(kChunk + 1) * kTexStride];  // slot 0: reference texture, slots 1..kChunk: chunk members
+    float ave[(kChunk + 1) * 4];           // per slot: channel means, then sqrt(variance)
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // single wavefront: DS operations execute in issue order; this only stops the compiler from
+    // moving LDS accesses across the hand-over between lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct Taps { uint2 a, b; float f00, f01, f10, f11; };
+
+// address + weights of the texel this lane samples (sampleTexture's stepping: l += dy per row,
+// c += dx per column, PatchOptimizer.cpp:511-526), and the two tap loads
+__device__ __forceinline__ Taps issue_taps(float tlx, float tly, float dxx, float dxy, float dyx, float dyy,
+                                           const uint8_t* pix, int W, int ixx, int iyy) {
+    float x = tlx, y = tly;
+#pragma unroll
+    for (int k = 0; k < kTex - 1; k++) { if (k < iyy) { x += dyx; y += dyy; } }
+#pragma unroll
+    for (int k = 0; k < kTex - 1; k++) { if (k < ixx) { x += dxx; y += dxy; } }
+    const int lx = (int)x, ly = (int)y;
+    const uint8_t* p0 = pix + 3 * (ly * W + lx);
+    Taps t;
+    t.a = load8(p0);
+    t.b = load8(p0 + 3 * W);
+    const float dx1 = x - (float)lx, dx0 = 1.0f - dx1;
+    const float dy1 = y - (float)ly, dy0 = 1.0f - dy1;
+    t.f00 = dx0 * dy0; t.f01 = dx0 * dy1; t.f10 = dx1 * dy0; t.f11 = dx1 * dy1;
+    return t;
+}
+
+// Image::getColor (Image.h:104-113) in its evaluation order; stores the lane's texel into the staged texture
+__device__ __forceinline__ void store_texel(const Taps& t, float* tex, int lane) {
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    r += (float)(t.a.x & 0xff) * t.f00 + (float)(t.b.x & 0xff) * t.f01;
+    g += (float)((t.a.x >> 8) & 0xff) * t.f00 + (float)((t.b.x >> 8) & 0xff) * t.f01;
+    b += (float)((t.a.x >> 16) & 0xff) * t.f00 + (float)((t.b.x >> 16) & 0xff) * t.f01;
+    r += (float)(t.a.x >> 24) * t.f10 + (float)(t.b.x >> 24) * t.f11;
+    g += (float)(t.a.y & 0xff) * t.f10 + (float)(t.b.y & 0xff) * t.f11;
+    b += (float)((t.a.y >> 8) & 0xff) * t.f10 + (float)((t.b.y >> 8) & 0xff) * t.f11;
+    tex[3 * lane + 0] = r; tex[3 * lane + 1] = g; tex[3 * lane + 2] = b;
+}
+
+template <typename ListT>
+__device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const DevOptions& o, const ListT* list,
+                                                      int nimg, int ref_slot, const float* c, const float* n,
+                                                      float scale, int obj_mode, int robust, EvalLds& L) {
+    EvalResult res;
+    res.obj = 2.0; res.incc_lane = 2.0f; res.incc_sum = 0.0f; res.ngrabs = 0;
+    const int lane = lane_id();
+    const bool active = lane < kTexPix;
+    const int sl = active ? lane : kTexPix - 1;
+    const int iyy = sl / kTex, ixx = sl % kTex;
+
+    const DevView& RV = sc.views[(int)list[ref_slot]];
+    float px[3], py[3], pz[3];
+    calc_patch_axes(RV.xaxis, RV.yaxis, n, scale, px, py, pz);
+    float zax[3];
+    for (int k = 0; k < 3; k++) zax[k] = obj_mode ? pz[k] : n[k];
+
+    Prep P;
+    P.ok = 0; P.tlx = P.tly = P.dxx = P.dxy = P.dyx = P.dyy = 0.0f; P.pix = nullptr; P.W = 0;
+    if (lane < nimg) P = prep_image(sc.views[(int)list[lane]], o, c, scale, px, py, zax);
+
+    const unsigned long long okmask = __ballot(P.ok != 0);
+    if (!((okmask >> ref_slot) & 1ull)) {
+        if (!obj_mode) {
+            float s = 0.0f;
+            for (int k = 0; k < nimg; k++) s += 2.0f;
+            res.incc_sum = s;
+        }
+        return res;
+    }
+    unsigned long long todo = okmask & ~(1ull << ref_slot);
+    int ngr = 1, nok = 0;
+    double val = 0.0;
+    float mine = (lane == ref_slot) ? 0.0f : 2.0f;
+    bool first = true;
+    while (first || todo) {
+        // ---- members of this chunk: the lowest set bits of `todo`, ascending image index
+        unsigned long long chunk = 0ull, t = todo;
+        for (int k = 0; k < kChunk && t; k++) { chunk |= t & (~t + 1ull); t &= t - 1ull; }
+        todo = t;
+        const int nm = __popcll(chunk);
+        // lane s in 1..nm knows which image it stands for; slot 0 is the reference image
+        int member = ref_slot;
+        if (lane >= 1 && lane <= nm) {
+            unsigned long long u = chunk;
+            for (int j = 1; j < lane; j++) u &= u - 1ull;
+            member = __ffsll((long long)u) - 1;
+        }
+        const int s0 = first ? 0 : 1;
+        // ---- 1. fetch: issue every tap load of the chunk, then convert + stage
+        Taps taps[kChunk + 1];
+#pragma unroll
+        for (int s = 0; s <= kChunk; s++) {
+            if (s >= s0 && s <= nm) {
+                const int v = bcast_i(member, s);
+                taps[s] = issue_taps(bcast_f(P.tlx, v), bcast_f(P.tly, v), bcast_f(P.dxx, v), bcast_f(P.dxy, v),
+                                     bcast_f(P.dyx, v), bcast_f(P.dyy, v), bcast_p(P.pix, v), bcast_i(P.W, v), ixx, iyy);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s <= kChunk; s++) {
+            if (s >= s0 && s <= nm && active) store_texel(taps[s], &L.tex[s * kTexStride], lane);
+        }
+        wave_lds_sync();
+        // ---- 2. channel means: lane m*3+c, sequential over the 49 pixels (Patch2d.hpp:51-58)
+        {
+            const int m = lane / 3, ch = lane - 3 * m;
+            if (m >= s0 && m <= nm) {
+                const float* tp = &L.tex[m * kTexStride + ch];
+                float a = 0.0f;
+                for (int i = 0; i < kTexPix; i++) a += tp[3 * i];
+                L.ave[m * 4 + ch] = a / 49.0f;
+            }
+        }
+        wave_lds_sync();
+        // ---- 3. variance: lane m, sequential (Patch2d.hpp:60-70)
+        if (lane >= s0 && lane <= nm) {
+            const float* tp = &L.tex[lane * kTexStride];
+            const float a0 = L.ave[lane * 4 + 0], a1 = L.ave[lane * 4 + 1], a2 = L.ave[lane * 4 + 2];
+            float v2 = 0.0f;
+            for (int i = 0; i < kTexPix; i++) {
+                const float f0 = a0 - tp[3 * i], f1 = a1 - tp[3 * i + 1], f2 = a2 - tp[3 * i + 2];
+                v2 += f0 * f0 + f1 * f1 + f2 * f2;
+            }
+            v2 = sqrtf(v2 / 147.0f);
+            if (v2 == 0.0f) v2 = 1.0f;
+            L.ave[lane * 4 + 3] = v2;
+        }
+        wave_lds_sync();
+        // ---- 4. normalise in place (Patch2d.hpp:75-83): every lane takes elements lane, lane+64, lane+128
+        for (int s = s0; s <= nm; s++) {
+            float* tp = &L.tex[s * kTexStride];
+            const float dv = L.ave[s * 4 + 3];
+            for (int e = lane; e < 147; e += 64) {
+                float tv = tp[e];
+                tv -= L.ave[s * 4 + (e % 3)];
+                tv /= dv;
+                tp[e] = tv;
+            }
+        }
+        wave_lds_sync();
+        // ---- 5. NCC dot with the reference texture: lane m, sequential over 147 (Patch2d.hpp:37-44)
+        float raw = 2.0f;
+        if (lane >= 1 && lane <= nm) {
+            const float* rp = &L.tex[0];
+            const float* tp = &L.tex[lane * kTexStride];
+            float ans = 0.0f;
+            for (int k = 0; k < 147; k++) ans += rp[k] * tp[k];
+            raw = 1.0f - ans / 147.0f;
+        }
+        // ---- deliver in ascending image order
+        for (int s = 1; s <= nm; s++) {
+            const int v = bcast_i(member, s);
+            const float e = bcast_f(raw, s);
+            ngr++;
+            if (obj_mode) {
+                val += (double)robustincc(e);
+                nok++;
+            } else if (lane == v) {
+                mine = robust ? robustincc(e) : e;
+            }
+        }
+        wave_lds_sync();
+        first = false;
+    }
+    res.ngrabs = ngr;
+    if (obj_mode) {
+        res.obj = (nok < o.MIN_IMAGES_PER_PATCH - 1) ? 2.0 : val / (double)nok;
+    } else {
+        res.incc_lane = mine;
+        float s = 0.0f;
+        for (int k = 0; k < nimg; k++) s += bcast_f(mine, k);
+        res.incc_sum = s;
+    }
+    return res;
+}
+
+// ------------------------------------------------------------------------------------------
 // optimiser-variable <-> patch maps (per-lane scalar)
 
 struct OptFields {       // setOptimizationFields (PatchOptimizer.cpp:384-399)
@@ -380,12 +581,50 @@ __device__ __forceinline__ void set_center_norm(const OptFields& F, const DevOpt
     for (int k = 0; k < 3; k++) n[k] = (F.imgX[k] * fx + F.imgY[k] * fy) + F.imgZ[k] * fz;
 }
 
+// std::asin(float) as the host C library computes it.  x[2] of the BOBYQA start point is
+// asinf(fy) / angleScale (PatchOptimizer.cpp:427): a one-ulp float difference there changes the
+// whole trajectory, so the device evaluates the SAME algorithm as glibc 2.35's __ieee754_asinf
+// (sysdeps/ieee754/flt-32/e_asinf.c: 5-term polynomial on |x| < 0.5, sqrt reduction with a split
+// high part above), float32 operations in the same order.  tools/asinf_check.py verifies the
+// restatement bit for bit against the host libm.
+__device__ __forceinline__ float asinf_glibc(float x) {
+    const float one = 1.0f, pio2_hi = 1.57079637050628662109375f, pio2_lo = -4.37113900018624283e-8f,
+                pio4_hi = 0.785398185253143310546875f;
+    const float p0 = 1.666675248e-1f, p1 = 7.495297643e-2f, p2 = 4.547037598e-2f, p3 = 2.417951451e-2f,
+                p4 = 4.216630880e-2f;
+    const int hx = __float_as_int(x);
+    const int ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000) return x * pio2_hi + x * pio2_lo;
+    if (ix > 0x3f800000) return (x - x) / (x - x);
+    if (ix < 0x3f000000) {
+        if (ix < 0x32000000) return x;
+        const float t = x * x;
+        const float w = t * (p0 + t * (p1 + t * (p2 + t * (p3 + t * p4))));
+        return x + x * w;
+    }
+    float w = one - fabsf(x);
+    float t = w * 0.5f;
+    float p = t * (p0 + t * (p1 + t * (p2 + t * (p3 + t * p4))));
+    const float s = sqrtf(t);
+    if (ix >= 0x3F79999A) {
+        t = pio2_hi - (2.0f * (s + s * p) - pio2_lo);
+    } else {
+        w = __int_as_float(__float_as_int(s) & 0xfffff000);
+        const float c = (t - w * w) / (s + w);
+        const float r = p;
+        p = 2.0f * s * r - (pio2_lo - 2.0f * c);
+        const float q = pio4_hi - 2.0f * w;
+        t = pio4_hi - (p - q);
+    }
+    return hx > 0 ? t : -t;
+}
+
 // parametersFromCenterNorm (PatchOptimizer.cpp:416-446) for c = refCenter_ (the only call site)
 __device__ __forceinline__ void parameters_from_center_norm(const OptFields& F, const DevOptions& o, const float* n,
                                                             const double* lb, const double* ub, double* x) {
     x[0] = 0.0;  // (refCenter - refCenter) . refRay
     const float fx = dot3f(F.imgX, n), fy = dot3f(F.imgY, n), fz = dot3f(F.imgZ, n);
-    x[2] = (double)asinf(fy);
+    x[2] = (double)asinf_glibc(fy);
     double t = (x[2] < 1.0) ? x[2] : 1.0;
     t = (-1.0 < t) ? t : -1.0;
     const float cosb = (float)cos(t);

@@ -1,19 +1,18 @@
 """GPU parity of the full refinement (hpmvs_optimize_batch) against the CPU oracle, which runs the
 restated photometric path around the reference's GENUINE NLopt BOBYQA (oracle/_ref) when that
-library travelled, else the oracle's own port.
+library travelled, else the goldens it produced.
 
-Stated tolerances (float32 textures + float64 optimiser; GPU reductions are tree-shaped and use FMA,
-so objective values differ from the CPU's at the 1e-6 level and BOBYQA trajectories may part ways
-late in the run):
-  * success / failure decision and failing stage : identical for >= 97 % of patches
-  * on patches where both succeed:
-      NCC score  ncc = 1 - unrobust(f*)      : mean |d| <= 2e-3 (SURVEY 8d proposed 5e-3)
-      same basin (|d depth| < 0.25 scale and normal within 2 deg) : >= 80 %
-      attached image list after optimize()   : identical for >= 80 %
-    The basin figure is bounded by the reference algorithm itself, not by this implementation:
-    BOBYQA on this piecewise-smooth objective amplifies a 1e-9 RELATIVE perturbation of f into a
-    different basin for 7-8 % of patches on the CPU (tests/sensitivity_probe.py, DESIGN.md
-    "Parity"), so any objective that is not bit-identical tops out near 92 %.
+Stated tolerance.  Every float32 operation of the objective and every float64 operation of BOBYQA
+is the one the CPU executes, so the whole refinement is expected to be BIT-IDENTICAL: same
+success/failure and failing stage, same evaluation count, same centre / normal / image list /
+colour.  The only arithmetic that is not reproduced operation-for-operation is the C library's
+double acos()/cos()/log2() (used once per patch for the BOBYQA start point and the level tests;
+asinf IS reproduced, see photometric.hpp): a last-bit difference there perturbs the float64 start
+point by ~1e-16 and BOBYQA can amplify that (it moves 7 % of patches out of their basin for a 1e-9
+relative perturbation of f, tests/sensitivity_probe.py).  The tests therefore require
+  * decisions + failing stage identical            : 100 %
+  * bit-identical refined patch (all float fields) : >= 99 %  (measured 100 %)
+  * mean |d ncc| over all jointly successful patches <= 1e-5  (SURVEY 8d proposed 5e-3)
 """
 import numpy as np
 import pytest
@@ -56,6 +55,12 @@ def compare(seeds, oracle_scene, gpu_scene, tag):
                   same_basin=float(basin.mean()), mean_dncc=float(np.mean(dncc)), med_dd=float(np.median(dd)),
                   p95_dd=float(np.percentile(dd, 95)), med_dn=float(np.median(dn)), same_imgs=float(np.mean(same_imgs)),
                   identical_x=float(np.mean([np.array_equal(np.array(P[k].x[:]), batch.x[k]) for k in both])),
+                  bit_identical_patch=float(np.mean([
+                      np.array_equal(np.array(P[k].center[:], dtype=np.float32), batch.center[k]) and
+                      np.array_equal(np.array(P[k].normal[:], dtype=np.float32), batch.normal[k]) and
+                      np.array_equal(np.array(P[k].color[:], dtype=np.float32), batch.color[k]) and
+                      P[k].nevals == batch.nevals[k] and
+                      list(P[k].images[:P[k].n_images]) == list(batch.images[k, :batch.n_images[k]]) for k in both])),
                   nevals_cpu=float(np.mean([P[k].nevals for k in both])), nevals_gpu=float(batch.nevals[both].mean()),
                   max_dcol_same=float(np.max(np.array(dcol)[np.array(same_imgs)])) if any(same_imgs) else -1.0)
     print(report)
@@ -63,10 +68,10 @@ def compare(seeds, oracle_scene, gpu_scene, tag):
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/parity_reports.jsonl", "a") as fh:
         fh.write(json.dumps(report) + "\n")
-    assert agree.mean() >= 0.97, report
-    assert basin.mean() >= 0.80, report
-    assert np.mean(dncc) <= 2e-3, report
-    assert np.mean(same_imgs) >= 0.80, report
+    assert agree.mean() == 1.0, report
+    assert report["bit_identical_patch"] >= 0.99, report
+    assert np.mean(dncc) <= 1e-5, report
+    assert basin.mean() >= 0.99 and np.mean(same_imgs) >= 0.99, report
     # scale_3dx_ is returned unchanged and ncc_ is the reference's constant
     assert np.all(batch.ncc[ok_gpu] == np.float32(1.4))
     return report
@@ -131,14 +136,15 @@ def test_gpu_against_committed_goldens():
         x = np.array([by_patch[k][j]["x"] for k in idx])
         want = np.array([by_patch[k][j]["f"] for k in idx])
         got, _ = api.objective_batch(gpu, api.Batch.from_seeds(seeds, idx), x)
-        assert np.array_equal(got == 2.0, want == 2.0)
-        assert np.abs(got - want).max() <= 2e-5
+        assert np.array_equal(got, want)
     api.optimize_batch(gpu, batch)
     e = exp["patches"]
     ok_cpu = np.array([bool(p["ok"]) for p in e])
-    assert (ok_cpu == batch.ok.astype(bool)).mean() >= 0.97
+    assert np.array_equal(ok_cpu, batch.ok.astype(bool))
     both = np.nonzero(ok_cpu & batch.ok.astype(bool))[0]
-    dncc = [abs(unrobust(e[k]["fmin"]) - unrobust(batch.fmin[k])) for k in both]
-    same = [e[k]["images"] == list(batch.images[k, :batch.n_images[k]]) for k in both]
-    assert np.mean(dncc) <= 2e-3 and np.mean(same) >= 0.8
+    same = [e[k]["images"] == list(batch.images[k, :batch.n_images[k]]) and e[k]["nevals"] == batch.nevals[k] and
+            np.array_equal(np.array(e[k]["center"], dtype=np.float32), batch.center[k]) and
+            np.array_equal(np.array(e[k]["normal"], dtype=np.float32), batch.normal[k]) and
+            np.array_equal(np.array(e[k]["color"], dtype=np.float32), batch.color[k]) for k in both]
+    assert np.mean(same) >= 0.99, np.mean(same)
     gpu.close()

@@ -1,10 +1,9 @@
 """GPU parity of the photometric kernels against the CPU oracle (through the C ABI).
 
-Tolerances (float32 path; the GPU uses FMA contraction and tree-shaped wave reductions where the
-reference sums sequentially):
-  pyramid            : bit-exact (u8)
-  setINCCs entries   : |d| <= 2e-5
-  objective_fn value : |d| <= 2e-5   (SURVEY 8d proposed 1e-4)
+Tolerance: NONE.  The kernels execute the reference's float32 arithmetic operation for operation
+(sequential summation order of Patch2d::normalize/dot, incremental sample stepping, no FMA
+contraction), so pyramid bytes, setINCCs entries and objective_fn values must be BIT-IDENTICAL to
+the CPU oracle (SURVEY 8d had proposed |d| <= 1e-4).
 """
 import numpy as np
 import pytest
@@ -43,7 +42,7 @@ def test_inccs_parity(tiny_seeds, oracle_scene, gpu_scene):
             want = orc.inccs(oracle_scene, P[k], ref_idx, robust)
             n = P[k].n_images
             worst = max(worst, float(np.abs(got[k, :n] - want).max()))
-        assert worst <= 2e-5, (ref_idx, robust, worst)
+        assert worst == 0.0, (ref_idx, robust, worst)
 
 
 def test_objective_parity(tiny_seeds, oracle_scene, gpu_scene):
@@ -58,7 +57,5 @@ def test_objective_parity(tiny_seeds, oracle_scene, gpu_scene):
         x = x0 + (rng.uniform(-1, 1, size=x0.shape) * np.array([0.3, 2.0, 2.0]) if trial else 0.0)
         f_gpu, g_gpu = api.objective_batch(gpu_scene, batch, x)
         f_cpu = np.array([orc.objective_at(oracle_scene, P[k], x[k]) for k in range(len(idx))])
-        # plateau decisions (2.0) must agree exactly, values within tolerance
-        assert np.array_equal(f_gpu == 2.0, f_cpu == 2.0)
-        assert np.abs(f_gpu - f_cpu).max() <= 2e-5, np.abs(f_gpu - f_cpu).max()
+        assert np.array_equal(f_gpu, f_cpu), np.abs(f_gpu - f_cpu).max()
         assert (f_cpu < 2.0).sum() > 10
