@@ -45,10 +45,10 @@
 #include <math.h>
 
 // optional region timers (only in -DHPMVS_PROFILE_PHASES device builds; see tools/phase_profile.py)
+#include "prof.h"
 #if defined(HPMVS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
-extern __device__ unsigned long long g_bqprof[32];
 #define BQ_PROF_BEGIN(v) const long long v = clock64()
-#define BQ_PROF_END(v, i) do { atomicAdd(&g_bqprof[2 * (i)], (unsigned long long)(clock64() - v)); atomicAdd(&g_bqprof[2 * (i) + 1], 1ull); } while (0)
+#define BQ_PROF_END(v, i) do { if (__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) { s_prof[2 * (i)] += (unsigned long long)(clock64() - v); s_prof[2 * (i) + 1] += 1ull; } } while (0)
 #else
 #define BQ_PROF_BEGIN(v) do { } while (0)
 #define BQ_PROF_END(v, i) do { } while (0)

@@ -472,7 +472,7 @@ int hpmvs_debug_counters(const hpmvs_scene* s, unsigned long long* out4) {
     if (!s || !out4) return fail(HPMVS_ERR_ARG, "debug_counters: null argument");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out4, (char*)s->dqueue + 16, 160, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out4, (char*)s->dqueue + 16, 192, hipMemcpyDeviceToHost));
     return HPMVS_OK;
 }
 

@@ -27,9 +27,7 @@
 #include <hip/hip_runtime.h>
 
 // optimiser state of the kP patches a wavefront owns lives in LDS (see bobyqa3.hpp)
-#ifdef HPMVS_PROFILE_PHASES
-__device__ unsigned long long g_bqprof[32];
-#endif
+#include "prof.h"
 #define BQ_STATE_LDS 1
 #ifndef BQ_P
 #define BQ_P 16
@@ -250,7 +248,8 @@ __global__ void __launch_bounds__(64, 2) optimize_kernel(DevScene sc, DevOptions
     OptFields F;
     Bobyqa3 B;
     B.slot = lane < kP ? lane : 0;
-    // request posted to phase B
+    // request posted to phase B (with the patch axes of calculatePatchAxis for the request's reference image)
+    float ax[3] = {0, 0, 0}, ay[3] = {0, 0, 0}, az[3] = {0, 0, 1};
     int op = OP_NONE, req_ref = 0, req_robust = 0;
     float req_thr = 0.0f;
     // results delivered by phase B
@@ -262,6 +261,8 @@ __global__ void __launch_bounds__(64, 2) optimize_kernel(DevScene sc, DevOptions
 
 #ifdef HPMVS_PROFILE_PHASES
     long long tA = 0, tB = 0, nrounds = 0, nreq = 0, t0 = clock64();
+    if (lane < 32) s_prof[lane] = 0ull;
+    __syncthreads();
 #endif
     for (;;) {
         // ================= phase A: every lane advances its own patch until it needs the wave
@@ -378,6 +379,10 @@ __global__ void __launch_bounds__(64, 2) optimize_kernel(DevScene sc, DevOptions
                 stage = S_FETCH;
             }
         }
+        if (op != OP_NONE) {  // calculatePatchAxis (PatchOptimizer.cpp:532-548), lane-parallel
+            const DevView& RV = sc.views[row[op == OP_OBJ ? 0 : req_ref]];
+            calc_patch_axes(RV.xaxis, RV.yaxis, n, scale, ax, ay, az);
+        }
         // ================= phase B: the wave serves the posted requests one patch at a time
         __syncthreads();  // single-wave workgroup: orders the lanes' LDS list updates before cross-lane reads
         unsigned long long pending = __ballot(op != OP_NONE);
@@ -396,7 +401,11 @@ __global__ void __launch_bounds__(64, 2) optimize_kernel(DevScene sc, DevOptions
             const int pref = (opp == OP_OBJ) ? 0 : bcast_i(req_ref, p);
             const int prob = bcast_i(req_robust, p);
             const uint16_t* prow = &lists[p * kRow];
-            const EvalResult r = wave_eval_exact(sc, o, prow, pnimg, pref, pc, pn, pscale, opp == OP_OBJ ? 1 : 0, prob, evlds);
+            const float pax[3] = {bcast_f(ax[0], p), bcast_f(ax[1], p), bcast_f(ax[2], p)};
+            const float pay[3] = {bcast_f(ay[0], p), bcast_f(ay[1], p), bcast_f(ay[2], p)};
+            const float paz[3] = {bcast_f(az[0], p), bcast_f(az[1], p), bcast_f(az[2], p)};
+            const EvalResult r = wave_eval_exact(sc, o, prow, pnimg, pref, pc, pn, pscale, pax, pay, paz,
+                                                 opp == OP_OBJ ? 1 : 0, prob, evlds);
             const float thr = bcast_f(req_thr, p);
             unsigned long long keep = __ballot(r.incc_lane < 1.0f - thr);
             if (lane == p) {
@@ -419,7 +428,7 @@ __global__ void __launch_bounds__(64, 2) optimize_kernel(DevScene sc, DevOptions
         atomicAdd(&dbg[1], (unsigned long long)tB);
         atomicAdd(&dbg[2], (unsigned long long)nrounds);
         atomicAdd(&dbg[3], (unsigned long long)nreq);
-        if (blockIdx.x == 0) for (int k = 0; k < 16; k++) dbg[4 + k] = g_bqprof[k];  // (approximate: read while others run)
+        for (int k = 0; k < 20; k++) atomicAdd(&dbg[4 + k], s_prof[k]);
     }
 #endif
 }

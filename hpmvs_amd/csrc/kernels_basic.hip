@@ -70,7 +70,9 @@ __global__ void __launch_bounds__(256) objective_kernel(DevScene sc, DevOptions 
             const double x[3] = {xs[3 * p], xs[3 * p + 1], xs[3 * p + 2]};
             float c[3], n[3];
             set_center_norm(F, o, x, c, n);
-            const EvalResult r = wave_eval_exact(sc, o, list, nimg, 0, c, n, b.scale[p], 1, 0, L);
+            float px[3], py[3], pz[3];
+            calc_patch_axes(sc.views[list[0]].xaxis, sc.views[list[0]].yaxis, n, b.scale[p], px, py, pz);
+            const EvalResult r = wave_eval_exact(sc, o, list, nimg, 0, c, n, b.scale[p], px, py, pz, 1, 0, L);
             f = r.obj;
             ngr = r.ngrabs;
         }
@@ -106,7 +108,9 @@ __global__ void __launch_bounds__(256) inccs_kernel(DevScene sc, DevOptions o, D
         if (nimg > 0 && nimg <= kMaxImages && ref_idx < nimg) {
             const float c[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
             const float n[3] = {b.normal[4 * p], b.normal[4 * p + 1], b.normal[4 * p + 2]};
-            const EvalResult r = wave_eval_exact(sc, o, list, nimg, ref_idx, c, n, b.scale[p], 0, robust, L);
+            float px[3], py[3], pz[3];
+            calc_patch_axes(sc.views[list[ref_idx]].xaxis, sc.views[list[ref_idx]].yaxis, n, b.scale[p], px, py, pz);
+            const EvalResult r = wave_eval_exact(sc, o, list, nimg, ref_idx, c, n, b.scale[p], px, py, pz, 0, robust, L);
             mine = r.incc_lane;
         }
         if (lane < b.max_images) out[(size_t)p * b.max_images + lane] = (lane < nimg) ? mine : 0.0f;

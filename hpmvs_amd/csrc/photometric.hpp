@@ -25,6 +25,15 @@
 
 #include "dev_types.h"
 
+#include "prof.h"
+#if defined(HPMVS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+#define PH_T(v) const long long v = clock64()
+#define PH_ADD(v0, v1, i) do { if (__lane_id() == 0) { s_prof[2 * (i)] += (unsigned long long)((v1) - (v0)); s_prof[2 * (i) + 1] += 1ull; } } while (0)
+#else
+#define PH_T(v) do { } while (0)
+#define PH_ADD(v0, v1, i) do { } while (0)
+#endif
+
 namespace hpmvs {
 
 // ------------------------------------------------------------------------------------------
@@ -331,9 +340,11 @@ __device__ __forceinline__ EvalResult wave_eval(const DevScene& sc, const DevOpt
 //   5. lane m forms the 147-term dot product with the reference texture sequentially.
 // Built with -ffp-contract=off, every float operation is the one the CPU executes.
 constexpr int kChunk = 7;            // images per chunk besides the reference texture
-constexpr int kTexStride = 148;      // floats per staged texture (147 + 1: 16-byte rows, distinct banks)
-struct EvalLds {
-    float tex[(kChunk + 1) * kTexStride];  // slot 0: reference texture, slots 1..kChunk: chunk members
+constexpr int kPlane = 52;           // floats per staged channel plane (49 + 3: 16-byte aligned planes)
+constexpr int kTexStride = 160;      // floats per staging slot: 3 planes of raw texels, later reused for the
+                                     // 49 squared deviations and then the 147 products ref[k]*img[k]
+struct alignas(16) EvalLds {
+    float buf[(kChunk + 1) * kTexStride];  // slot 0: reference image, slots 1..kChunk: chunk members
     float ave[(kChunk + 1) * 4];           // per slot: channel means, then sqrt(variance)
 };
 
@@ -343,6 +354,27 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sequential float sum of N contiguous LDS floats (16-byte aligned, padded to a multiple of 4) by one
+// lane: float4 reads, adds strictly in index order
+template <int N>
+__device__ __forceinline__ float seq_sum(const float* p) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    float a = 0.0f;
+    constexpr int Q = N / 4;
+#pragma unroll 6
+    for (int q = 0; q < Q; q++) {
+        const float4 u = p4[q];
+        a += u.x; a += u.y; a += u.z; a += u.w;
+    }
+    if (N % 4) {
+        const float4 u = p4[Q];
+        if (N % 4 >= 1) a += u.x;
+        if (N % 4 >= 2) a += u.y;
+        if (N % 4 >= 3) a += u.z;
+    }
+    return a;
 }
 
 struct Taps { uint2 a, b; float f00, f01, f10, f11; };
@@ -367,38 +399,39 @@ __device__ __forceinline__ Taps issue_taps(float tlx, float tly, float dxx, floa
     return t;
 }
 
-// Image::getColor (Image.h:104-113) in its evaluation order; stores the lane's texel into the staged texture
-__device__ __forceinline__ void store_texel(const Taps& t, float* tex, int lane) {
-    float r = 0.0f, g = 0.0f, b = 0.0f;
+// Image::getColor (Image.h:104-113) in its evaluation order
+__device__ __forceinline__ void texel(const Taps& t, float& r, float& g, float& b) {
+    r = 0.0f; g = 0.0f; b = 0.0f;
     r += (float)(t.a.x & 0xff) * t.f00 + (float)(t.b.x & 0xff) * t.f01;
     g += (float)((t.a.x >> 8) & 0xff) * t.f00 + (float)((t.b.x >> 8) & 0xff) * t.f01;
     b += (float)((t.a.x >> 16) & 0xff) * t.f00 + (float)((t.b.x >> 16) & 0xff) * t.f01;
     r += (float)(t.a.x >> 24) * t.f10 + (float)(t.b.x >> 24) * t.f11;
     g += (float)(t.a.y & 0xff) * t.f10 + (float)(t.b.y & 0xff) * t.f11;
     b += (float)((t.a.y >> 8) & 0xff) * t.f10 + (float)((t.b.y >> 8) & 0xff) * t.f11;
-    tex[3 * lane + 0] = r; tex[3 * lane + 1] = g; tex[3 * lane + 2] = b;
 }
 
+// px, py, pz: calculatePatchAxis output for the reference image's camera (wave-uniform, computed by
+// the requesting lane in phase A / by the caller).
 template <typename ListT>
 __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const DevOptions& o, const ListT* list,
                                                       int nimg, int ref_slot, const float* c, const float* n,
-                                                      float scale, int obj_mode, int robust, EvalLds& L) {
+                                                      float scale, const float* px, const float* py, const float* pz,
+                                                      int obj_mode, int robust, EvalLds& L) {
     EvalResult res;
     res.obj = 2.0; res.incc_lane = 2.0f; res.incc_sum = 0.0f; res.ngrabs = 0;
     const int lane = lane_id();
     const bool active = lane < kTexPix;
     const int sl = active ? lane : kTexPix - 1;
     const int iyy = sl / kTex, ixx = sl % kTex;
-
-    const DevView& RV = sc.views[(int)list[ref_slot]];
-    float px[3], py[3], pz[3];
-    calc_patch_axes(RV.xaxis, RV.yaxis, n, scale, px, py, pz);
+    PH_T(t1);
     float zax[3];
     for (int k = 0; k < 3; k++) zax[k] = obj_mode ? pz[k] : n[k];
 
     Prep P;
     P.ok = 0; P.tlx = P.tly = P.dxx = P.dxy = P.dyx = P.dyy = 0.0f; P.pix = nullptr; P.W = 0;
     if (lane < nimg) P = prep_image(sc.views[(int)list[lane]], o, c, scale, px, py, zax);
+    PH_T(t2);
+    PH_ADD(t1, t2, 5);
 
     const unsigned long long okmask = __ballot(P.ok != 0);
     if (!((okmask >> ref_slot) & 1ull)) {
@@ -413,6 +446,7 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
     int ngr = 1, nok = 0;
     double val = 0.0;
     float mine = (lane == ref_slot) ? 0.0f : 2.0f;
+    float refn0 = 0.0f, refn1 = 0.0f, refn2 = 0.0f;  // this lane's normalised reference texel
     bool first = true;
     while (first || todo) {
         // ---- members of this chunk: the lowest set bits of `todo`, ascending image index
@@ -428,8 +462,11 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
             member = __ffsll((long long)u) - 1;
         }
         const int s0 = first ? 0 : 1;
-        // ---- 1. fetch: issue every tap load of the chunk, then convert + stage
+        PH_T(t3);
+        // ---- 1. fetch: issue every tap load of the chunk, then convert; stage the raw texels as
+        //         three channel planes per slot (plane c at buf[c*kPlane + pixel])
         Taps taps[kChunk + 1];
+        float rr[kChunk + 1], gg[kChunk + 1], bb[kChunk + 1];
 #pragma unroll
         for (int s = 0; s <= kChunk; s++) {
             if (s >= s0 && s <= nm) {
@@ -440,55 +477,68 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
         }
 #pragma unroll
         for (int s = 0; s <= kChunk; s++) {
-            if (s >= s0 && s <= nm && active) store_texel(taps[s], &L.tex[s * kTexStride], lane);
+            rr[s] = gg[s] = bb[s] = 0.0f;
+            if (s >= s0 && s <= nm) {
+                texel(taps[s], rr[s], gg[s], bb[s]);
+                if (active) {
+                    float* bp = &L.buf[s * kTexStride];
+                    bp[lane] = rr[s]; bp[kPlane + lane] = gg[s]; bp[2 * kPlane + lane] = bb[s];
+                }
+            }
         }
         wave_lds_sync();
-        // ---- 2. channel means: lane m*3+c, sequential over the 49 pixels (Patch2d.hpp:51-58)
+        PH_T(t4);
+        PH_ADD(t3, t4, 6);
+        // ---- 2. channel means (Patch2d.hpp:51-58): lane m*3+c adds the 49 texels of plane c of slot m in order
         {
             const int m = lane / 3, ch = lane - 3 * m;
-            if (m >= s0 && m <= nm) {
-                const float* tp = &L.tex[m * kTexStride + ch];
-                float a = 0.0f;
-                for (int i = 0; i < kTexPix; i++) a += tp[3 * i];
-                L.ave[m * 4 + ch] = a / 49.0f;
+            if (m >= s0 && m <= nm) L.ave[m * 4 + ch] = seq_sum<49>(&L.buf[m * kTexStride + ch * kPlane]) / 49.0f;
+        }
+        wave_lds_sync();
+        // ---- 3. squared deviations per pixel (Patch2d.hpp:62-69), computed by the pixel lanes ...
+#pragma unroll
+        for (int s = 0; s <= kChunk; s++) {
+            if (s >= s0 && s <= nm && active) {
+                const float4 av = *reinterpret_cast<const float4*>(&L.ave[s * 4]);
+                const float f0 = av.x - rr[s], f1 = av.y - gg[s], f2 = av.z - bb[s];
+                L.buf[s * kTexStride + lane] = f0 * f0 + f1 * f1 + f2 * f2;
             }
         }
         wave_lds_sync();
-        // ---- 3. variance: lane m, sequential (Patch2d.hpp:60-70)
+        // ---- ... and summed in pixel order by lane m
         if (lane >= s0 && lane <= nm) {
-            const float* tp = &L.tex[lane * kTexStride];
-            const float a0 = L.ave[lane * 4 + 0], a1 = L.ave[lane * 4 + 1], a2 = L.ave[lane * 4 + 2];
-            float v2 = 0.0f;
-            for (int i = 0; i < kTexPix; i++) {
-                const float f0 = a0 - tp[3 * i], f1 = a1 - tp[3 * i + 1], f2 = a2 - tp[3 * i + 2];
-                v2 += f0 * f0 + f1 * f1 + f2 * f2;
-            }
-            v2 = sqrtf(v2 / 147.0f);
+            float v2 = sqrtf(seq_sum<49>(&L.buf[lane * kTexStride]) / 147.0f);
             if (v2 == 0.0f) v2 = 1.0f;
             L.ave[lane * 4 + 3] = v2;
         }
         wave_lds_sync();
-        // ---- 4. normalise in place (Patch2d.hpp:75-83): every lane takes elements lane, lane+64, lane+128
-        for (int s = s0; s <= nm; s++) {
-            float* tp = &L.tex[s * kTexStride];
-            const float dv = L.ave[s * 4 + 3];
-            for (int e = lane; e < 147; e += 64) {
-                float tv = tp[e];
-                tv -= L.ave[s * 4 + (e % 3)];
-                tv /= dv;
-                tp[e] = tv;
+        PH_T(t5);
+        PH_ADD(t4, t5, 7);
+        // ---- 4. normalise (Patch2d.hpp:75-83) in registers; products with the reference texture
+        //         (Patch2d.hpp:41) staged in the reference's element order (pixel*3 + channel)
+#pragma unroll
+        for (int s = 0; s <= kChunk; s++) {
+            if (s >= s0 && s <= nm) {
+                const float4 av = *reinterpret_cast<const float4*>(&L.ave[s * 4]);
+                float r = rr[s], g = gg[s], b = bb[s];
+                r -= av.x; r /= av.w;
+                g -= av.y; g /= av.w;
+                b -= av.z; b /= av.w;
+                if (s == 0) { refn0 = r; refn1 = g; refn2 = b; }
+                else if (active) {
+                    float* bp = &L.buf[s * kTexStride + 3 * lane];
+                    bp[0] = refn0 * r; bp[1] = refn1 * g; bp[2] = refn2 * b;
+                }
             }
         }
         wave_lds_sync();
-        // ---- 5. NCC dot with the reference texture: lane m, sequential over 147 (Patch2d.hpp:37-44)
+        PH_T(t6);
+        PH_ADD(t5, t6, 8);
+        // ---- 5. NCC: lane m adds the 147 products in order (Patch2d.hpp:37-44)
         float raw = 2.0f;
-        if (lane >= 1 && lane <= nm) {
-            const float* rp = &L.tex[0];
-            const float* tp = &L.tex[lane * kTexStride];
-            float ans = 0.0f;
-            for (int k = 0; k < 147; k++) ans += rp[k] * tp[k];
-            raw = 1.0f - ans / 147.0f;
-        }
+        if (lane >= 1 && lane <= nm) raw = 1.0f - seq_sum<147>(&L.buf[lane * kTexStride]) / 147.0f;
+        PH_T(t7);
+        PH_ADD(t6, t7, 9);
         // ---- deliver in ascending image order
         for (int s = 1; s <= nm; s++) {
             const int v = bcast_i(member, s);

@@ -11,11 +11,11 @@ b=api.Batch.from_seeds(seeds)
 api.optimize_batch(g,b)
 b=api.Batch.from_seeds(seeds)
 api.optimize_batch(g,b)
-out=(C.c_ulonglong*20)()
+out=(C.c_ulonglong*40)()
 L.hpmvs_debug_counters.argtypes=[C.c_void_p,C.POINTER(C.c_ulonglong)]
 L.hpmvs_debug_counters(g.h,out)
 tA,tB,nr,nq=[int(v) for v in out[:4]]
-names=['trsbox','altmov','update','bq_step']
+names=['trsbox','altmov','update','bq_step','B:axes','B:prep','B:fetch+stage','B:mean+var','B:normalise','B:dot']
 for i,nm in enumerate(names):
     tot,cnt=int(out[4+2*i]),int(out[5+2*i])
     print(nm,'lane-calls',cnt,'avg cycles per call %.0f'%(tot/max(cnt,1)))
