@@ -30,7 +30,7 @@
 #include "prof.h"
 #define BQ_STATE_LDS 1
 #ifndef BQ_P
-#define BQ_P 16
+#define BQ_P 8
 #endif
 #include "bobyqa3.hpp"
 #include "launch.h"

@@ -341,7 +341,7 @@ __device__ __forceinline__ EvalResult wave_eval(const DevScene& sc, const DevOpt
 // Built with -ffp-contract=off, every float operation is the one the CPU executes.
 constexpr int kChunk = 7;            // images per chunk besides the reference texture
 constexpr int kPlane = 52;           // floats per staged channel plane (49 + 3: 16-byte aligned planes)
-constexpr int kTexStride = 160;      // floats per staging slot: 3 planes of raw texels, later reused for the
+constexpr int kTexStride = 164;      // floats per staging slot (16-byte multiple; 164 mod 64 = 36 spreads the per-slot float4 reads over distinct LDS banks): 3 planes of raw texels, later reused for the
                                      // 49 squared deviations and then the 147 products ref[k]*img[k]
 struct alignas(16) EvalLds {
     float buf[(kChunk + 1) * kTexStride];  // slot 0: reference image, slots 1..kChunk: chunk members
