@@ -233,7 +233,10 @@ __device__ __noinline__ void patch_colour(const DevScene& sc, const uint16_t* ro
 
 }  // namespace
 
-__global__ void __launch_bounds__(64, 2) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
+#ifndef HPMVS_WAVES_PER_EU
+#define HPMVS_WAVES_PER_EU 2
+#endif
+__global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
     __shared__ uint16_t lists[kP * kRow];
     __shared__ EvalLds evlds;
     const int lane = lane_id();
@@ -442,7 +445,7 @@ void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b,
     // waves per CU: LDS (optimiser state + lists) and the 32-waves-per-CU limit
     const int lds_per_wave = (int)(sizeof(double) * BQ_ND * kP + sizeof(int) * BQ_NI * kP + sizeof(uint16_t) * kP * kRow + sizeof(EvalLds));
     int per_cu = (160 * 1024) / lds_per_wave;
-    if (per_cu > 16) per_cu = 16;
+    if (per_cu > 4 * HPMVS_WAVES_PER_EU) per_cu = 4 * HPMVS_WAVES_PER_EU;
     const int cap = n_cus * per_cu;
     if (waves > cap) waves = cap;
     hipLaunchKernelGGL(optimize_kernel, dim3(waves), dim3(64), 0, st, sc, o, b, queue_counter);

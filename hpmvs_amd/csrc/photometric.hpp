@@ -339,7 +339,10 @@ __device__ __forceinline__ EvalResult wave_eval(const DevScene& sc, const DevOpt
 //   3. lane m forms the variance sum sequentially; 4. lanes 0..48 normalise in place;
 //   5. lane m forms the 147-term dot product with the reference texture sequentially.
 // Built with -ffp-contract=off, every float operation is the one the CPU executes.
-constexpr int kChunk = 7;            // images per chunk besides the reference texture
+#ifndef HPMVS_CHUNK
+#define HPMVS_CHUNK 7
+#endif
+constexpr int kChunk = HPMVS_CHUNK;  // images per chunk besides the reference texture
 constexpr int kPlane = 52;           // floats per staged channel plane (49 + 3: 16-byte aligned planes)
 constexpr int kTexStride = 164;      // floats per staging slot (16-byte multiple; 164 mod 64 = 36 spreads the per-slot float4 reads over distinct LDS banks): 3 planes of raw texels, later reused for the
                                      // 49 squared deviations and then the 147 products ref[k]*img[k]

@@ -590,6 +590,7 @@ static double static_objective_fn(unsigned n, const double *x, double *grad, voi
 
 typedef int (*ref_bobyqa_fn)(int n, int npt, double *x, const double *lb, const double *ub, const double *dx,
                              double xtol_rel, int maxeval, double *minf, int *nevals, orc_obj_fn f, void *data);
+/* oracle/bobyqa_port.cpp */
 int orc_port_bobyqa(int n, int npt, double *x, const double *lb, const double *ub, const double *dx,
                     double xtol_rel, int maxeval, double *minf, int *nevals, orc_obj_fn f, void *data);
 int orc_port_bobyqa_available(void);

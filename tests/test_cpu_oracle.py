@@ -202,3 +202,19 @@ def test_state_machine_reproduces_golden_optimiser_results():
             assert rc == e["nlopt_result"] and mf.value == e["fmin"] and list(x) == e["x"]
             n += 1
     assert n >= 1
+
+
+def test_oracle_port_optimizer_matches_goldens():
+    """The oracle's fallback optimiser (used when oracle/_ref did not travel) reproduces the goldens that
+    the genuine NLopt library produced: identical decisions, evaluation counts and float results."""
+    from oracle import oracle as orc
+    scene, seeds, exp = golden_scene()
+    osc = orc.OracleScene(scene)
+    P = orc.patches_from_seeds(seeds)
+    assert orc.optimizer_available(orc.OPT_PORT)
+    orc.optimize_batch(osc, P, which=orc.OPT_PORT, n_threads=2)
+    for p, e in zip(P, exp["patches"]):
+        assert (p.stage == 0) == bool(e["ok"]) and p.nevals == e["nevals"] and p.nlopt_result == e["nlopt_result"]
+        if e["ok"]:
+            assert list(p.center) == e["center"] and list(p.normal) == e["normal"] and p.fmin == e["fmin"]
+            assert list(p.images[:p.n_images]) == e["images"] and list(p.x) == e["x"]
