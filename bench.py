@@ -106,7 +106,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("HPMVS_BENCH_FORCE_DIST") == "1"  # the latter: 1-GPU test of the RCCL path
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     views, W, H, n_seeds, start_level = WORKLOADS[args.workload]
@@ -126,7 +127,7 @@ def main():
     opts = api.default_options()
     L = api.lib()
     stream = torch.cuda.current_stream().cuda_stream
-    gathered = torch.empty((world * n_seeds, RECORD_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered = torch.empty((world * n_seeds, RECORD_BYTES), dtype=torch.uint8, device=dev) if use_dist else None
 
     events = []
 
@@ -143,12 +144,12 @@ def main():
             raise RuntimeError(L.hpmvs_last_error().decode())
         if timed:
             events.append((e0, e1))
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, pack_records(work))  # == dd.all_gather_records (equal shards)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -164,7 +165,7 @@ def main():
     last_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     lib_ms = gpu_scene.last_kernel_ms()  # the library's own event pair around the last launch (cross-check)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
@@ -266,7 +267,7 @@ def main():
         }
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

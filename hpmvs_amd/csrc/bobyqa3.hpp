@@ -47,9 +47,11 @@
 // optional region timers (only in -DHPMVS_PROFILE_PHASES device builds; see tools/phase_profile.py)
 #include "prof.h"
 #if defined(HPMVS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+#define BQ_PROF_COUNT(i, n) atomicAdd(&s_prof[(i)], (unsigned long long)(n))
 #define BQ_PROF_BEGIN(v) const long long v = clock64()
 #define BQ_PROF_END(v, i) do { if (__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) { s_prof[2 * (i)] += (unsigned long long)(clock64() - v); s_prof[2 * (i) + 1] += 1ull; } } while (0)
 #else
+#define BQ_PROF_COUNT(i, n) do { } while (0)
 #define BQ_PROF_BEGIN(v) do { } while (0)
 #define BQ_PROF_END(v, i) do { } while (0)
 #endif
@@ -305,6 +307,7 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             if (beta == 0.0) { gredsq = stepsq; itermax = iterc + 3 - nact; }
             if (gredsq * delsq <= qred * 1e-4 * qred) { st = FINISH; continue; }
             hess_mul(B, s, hs);
+            BQ_PROF_COUNT(28, 1);
             resid = delsq; ds = 0.0; shs = 0.0;
             for (int i = 0; i < 3; i++)
                 if (xbdi[i] == 0.0) { resid -= BQA(d, i) * BQA(d, i); ds += s[i] * BQA(d, i); shs += s[i] * hs[i]; }
@@ -414,6 +417,8 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
                 if (xbdi[i] == 0.0) { shs += s[i] * hs[i]; dhs += BQA(d, i) * hs[i]; dhd += BQA(d, i) * hred[i]; }
             redmax = 0.0; isav = 0; redsav = 0.0;
             iu = (int)(angbd * 17. + 3.1);
+            BQ_PROF_COUNT(29, 1);
+            BQ_PROF_COUNT(30, iu);
             for (int i = 1; i <= iu; i++) {
                 angt = angbd * (double)i / (double)iu;
                 sth = (angt + angt) / (1.0 + angt * angt);
@@ -450,6 +455,7 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
         }
         if (st == FINISH) break;
     }
+    BQ_PROF_COUNT(31, 1);
     BQS(dsq) = 0.0;
     for (int i = 0; i < 3; i++) {
         BQA(xnew, i) = mx(mn(BQA(xopt, i) + BQA(d, i), BQA(su, i)), BQA(sl, i));
@@ -943,7 +949,12 @@ BQ_HD int run(Bobyqa3& B, int label) {
         else if (__any(live && label == L60)) pick = L60;
         else if (__any(live && label == L210)) pick = L210;
         else if (__any(live && label == L230)) pick = L230;
-        if (live && label == pick) label = step_label(B, label);
+        if (live && label == pick) {
+            BQ_PROF_BEGIN(tl_);
+            const int was = label;
+            label = step_label(B, label);
+            BQ_PROF_END(tl_, 4 + was);  // per-label timers (profiling builds only)
+        }
     }
 #else
     while (label != LRET_CONT && label != LRET_DONE) label = step_label(B, label);

@@ -221,8 +221,8 @@ int hpmvs_scene_commit(hpmvs_scene* s) {
     HIPCHK(hipMemcpy(s->dcovis_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&s->dcovis, sizeof(int32_t) * flat.size()));
     HIPCHK(hipMemcpy(s->dcovis, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)&s->dqueue, 256));
-    HIPCHK(hipMemset(s->dqueue, 0, 256));
+    HIPCHK(hipMalloc((void**)&s->dqueue, 512));
+    HIPCHK(hipMemset(s->dqueue, 0, 512));
     s->bytes += sizeof(DevView) * (size_t)s->n_views + sizeof(int32_t) * (off.size() + flat.size());
     s->committed = true;
     return HPMVS_OK;
@@ -382,7 +382,7 @@ int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_pat
     const DevOptions d = make_dev_options(o);
     {
         std::lock_guard<std::mutex> lk(s->mu);  // one work-queue counter + one event pair per scene
-        HIPCHK(hipMemsetAsync(s->dqueue, 0, 256, st));
+        HIPCHK(hipMemsetAsync(s->dqueue, 0, 512, st));
         HIPCHK(hipEventRecord(s->ev0, st));
         launch_optimize(dev_scene(s), d, sg.d, s->dqueue, s->n_cus, st);
         HIPCHK(hipGetLastError());
@@ -472,7 +472,7 @@ int hpmvs_debug_counters(const hpmvs_scene* s, unsigned long long* out4) {
     if (!s || !out4) return fail(HPMVS_ERR_ARG, "debug_counters: null argument");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out4, (char*)s->dqueue + 16, 192, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out4, (char*)s->dqueue + 16, 288, hipMemcpyDeviceToHost));
     return HPMVS_OK;
 }
 

@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
         atomicAdd(&dbg[1], (unsigned long long)tB);
         atomicAdd(&dbg[2], (unsigned long long)nrounds);
         atomicAdd(&dbg[3], (unsigned long long)nreq);
-        for (int k = 0; k < 20; k++) atomicAdd(&dbg[4 + k], s_prof[k]);
+        for (int k = 0; k < 32; k++) atomicAdd(&dbg[4 + k], s_prof[k]);
     }
 #endif
 }

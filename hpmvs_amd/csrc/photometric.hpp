@@ -434,7 +434,7 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
     P.ok = 0; P.tlx = P.tly = P.dxx = P.dxy = P.dyx = P.dyy = 0.0f; P.pix = nullptr; P.W = 0;
     if (lane < nimg) P = prep_image(sc.views[(int)list[lane]], o, c, scale, px, py, zax);
     PH_T(t2);
-    PH_ADD(t1, t2, 5);
+    PH_ADD(t1, t2, 13);
 
     const unsigned long long okmask = __ballot(P.ok != 0);
     if (!((okmask >> ref_slot) & 1ull)) {
@@ -491,7 +491,7 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
         }
         wave_lds_sync();
         PH_T(t4);
-        PH_ADD(t3, t4, 6);
+        
         // ---- 2. channel means (Patch2d.hpp:51-58): lane m*3+c adds the 49 texels of plane c of slot m in order
         {
             const int m = lane / 3, ch = lane - 3 * m;
@@ -516,7 +516,7 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
         }
         wave_lds_sync();
         PH_T(t5);
-        PH_ADD(t4, t5, 7);
+        
         // ---- 4. normalise (Patch2d.hpp:75-83) in registers; products with the reference texture
         //         (Patch2d.hpp:41) staged in the reference's element order (pixel*3 + channel)
 #pragma unroll
@@ -536,12 +536,12 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
         }
         wave_lds_sync();
         PH_T(t6);
-        PH_ADD(t5, t6, 8);
+        
         // ---- 5. NCC: lane m adds the 147 products in order (Patch2d.hpp:37-44)
         float raw = 2.0f;
         if (lane >= 1 && lane <= nm) raw = 1.0f - seq_sum<147>(&L.buf[lane * kTexStride]) / 147.0f;
         PH_T(t7);
-        PH_ADD(t6, t7, 9);
+        
         // ---- deliver in ascending image order
         for (int s = 1; s <= nm; s++) {
             const int v = bcast_i(member, s);

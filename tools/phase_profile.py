@@ -11,14 +11,15 @@ b=api.Batch.from_seeds(seeds)
 api.optimize_batch(g,b)
 b=api.Batch.from_seeds(seeds)
 api.optimize_batch(g,b)
-out=(C.c_ulonglong*40)()
+out=(C.c_ulonglong*36)()
 L.hpmvs_debug_counters.argtypes=[C.c_void_p,C.POINTER(C.c_ulonglong)]
 L.hpmvs_debug_counters(g.h,out)
 tA,tB,nr,nq=[int(v) for v in out[:4]]
-names=['trsbox','altmov','update','bq_step','B:axes','B:prep','B:fetch+stage','B:mean+var','B:normalise','B:dot']
+names=['trsbox','altmov','update','bq_step','L20','L60(trsbox+)','L90(shift)','L210(altmov+)','L230(vlag,beta)','L360','L650','L680','L720','-']
 for i,nm in enumerate(names):
     tot,cnt=int(out[4+2*i]),int(out[5+2*i])
     print(nm,'lane-calls',cnt,'avg cycles per call %.0f'%(tot/max(cnt,1)))
+print('trsbox per-lane: calls',int(out[4+31]),'CG iters/call %.2f'%(int(out[4+28])/max(int(out[4+31]),1)),'ALT iters/call %.2f'%(int(out[4+29])/max(int(out[4+31]),1)),'angle steps per ALT iter %.1f'%(int(out[4+30])/max(int(out[4+29]),1)))
 print('kernel ms',g.last_kernel_ms(),'phaseA cycles',tA,'phaseB cycles',tB,'rounds',nr,'requests',nq)
 print('A share %.2f  cycles/round A %.0f  B per request %.0f  req/round %.2f'%(tA/(tA+tB), tA/nr, tB/max(nq,1), nq/nr))
 print('evals mean', b.nevals[b.nevals>0].mean(), 'ok', b.ok.mean(), 'nevals hist', np.percentile(b.nevals,[50,90,99,100]))
