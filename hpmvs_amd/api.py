@@ -49,7 +49,7 @@ EXPORTS = [
     "hpmvs_last_error", "hpmvs_device_count", "hpmvs_default_options", "hpmvs_camera_from_nvm",
     "hpmvs_scene_create", "hpmvs_scene_set_view", "hpmvs_scene_set_covis", "hpmvs_scene_commit",
     "hpmvs_scene_destroy", "hpmvs_scene_get_level", "hpmvs_scene_bytes", "hpmvs_build_pyramid",
-    "hpmvs_optimize_batch", "hpmvs_objective_batch", "hpmvs_inccs_batch", "hpmvs_last_kernel_ms",
+    "hpmvs_optimize_batch", "hpmvs_init_patches_batch", "hpmvs_objective_batch", "hpmvs_inccs_batch", "hpmvs_last_kernel_ms",
 ]
 
 _lib = None
@@ -78,6 +78,8 @@ def lib():
     L.hpmvs_scene_bytes.argtypes = [C.c_void_p]
     L.hpmvs_build_pyramid.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.hpmvs_optimize_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(PatchBatch), C.c_int, C.c_void_p]
+    L.hpmvs_init_patches_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.POINTER(PatchBatch), C.c_int, C.c_void_p]
     L.hpmvs_objective_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(PatchBatch), C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.hpmvs_inccs_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(PatchBatch), C.c_int, C.c_int,
@@ -214,6 +216,23 @@ def optimize_batch(scene: Scene, batch: Batch, options: Options | None = None) -
     o = options or default_options()
     b = batch.c_struct()
     _chk(lib().hpmvs_optimize_batch(scene.h, C.byref(o), C.byref(b), 0, None))
+    return batch
+
+
+def init_patches_batch(scene: Scene, xyz, meas_off, meas_img, start_level=4, max_images=32,
+                       options: Options | None = None) -> Batch:
+    """Scene::initPatches seed loop on the GPU (reference Scene.cpp:112-178): seeds built on device, refined,
+    drift-gated.  Returns the batch (seed patches, refined where ok)."""
+    o = options or default_options()
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    off = np.ascontiguousarray(meas_off, dtype=np.int32)
+    img = np.ascontiguousarray(meas_img, dtype=np.int32)
+    n = len(xyz)
+    batch = Batch(np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32), np.zeros(n, np.float32),
+                  np.zeros(n, np.int32), np.full((n, max_images), -1, np.int32))
+    b = batch.c_struct()
+    _chk(lib().hpmvs_init_patches_batch(scene.h, C.byref(o), start_level, n, xyz.ctypes.data, off.ctypes.data,
+                                        img.ctypes.data if len(img) else None, C.byref(b), 0, None))
     return batch
 
 

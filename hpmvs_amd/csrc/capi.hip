@@ -316,17 +316,23 @@ int stage_out(T* host, const T* dev, size_t count) {
     return HPMVS_OK;
 }
 
-int check_batch(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_patch_batch* b) {
+int check_batch_shape(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_patch_batch* b) {
     if (!s || !o || !b) return fail(HPMVS_ERR_ARG, "null scene/options/batch");
     if (!s->committed) return fail(HPMVS_ERR_STATE, "scene not committed");
     if (b->n < 0 || b->max_images < 1 || b->max_images > HPMVS_MAX_IMAGES) return fail(HPMVS_ERR_ARG, "bad n/max_images");
-    if (b->n > 0 && (!b->center || !b->normal || !b->scale || !b->n_images || !b->images))
-        return fail(HPMVS_ERR_ARG, "batch input arrays missing");
     if (o->MAXLEVEL < 1 || o->MAXLEVEL >= HPMVS_MAX_LEVELS) return fail(HPMVS_ERR_ARG, "MAXLEVEL out of range");
     return HPMVS_OK;
 }
 
-int stage_batch(Staged& st, const hpmvs_patch_batch* b, bool on_device, bool outputs) {
+int check_batch(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_patch_batch* b) {
+    const int rc = check_batch_shape(s, o, b);
+    if (rc) return rc;
+    if (b->n > 0 && (!b->center || !b->normal || !b->scale || !b->n_images || !b->images))
+        return fail(HPMVS_ERR_ARG, "batch input arrays missing");
+    return HPMVS_OK;
+}
+
+int stage_batch(Staged& st, const hpmvs_patch_batch* b, bool on_device, bool outputs, bool copy_inputs = true) {
     DevBatch& d = st.d;
     memset(&d, 0, sizeof(d));
     d.n = b->n; d.max_images = b->max_images;
@@ -339,11 +345,11 @@ int stage_batch(Staged& st, const hpmvs_patch_batch* b, bool on_device, bool out
     }
     st.staged = true;
     int rc;
-    if ((rc = stage_in(st, d.center, b->center, 4 * n, true))) return rc;
-    if ((rc = stage_in(st, d.normal, b->normal, 4 * n, true))) return rc;
-    if ((rc = stage_in(st, d.scale, b->scale, n, true))) return rc;
-    if ((rc = stage_in(st, d.n_images, b->n_images, n, true))) return rc;
-    if ((rc = stage_in(st, d.images, b->images, n * b->max_images, true))) return rc;
+    if ((rc = stage_in(st, d.center, b->center, 4 * n, copy_inputs))) return rc;
+    if ((rc = stage_in(st, d.normal, b->normal, 4 * n, copy_inputs))) return rc;
+    if ((rc = stage_in(st, d.scale, b->scale, n, copy_inputs))) return rc;
+    if ((rc = stage_in(st, d.n_images, b->n_images, n, copy_inputs))) return rc;
+    if ((rc = stage_in(st, d.images, b->images, n * b->max_images, copy_inputs))) return rc;
     if (outputs) {
         if ((rc = stage_in(st, d.ok, b->ok, n, false))) return rc;
         if ((rc = stage_in(st, d.color, b->color, 3 * n, false))) return rc;
@@ -355,6 +361,23 @@ int stage_batch(Staged& st, const hpmvs_patch_batch* b, bool on_device, bool out
         if ((rc = stage_in(st, d.stage, b->stage, n, false))) return rc;
         if ((rc = stage_in(st, d.ngrabs, b->ngrabs, n, false))) return rc;
     }
+    return HPMVS_OK;
+}
+
+int copy_outputs(hpmvs_patch_batch* b, const DevBatch& D) {
+    const size_t n = (size_t)b->n;
+    int rc;
+    if ((rc = stage_out(b->n_images, D.n_images, n))) return rc;
+    if ((rc = stage_out(b->images, D.images, n * b->max_images))) return rc;
+    if ((rc = stage_out(b->ok, D.ok, n))) return rc;
+    if ((rc = stage_out(b->color, D.color, 3 * n))) return rc;
+    if ((rc = stage_out(b->ncc, D.ncc, n))) return rc;
+    if ((rc = stage_out(b->fmin, D.fmin, n))) return rc;
+    if ((rc = stage_out(b->x, D.x, 3 * n))) return rc;
+    if ((rc = stage_out(b->result, D.result, n))) return rc;
+    if ((rc = stage_out(b->nevals, D.nevals, n))) return rc;
+    if ((rc = stage_out(b->stage, D.stage, n))) return rc;
+    if ((rc = stage_out(b->ngrabs, D.ngrabs, n))) return rc;
     return HPMVS_OK;
 }
 
@@ -406,6 +429,58 @@ int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_pat
         if ((rc = stage_out(b->nevals, D.nevals, n))) return rc;
         if ((rc = stage_out(b->stage, D.stage, n))) return rc;
         if ((rc = stage_out(b->ngrabs, D.ngrabs, n))) return rc;
+    }
+    return HPMVS_OK;
+}
+
+int hpmvs_init_patches_batch(const hpmvs_scene* s, const hpmvs_options* o, int start_level, int n_points,
+                             const double* xyz, const int32_t* meas_off, const int32_t* meas_img, hpmvs_patch_batch* b,
+                             int on_device, void* stream) {
+    int rc = check_batch_shape(s, o, b);
+    if (rc) return rc;
+    if (b->n != n_points) return fail(HPMVS_ERR_ARG, "init_patches_batch: b->n must equal n_points");
+    if (n_points > 0 && (!xyz || !meas_off || !meas_img || !b->center || !b->normal || !b->scale || !b->n_images ||
+                         !b->images || !b->ok))
+        return fail(HPMVS_ERR_ARG, "init_patches_batch: missing array");
+    if (start_level < 0 || start_level > o->MAXLEVEL) return fail(HPMVS_ERR_ARG, "init_patches_batch: bad start_level");
+    if (n_points == 0) return HPMVS_OK;
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    Staged sg;
+    rc = stage_batch(sg, b, on_device != 0, true, /*copy_inputs=*/false);
+    if (rc) return rc;
+    const double* dxyz = xyz;
+    const int32_t *doff = meas_off, *dimg = meas_img;
+    const size_t n = (size_t)n_points;
+    if (!on_device) {
+        double* tx = nullptr; int32_t *to = nullptr, *ti = nullptr;
+        const size_t nm = (size_t)meas_off[n_points];
+        if ((rc = stage_in(sg, tx, xyz, 3 * n, true))) return rc;
+        if ((rc = stage_in(sg, to, meas_off, n + 1, true))) return rc;
+        if ((rc = stage_in(sg, ti, meas_img, nm ? nm : 1, nm != 0))) return rc;
+        dxyz = tx; doff = to; dimg = ti;
+    }
+    const DevOptions d = make_dev_options(o);
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        launch_seed_init(dev_scene(s), d, start_level, n_points, dxyz, doff, dimg, sg.d, st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemsetAsync(s->dqueue, 0, 512, st));
+        HIPCHK(hipEventRecord(s->ev0, st));
+        launch_optimize(dev_scene(s), d, sg.d, s->dqueue, s->n_cus, st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(s->ev1, st));
+        s->timed = true;
+        launch_drift_gate(n_points, dxyz, sg.d, st);
+        HIPCHK(hipGetLastError());
+        if (!on_device) HIPCHK(hipStreamSynchronize(st));
+    }
+    if (!on_device) {
+        const DevBatch& D = sg.d;
+        if ((rc = stage_out(b->center, D.center, 4 * n))) return rc;
+        if ((rc = stage_out(b->normal, D.normal, 4 * n))) return rc;
+        if ((rc = stage_out(b->scale, D.scale, n))) return rc;
+        if ((rc = copy_outputs(b, D))) return rc;
     }
     return HPMVS_OK;
 }

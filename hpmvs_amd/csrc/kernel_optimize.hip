@@ -280,6 +280,7 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
                 nimg = b.n_images[idx];
                 ngrabs = 0; nl_result = 0; BQN(nevals) = 0; BQS(minf) = 0.0;
                 BQA(xfinal, 0) = 0.0; BQA(xfinal, 1) = 0.0; BQA(xfinal, 2) = 0.0;
+                if (nimg < 0) { fail_stage = -nimg; nimg = 0; finish_fail = true; break; }  // rejected by seed_init_kernel
                 if (nimg > kMaxImages || nimg > b.max_images) { fail_stage = 100; finish_fail = true; break; }
                 for (int k = 0; k < nimg; k++) row[k] = (uint16_t)b.images[(size_t)idx * b.max_images + k];
                 nimg = add_images(sc, o, row, nimg, c, n, scale);

@@ -126,4 +126,85 @@ void launch_inccs(const DevScene& sc, const DevOptions& o, const DevBatch& b, in
     hipLaunchKernelGGL(inccs_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, st, sc, o, b, ref_idx, robust, out);
 }
 
+// ------------------------------------------------------------------------------------------
+// Seed construction of Scene::initPatches (reference src/hpmvs/Scene.cpp:118-163), one thread per
+// NVM point.  Seeds that the reference skips before optimize() get n_images = -reason; the
+// refinement kernel drops them immediately with stage = reason.
+__global__ void __launch_bounds__(256) seed_init_kernel(DevScene sc, DevOptions o, int start_level, int n,
+                                                        const double* __restrict__ xyz,
+                                                        const int32_t* __restrict__ meas_off,
+                                                        const int32_t* __restrict__ meas_img, DevBatch b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float c[3] = {(float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2]};
+    int32_t* row = b.images + (size_t)i * b.max_images;
+    int nimg = 0, why = 0;
+    const int m0 = meas_off[i], m1 = meas_off[i + 1];
+    if (m1 - m0 < o.MIN_IMAGES_PER_PATCH) why = 10;
+    else {
+        const float s = __int_as_float((127 - start_level) << 23);
+        const int margin = 2;  // cSize, Scene.cpp:91,143
+        for (int m = m0; m < m1; m++) {
+            const int idx = meas_img[m];
+            if (idx < 0 || idx >= sc.n_views) continue;
+            const DevView& V = sc.views[idx];
+            float P[12];
+            for (int k = 0; k < 12; k++) P[k] = V.P0[k];
+            float u, v;
+            project0(P, c[0], c[1], c[2], u, v);
+            u *= s; v *= s;
+            if (u < (float)margin || v < (float)margin || u >= (float)(V.w[start_level] - margin) ||
+                v >= (float)(V.h[start_level] - margin))
+                continue;
+            if (nimg < b.max_images) row[nimg] = idx;
+            nimg++;
+        }
+        if (nimg < 2) why = 11;
+        else if (nimg > b.max_images) why = 100;
+    }
+    float nrm[3] = {0.0f, 0.0f, 0.0f};
+    float scale = 0.0f;
+    if (!why) {
+        const DevView& V0 = sc.views[row[0]];
+        const float d[3] = {V0.center[0] - c[0], V0.center[1] - c[1], V0.center[2] - c[2]};
+        normalized3f(d, nrm);  // Vector4f::normalize() with w = 1 - 1 = 0
+        const float e[3] = {c[0] - V0.center[0], c[1] - V0.center[1], c[2] - V0.center[2]};
+        const float fz = sqrtf(dot3f(e, e));
+        scale = (V0.fsum == 0.0f) ? 1.0f
+                                  : (float)(2.0 * (double)fz * (double)(1 << start_level) / (double)V0.fsum);  // getScale
+    }
+    b.center[4 * i] = c[0]; b.center[4 * i + 1] = c[1]; b.center[4 * i + 2] = c[2]; b.center[4 * i + 3] = 1.0f;
+    b.normal[4 * i] = nrm[0]; b.normal[4 * i + 1] = nrm[1]; b.normal[4 * i + 2] = nrm[2]; b.normal[4 * i + 3] = 0.0f;
+    b.scale[i] = scale;
+    b.n_images[i] = why ? -why : nimg;  // negative: rejected before optimize(); the refinement kernel reports -n as stage
+    b.ok[i] = 0;
+}
+
+void launch_seed_init(const DevScene& sc, const DevOptions& o, int start_level, int n, const double* xyz,
+                      const int32_t* meas_off, const int32_t* meas_img, const DevBatch& b, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(seed_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sc, o, start_level, n, xyz, meas_off,
+                       meas_img, b);
+}
+
+// |centre - xyz| > 2 * scale -> drop (Scene.cpp:171)
+__global__ void __launch_bounds__(256) drift_gate_kernel(int n, const double* __restrict__ xyz, DevBatch b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (b.ok[i]) {
+        const float d[3] = {b.center[4 * i] - (float)xyz[3 * i], b.center[4 * i + 1] - (float)xyz[3 * i + 1],
+                            b.center[4 * i + 2] - (float)xyz[3 * i + 2]};
+        if (sqrtf(dot3f(d, d)) > b.scale[i] * 2) {
+            b.ok[i] = 0;
+            if (b.stage) b.stage[i] = 12;
+        }
+    }
+    if (b.n_images[i] < 0) b.n_images[i] = 0;
+}
+
+void launch_drift_gate(int n, const double* xyz, const DevBatch& b, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(drift_gate_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, xyz, b);
+}
+
 }  // namespace hpmvs

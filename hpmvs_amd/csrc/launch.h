@@ -11,6 +11,9 @@ void launch_objective(const DevScene& sc, const DevOptions& o, const DevBatch& b
                       int32_t* ngrabs_out, hipStream_t st);
 void launch_inccs(const DevScene& sc, const DevOptions& o, const DevBatch& b, int ref_idx, int robust, float* out,
                   hipStream_t st);
+void launch_seed_init(const DevScene& sc, const DevOptions& o, int start_level, int n, const double* xyz,
+                      const int32_t* meas_off, const int32_t* meas_img, const DevBatch& b, hipStream_t st);
+void launch_drift_gate(int n, const double* xyz, const DevBatch& b, hipStream_t st);
 // workspace: one int32 work-queue counter (zeroed by the launcher on `st`)
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* queue_counter,
                      int n_cus, hipStream_t st);

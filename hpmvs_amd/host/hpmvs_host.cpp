@@ -173,6 +173,50 @@ bool Scene::extractCoVisiblilty(const NVM_Model& model, const HpmvsOptions&) {
     return true;
 }
 
+bool Scene::initPatches(const NVM_Model& model, const HpmvsOptions& options, std::vector<Ppatch3d>& out) const {
+    hpmvs_scene* dev = deviceScene();
+    if (!dev) return false;
+    const size_t n = model.points.size();
+    if (n == 0) return true;
+    std::vector<double> xyz(3 * n);
+    std::vector<int32_t> off(n + 1, 0), img;
+    for (size_t i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) xyz[3 * i + k] = model.points[i].xyz[k];
+        for (const NVM_Measurement& m : model.points[i].measurements) img.push_back(m.imgIndex);
+        off[i + 1] = (int32_t)img.size();
+    }
+    const int stride = HPMVS_MAX_IMAGES;
+    std::vector<float> center(4 * n), normal(4 * n), scale(n), color(3 * n), ncc(n);
+    std::vector<int32_t> nimg(n), images(n * stride, -1);
+    std::vector<uint8_t> ok(n);
+    hpmvs_options o;
+    o.MAXLEVEL = options.MAXLEVEL; o.MINLEVEL = options.MINLEVEL; o.MAX_ANGLE = options.MAX_ANGLE;
+    o.MIN_ANGLE = options.MIN_ANGLE; o.MAX_IMAGES_PER_PATCH = options.MAX_IMAGES_PER_PATCH;
+    o.MIN_IMAGES_PER_PATCH = options.MIN_IMAGES_PER_PATCH; o.NCC_ALPHA_1 = options.NCC_ALPHA_1;
+    o.NCC_ALPHA_2 = options.NCC_ALPHA_2;
+    hpmvs_patch_batch b;
+    memset(&b, 0, sizeof(b));
+    b.n = (int32_t)n; b.max_images = stride;
+    b.center = center.data(); b.normal = normal.data(); b.scale = scale.data(); b.n_images = nimg.data();
+    b.images = images.data(); b.ok = ok.data(); b.color = color.data(); b.ncc = ncc.data();
+    if (hpmvs_init_patches_batch(dev, &o, options.START_LEVEL, (int)n, xyz.data(), off.data(),
+                                 img.empty() ? nullptr : img.data(), &b, 0, nullptr) != HPMVS_OK) {
+        std::cerr << "initPatches: " << hpmvs_last_error() << std::endl;
+        return false;
+    }
+    for (size_t i = 0; i < n; i++) {
+        if (!ok[i]) continue;
+        Ppatch3d p(new Patch3d);
+        for (int k = 0; k < 4; k++) { p->center_[k] = center[4 * i + k]; p->normal_[k] = normal[4 * i + k]; }
+        p->scale_3dx_ = scale[i];
+        p->images_.assign(images.begin() + i * stride, images.begin() + i * stride + nimg[i]);
+        p->ncc_ = ncc[i];
+        p->color_ = Eigen::Vector3f(color[3 * i], color[3 * i + 1], color[3 * i + 2]);
+        out.push_back(p);
+    }
+    return true;
+}
+
 hpmvs_scene* Scene::deviceScene() const {
     std::lock_guard<std::mutex> lk(mu_);
     if (dev_) return dev_;

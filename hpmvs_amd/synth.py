@@ -291,3 +291,38 @@ def make_seeds(scene: SynthScene, n: int, start_level: int = 4, max_images: int 
     scale = (2.0 * fz.astype(np.float64) * (1 << start_level) / (2.0 * F[first].astype(np.float32))).astype(np.float32)
     return Seeds(center=c32, normal=nvec.astype(np.float32), scale=scale, n_images=n_images,
                  images=images, truth=P)
+
+
+def make_nvm_points(scene: SynthScene, n: int, start_level: int = 4, extent: float = 8.0, seed: int = SEED,
+                    noise: float = 0.3):
+    """NVM-style sparse points (reference NVM_Point: xyz + measurements[].imgIndex,
+    include/hpmvs/NVMReader.h:38-42): surface points displaced by `noise` * (one START_LEVEL sample
+    step) along the viewing ray, each measured in every camera that sees it (ascending index,
+    within 60 deg of the surface normal).  Returns (xyz[n,3] float64, meas_off[n+1], meas_img)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 3))
+    x = (_halton_vec(n, 2) * 2 - 1) * extent
+    y = (_halton_vec(n, 3) * 2 - 1) * extent
+    P = np.stack([x, y, height(x, y)], axis=1)
+    gx, gy = height_grad(x, y)
+    nrm = np.stack([-gx, -gy, np.ones_like(gx)], axis=1)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    C = np.stack([v.c for v in scene.views])
+    Rm = np.stack([_R_from_quat(v.q) for v in scene.views])
+    vis = np.zeros((n, scene.n_views), dtype=bool)
+    for vi, v in enumerate(scene.views):
+        d = P - C[vi]
+        pc = d @ Rm[vi].T
+        u = v.f * pc[:, 0] / pc[:, 2] + v.width / 2.0
+        w = v.f * pc[:, 1] / pc[:, 2] + v.height / 2.0
+        ray = -d / np.linalg.norm(d, axis=1, keepdims=True)
+        vis[:, vi] = (pc[:, 2] > 0) & (u >= 0) & (w >= 0) & (u < v.width) & (w < v.height) & \
+                     ((ray * nrm).sum(axis=1) > math.cos(math.radians(60.0)))
+    first = np.argmax(vis, axis=1)
+    to_cam = C[first] - P
+    dist = np.linalg.norm(to_cam, axis=1)
+    step = 2.0 * dist * (1 << start_level) / (2.0 * np.array([scene.views[i].f for i in first]))
+    xyz = P + (to_cam / dist[:, None]) * (rng.uniform(-1, 1, size=n) * noise * step)[:, None]
+    counts = vis.sum(axis=1)
+    meas_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    meas_img = np.nonzero(vis)[1].astype(np.int32)
+    return xyz, meas_off, meas_img

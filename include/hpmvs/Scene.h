@@ -26,6 +26,10 @@ public:
     bool addCameras(const NVM_Model& model, const HpmvsOptions& options);
     // Scene::extractCoVisiblilty (src/hpmvs/Scene.cpp:241-298), including its positional-index quirk
     bool extractCoVisiblilty(const NVM_Model& model, const HpmvsOptions& options);
+    // The seed loop of Scene::initPatches (src/hpmvs/Scene.cpp:112-178) as ONE batched GPU call: seed
+    // construction, optimize(), drift gate.  Survivors are appended to `out` in point order; inserting
+    // them into the octree / depth maps (Scene.cpp:183-199) stays with the host application.
+    bool initPatches(const NVM_Model& model, const HpmvsOptions& options, std::vector<Ppatch3d>& out) const;
     std::map<std::string, int> dict_;
     std::vector<Camera> cameras_;
     std::vector<Image> images_;

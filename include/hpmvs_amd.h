@@ -129,6 +129,20 @@ int hpmvs_build_pyramid(int device, const uint8_t *src, int w, int h, uint8_t *d
 int hpmvs_optimize_batch(const hpmvs_scene *s, const hpmvs_options *o, hpmvs_patch_batch *b,
                          int on_device, void *stream);
 
+/* The seed-initialisation loop of Scene::initPatches (reference src/hpmvs/Scene.cpp:112-178) as one
+ * call: for every NVM point build the seed patch on the GPU (centre = xyz, attached images = the
+ * point's measurements that project inside the START_LEVEL image with a 2 px margin, normal towards the
+ * first attached camera, scale = getScale(centre, START_LEVEL)), run optimize() on the whole batch,
+ * and apply the post-gate |centre - xyz| <= 2 * scale (Scene.cpp:171).
+ *   xyz[n][3] (float64), meas_off[n+1], meas_img[meas_off[n]] : NVM_Point::xyz / measurements[].imgIndex
+ * `b` receives the seed patches (refined where ok[i] = 1).  stage[i] additionally uses
+ *   10 = fewer than MIN_IMAGES_PER_PATCH measurements (Scene.cpp:127), 11 = fewer than 2 visible images
+ *   (Scene.cpp:153), 12 = failed the drift gate (Scene.cpp:171).
+ * Host or device pointers as for hpmvs_optimize_batch. */
+int hpmvs_init_patches_batch(const hpmvs_scene *s, const hpmvs_options *o, int start_level, int n_points,
+                             const double *xyz, const int32_t *meas_off, const int32_t *meas_img,
+                             hpmvs_patch_batch *b, int on_device, void *stream);
+
 /* objective_fn at optimiser variables x[n][3] for each patch's current image list, with
  * refCenter_/refRay_/axes taken from the patch as optimizePatch does.  f_out[n]. */
 int hpmvs_objective_batch(const hpmvs_scene *s, const hpmvs_options *o, const hpmvs_patch_batch *b,

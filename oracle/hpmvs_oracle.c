@@ -753,6 +753,46 @@ void orc_optimize_batch(const orc_scene *s, const orc_options *o, orc_patch *p, 
     for (int i = 0; i < n; i++) orc_optimize(s, o, &p[i], which);
 }
 
+/* Scene::initPatches, src/hpmvs/Scene.cpp:112-178 */
+void orc_init_patches(const orc_scene *s, const orc_options *o, int start_level, int n, const double *xyz,
+                      const int *meas_off, const int *meas_img, orc_patch *pp, int which, int n_threads) {
+#pragma omp parallel for schedule(dynamic, 64) num_threads(n_threads > 0 ? n_threads : 1)
+    for (int ii = 0; ii < n; ii++) {
+        orc_patch *p = &pp[ii];
+        memset(p, 0, sizeof(*p));
+        p->center[0] = (float)xyz[3 * ii]; p->center[1] = (float)xyz[3 * ii + 1]; p->center[2] = (float)xyz[3 * ii + 2];
+        p->center[3] = 1.0f;
+        const int m0 = meas_off[ii], m1 = meas_off[ii + 1];
+        if (m1 - m0 < o->MIN_IMAGES_PER_PATCH) { p->stage = 10; continue; }
+        const int margin = 2; /* cSize */
+        int nimg = 0;
+        for (int m = m0; m < m1; m++) {
+            const int idx = meas_img[m];
+            if (idx < 0) continue;
+            float pr[3];
+            cam_project(&s->cams[idx], p->center, start_level, pr);
+            if (pr[0] < margin || pr[1] < margin || pr[0] >= s->imgs[idx].w[start_level] - margin ||
+                pr[1] >= s->imgs[idx].h[start_level] - margin)
+                continue;
+            if (nimg < ORC_MAX_IMAGES) p->images[nimg] = idx;
+            nimg++;
+        }
+        if (nimg < 2) { p->stage = 11; continue; }
+        if (nimg > ORC_MAX_IMAGES) { p->stage = 100; continue; }
+        p->n_images = nimg;
+        const orc_camera *c0 = &s->cams[p->images[0]];
+        float d[4];
+        sub4(c0->center, p->center, d);
+        normalized4(d, p->normal); /* ppatch->normal_.normalize() */
+        p->normal[3] = 0.0f;
+        p->scale = cam_get_scale(c0, p->center, start_level);
+        const float before[3] = {p->center[0], p->center[1], p->center[2]};
+        if (!orc_optimize(s, o, p, which)) continue;
+        const float dd[3] = {p->center[0] - before[0], p->center[1] - before[1], p->center[2] - before[2]};
+        if (sqrtf(dot3(dd, dd)) > p->scale * 2) { p->stage = 12; }
+    }
+}
+
 double orc_objective_at(const orc_scene *s, const orc_options *o, const orc_patch *p, const double x[3]) {
     popt po;
     popt_begin(&po, s, o, p);

@@ -13,8 +13,8 @@
  * unpinned" for that part, anchored only by analytic known-answer tests.  The
  * optimiser part is pinned: it runs the reference's genuine vendored NLopt
  * 2.4.2 BOBYQA, compiled in place from /root/reference into oracle/_ref/
- * (see oracle/Makefile), and the own C port (oracle/bobyqa_port.c) is checked
- * against it evaluation by evaluation.
+ * (see oracle/Makefile); the fallback (oracle/bobyqa_port.cpp) is checked against
+ * it evaluation by evaluation.
  *
  * Every function cites the reference file:line it follows (paths relative to
  * the reference root).
@@ -111,6 +111,12 @@ int orc_optimizer_available(int which);
 int orc_optimize(const orc_scene *s, const orc_options *o, orc_patch *p, int which_optimizer);
 void orc_optimize_batch(const orc_scene *s, const orc_options *o, orc_patch *p, int n,
                         int which_optimizer, int n_threads);
+
+/* Scene::initPatches seed loop, src/hpmvs/Scene.cpp:112-178 (without the octree insertion): builds the
+ * seed patch of every NVM point, optimizes it and applies the drift gate.  p[i].stage: 0 ok, 1-9 optimize
+ * stage, 10 too few measurements, 11 fewer than 2 visible images, 12 drift gate. */
+void orc_init_patches(const orc_scene *s, const orc_options *o, int start_level, int n, const double *xyz,
+                      const int *meas_off, const int *meas_img, orc_patch *p, int which_optimizer, int n_threads);
 
 /* objective_fn at given optimiser variables x (PatchOptimizer.cpp:286-320) for the patch's
  * current image list; the seed centre/normal define refCenter_/refRay_/axes as optimizePatch does. */

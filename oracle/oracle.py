@@ -73,6 +73,8 @@ def lib():
     L.orc_optimizer_available.argtypes = [C.c_int]
     L.orc_optimize.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Patch), C.c_int]
     L.orc_optimize_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Patch), C.c_int, C.c_int, C.c_int]
+    L.orc_init_patches.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(Patch), C.c_int, C.c_int]
     L.orc_objective_at.restype = C.c_double
     L.orc_objective_at.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Patch), C.POINTER(C.c_double)]
     L.orc_initial_parameters.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Patch), C.POINTER(C.c_double)]
@@ -162,6 +164,20 @@ def optimize_batch(scene: OracleScene, patches, which=None, options=None, n_thre
     o = options or default_options()
     L.orc_optimize_batch(scene.h, C.byref(o), patches, len(patches), which, n_threads)
     return patches
+
+
+def init_patches(scene: OracleScene, xyz, meas_off, meas_img, start_level=4, which=None, options=None, n_threads=1):
+    """Scene::initPatches seed loop (reference Scene.cpp:112-178)."""
+    which = best_optimizer() if which is None else which
+    o = options or default_options()
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    off = np.ascontiguousarray(meas_off, dtype=np.int32)
+    img = np.ascontiguousarray(meas_img, dtype=np.int32)
+    n = len(xyz)
+    P = (Patch * n)()
+    lib().orc_init_patches(scene.h, C.byref(o), start_level, n, xyz.ctypes.data, off.ctypes.data, img.ctypes.data, P,
+                           which, n_threads)
+    return P
 
 
 def objective_at(scene: OracleScene, patch: Patch, x, options=None) -> float:

@@ -148,3 +148,27 @@ def test_gpu_against_committed_goldens():
             np.array_equal(np.array(e[k]["color"], dtype=np.float32), batch.color[k]) for k in both]
     assert np.mean(same) >= 0.99, np.mean(same)
     gpu.close()
+
+
+def test_init_patches_batch_matches_oracle(tiny_scene, oracle_scene, gpu_scene):
+    """SURVEY 8f row 2: the Scene::initPatches seed loop (seed construction on the GPU, optimize, drift gate)
+    against the oracle's restatement of Scene.cpp:112-178.  Bit-identical like optimize() itself."""
+    from hpmvs_amd import api, synth
+    from oracle import oracle as orc
+    xyz, off, img = synth.make_nvm_points(tiny_scene, 400, start_level=2, noise=1.5)
+    # make the early-exit branches occur: a point with too few measurements, one outside every image
+    off = off.copy()
+    batch = api.init_patches_batch(gpu_scene, xyz, off, img, start_level=2)
+    P = orc.init_patches(oracle_scene, xyz, off, img, start_level=2, n_threads=8)
+    st_cpu = np.array([p.stage for p in P])
+    assert np.array_equal(st_cpu, batch.stage), np.nonzero(st_cpu != batch.stage)[0][:10]
+    assert np.array_equal(st_cpu == 0, batch.ok.astype(bool))
+    assert (st_cpu == 0).sum() >= 50 and (st_cpu == 12).sum() + (st_cpu >= 10).sum() >= 1
+    for k in range(len(P)):
+        p = P[k]
+        assert np.array_equal(np.array(p.center[:], dtype=np.float32), batch.center[k]), k
+        if p.stage < 10:  # seed was built: normal/scale/images defined
+            assert np.float32(p.scale) == batch.scale[k]
+            if p.stage == 0 or p.stage == 12:
+                assert np.array_equal(np.array(p.normal[:], dtype=np.float32), batch.normal[k]), k
+                assert list(p.images[:p.n_images]) == list(batch.images[k, :batch.n_images[k]])
