@@ -167,6 +167,24 @@ struct Bobyqa3 { double dd[BQ_ND]; int ii[BQ_NI]; };
 
 namespace bq {
 
+// trsbox's 2-D boundary search evaluates the model at angt = angbd * i / iu, i = 1..iu (bobyqa.c:1590-1606).
+// Unless a bound restricts the rotation, angbd is exactly 1.0 and iu = (int)(17 + 3.1) = 20, so the
+// values angt_i = fl(i / 20) and sth_i = fl(fl(angt + angt) / fl(1 + fl(angt * angt))) are the same 20
+// numbers every time.  They are tabulated at compile time with the SAME IEEE operations the loop would
+// execute (constant evaluation is correctly rounded, no contraction), which removes 40 float64
+// divisions per boundary iteration without changing a single bit of the result.
+struct AngleTable {
+    double angt[20], sth[20];
+    constexpr AngleTable() : angt(), sth() {
+        for (int i = 1; i <= 20; i++) {
+            const double a = 1.0 * (double)i / (double)20;
+            angt[i - 1] = a;
+            sth[i - 1] = (a + a) / (1.0 + a * a);
+        }
+    }
+};
+static constexpr AngleTable kAngleTable{};
+
 BQ_HD double mn(double a, double b) { return a <= b ? a : b; }
 BQ_HD double mx(double a, double b) { return a >= b ? a : b; }
 BQ_HD bool is_inf(double v) { return fabs(v) >= HUGE_VAL * 0.99; }
@@ -268,49 +286,75 @@ BQ_HD void hess_mul(const Bobyqa3& B, const double* s, double* hs) {
     }
 }
 
+// same product with the model held in registers by the caller
+BQ_HD void hess_mul_local(const double* hq, const double* pq, const double* xpt, const double* s, double* hs) {
+    int ih = 0;
+    for (int j = 1; j <= 3; j++) {
+        hs[j - 1] = 0.0;
+        for (int i = 1; i <= j; i++) {
+            ++ih;
+            if (i < j) hs[j - 1] += hq[ih - 1] * s[i - 1];
+            hs[i - 1] += hq[ih - 1] * s[j - 1];
+        }
+    }
+    for (int k = 1; k <= 7; k++) {
+        if (pq[k - 1] != 0.0) {
+            double temp = 0.0;
+            for (int j = 1; j <= 3; j++) temp += xpt[(k - 1) * 3 + j - 1] * s[j - 1];
+            temp *= pq[k - 1];
+            for (int i = 1; i <= 3; i++) hs[i - 1] += temp * xpt[(k - 1) * 3 + i - 1];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- trsbox_ (bobyqa.c:1162-1711)
 // Approximately minimise the model within ||d|| <= delta and the bounds: truncated conjugate
 // gradients with restarts on newly active bounds, then 2-D searches on the boundary.
 // Sets B.xnew, B.d, B.gnew, BQS(dsq), BQS(crvmin).
 BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
     double xbdi[3], s[3] = {0, 0, 0}, hs[3], hred[3] = {0, 0, 0};
+    // read-only model data and the working vectors are held in registers for the whole call
+    // (one batch of LDS reads at entry, one write-back of d / gnew / xnew at exit)
+    double xopt_[3], sl_[3], su_[3], d_[3], gnew_[3];
+    for (int i = 0; i < 3; i++) { xopt_[i] = BQA(xopt, i); sl_[i] = BQA(sl, i); su_[i] = BQA(su, i); }
     int iterc = 0, nact = 0, itermax = 0, iact = 0, itcsav = 0, isav, iu;
     double delsq, qred = 0.0, crvmin = -1.0, beta = 0.0, stepsq, gredsq = 0.0, resid, ds, shs, temp, blen, stplen,
                   sdec, ggsav = 0.0, dredsq = 0.0, dredg = 0.0, sredg = 0.0, angbd = 0.0, xsav = 0.0, ssq, tempa,
                   tempb, dhs, dhd, redmax, redsav, angt = 0.0, sth, cth, rednew, rdprev = 0.0, rdnext = 0.0;
     for (int i = 0; i < 3; i++) {
         xbdi[i] = 0.0;
-        if (BQA(xopt, i) <= BQA(sl, i)) {
+        if (xopt_[i] <= sl_[i]) {
             if (BQA(gopt, i) >= 0.0) xbdi[i] = -1.0;
-        } else if (BQA(xopt, i) >= BQA(su, i)) {
+        } else if (xopt_[i] >= su_[i]) {
             if (BQA(gopt, i) <= 0.0) xbdi[i] = 1.0;
         }
         if (xbdi[i] != 0.0) ++nact;
-        BQA(d, i) = 0.0;
-        BQA(gnew, i) = BQA(gopt, i);
+        d_[i] = 0.0;
+        gnew_[i] = BQA(gopt, i);
     }
     delsq = BQS(delta) * BQS(delta);
 
     enum { CG_RESTART, CG_NEXT, BOUNDARY, ALT_SETUP, ALT_ITER, FINISH };
     int st = CG_RESTART;
     for (;;) {
+        BQ_PROF_BEGIN(tcg_);
         if (st == CG_RESTART) { beta = 0.0; st = CG_NEXT; }
         if (st == CG_NEXT) {
             stepsq = 0.0;
             for (int i = 0; i < 3; i++) {
                 if (xbdi[i] != 0.0) s[i] = 0.0;
-                else if (beta == 0.0) s[i] = -BQA(gnew, i);
-                else s[i] = beta * s[i] - BQA(gnew, i);
+                else if (beta == 0.0) s[i] = -gnew_[i];
+                else s[i] = beta * s[i] - gnew_[i];
                 stepsq += s[i] * s[i];
             }
             if (stepsq == 0.0) { st = FINISH; continue; }
             if (beta == 0.0) { gredsq = stepsq; itermax = iterc + 3 - nact; }
             if (gredsq * delsq <= qred * 1e-4 * qred) { st = FINISH; continue; }
             hess_mul(B, s, hs);
-            BQ_PROF_COUNT(28, 1);
+            BQ_PROF_COUNT(56, 1);
             resid = delsq; ds = 0.0; shs = 0.0;
             for (int i = 0; i < 3; i++)
-                if (xbdi[i] == 0.0) { resid -= BQA(d, i) * BQA(d, i); ds += s[i] * BQA(d, i); shs += s[i] * hs[i]; }
+                if (xbdi[i] == 0.0) { resid -= d_[i] * d_[i]; ds += s[i] * d_[i]; shs += s[i] * hs[i]; }
             if (resid <= 0.0) { st = BOUNDARY; continue; }
             temp = sqrt(stepsq * resid + ds * ds);
             if (ds < 0.0) blen = (temp - ds) / stepsq;
@@ -320,9 +364,9 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             iact = 0;
             for (int i = 0; i < 3; i++)
                 if (s[i] != 0.0) {
-                    const double xsum = BQA(xopt, i) + BQA(d, i);
-                    if (s[i] > 0.0) temp = (BQA(su, i) - xsum) / s[i];
-                    else temp = (BQA(sl, i) - xsum) / s[i];
+                    const double xsum = xopt_[i] + d_[i];
+                    if (s[i] > 0.0) temp = (su_[i] - xsum) / s[i];
+                    else temp = (sl_[i] - xsum) / s[i];
                     if (temp < stplen) { stplen = temp; iact = i + 1; }
                 }
             sdec = 0.0;
@@ -336,9 +380,9 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
                 ggsav = gredsq;
                 gredsq = 0.0;
                 for (int i = 0; i < 3; i++) {
-                    BQA(gnew, i) += stplen * hs[i];
-                    if (xbdi[i] == 0.0) gredsq += BQA(gnew, i) * BQA(gnew, i);
-                    BQA(d, i) += stplen * s[i];
+                    gnew_[i] += stplen * hs[i];
+                    if (xbdi[i] == 0.0) gredsq += gnew_[i] * gnew_[i];
+                    d_[i] += stplen * s[i];
                 }
                 sdec = mx(stplen * (ggsav - 0.5 * stplen * shs), 0.0);
                 qred += sdec;
@@ -347,7 +391,7 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
                 ++nact;
                 xbdi[iact - 1] = 1.0;
                 if (s[iact - 1] < 0.0) xbdi[iact - 1] = -1.0;
-                delsq -= BQA(d, iact - 1) * BQA(d, iact - 1);
+                delsq -= d_[iact - 1] * d_[iact - 1];
                 if (delsq <= 0.0) { st = BOUNDARY; continue; }
                 st = CG_RESTART;
                 continue;
@@ -361,16 +405,18 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             }
             st = BOUNDARY;
         }
+        BQ_PROF_END(tcg_, 16);
+        BQ_PROF_BEGIN(tas_);
         if (st == BOUNDARY) { crvmin = 0.0; st = ALT_SETUP; }
         if (st == ALT_SETUP) {
             if (nact >= 2) { st = FINISH; continue; }
             dredsq = 0.0; dredg = 0.0; gredsq = 0.0;
             for (int i = 0; i < 3; i++) {
                 if (xbdi[i] == 0.0) {
-                    dredsq += BQA(d, i) * BQA(d, i);
-                    dredg += BQA(d, i) * BQA(gnew, i);
-                    gredsq += BQA(gnew, i) * BQA(gnew, i);
-                    s[i] = BQA(d, i);
+                    dredsq += d_[i] * d_[i];
+                    dredg += d_[i] * gnew_[i];
+                    gredsq += gnew_[i] * gnew_[i];
+                    s[i] = d_[i];
                 } else s[i] = 0.0;
             }
             itcsav = iterc;
@@ -378,13 +424,15 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             for (int i = 0; i < 3; i++) hred[i] = hs[i];
             st = ALT_ITER;
         }
+        BQ_PROF_END(tas_, 17);
+        BQ_PROF_BEGIN(tai_);
         if (st == ALT_ITER) {
             ++iterc;
             temp = gredsq * dredsq - dredg * dredg;
             if (temp <= qred * 1e-4 * qred) { st = FINISH; continue; }
             temp = sqrt(temp);
             for (int i = 0; i < 3; i++) {
-                if (xbdi[i] == 0.0) s[i] = (dredg * BQA(d, i) - dredsq * BQA(gnew, i)) / temp;
+                if (xbdi[i] == 0.0) s[i] = (dredg * d_[i] - dredsq * gnew_[i]) / temp;
                 else s[i] = 0.0;
             }
             sredg = -temp;
@@ -393,17 +441,17 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             bool refix = false;
             for (int i = 0; i < 3; i++) {
                 if (xbdi[i] == 0.0) {
-                    tempa = BQA(xopt, i) + BQA(d, i) - BQA(sl, i);
-                    tempb = BQA(su, i) - BQA(xopt, i) - BQA(d, i);
+                    tempa = xopt_[i] + d_[i] - sl_[i];
+                    tempb = su_[i] - xopt_[i] - d_[i];
                     if (tempa <= 0.0) { ++nact; xbdi[i] = -1.0; refix = true; break; }
                     else if (tempb <= 0.0) { ++nact; xbdi[i] = 1.0; refix = true; break; }
-                    ssq = BQA(d, i) * BQA(d, i) + s[i] * s[i];
-                    temp = ssq - (BQA(xopt, i) - BQA(sl, i)) * (BQA(xopt, i) - BQA(sl, i));
+                    ssq = d_[i] * d_[i] + s[i] * s[i];
+                    temp = ssq - (xopt_[i] - sl_[i]) * (xopt_[i] - sl_[i]);
                     if (temp > 0.0) {
                         temp = sqrt(temp) - s[i];
                         if (angbd * temp > tempa) { angbd = tempa / temp; iact = i + 1; xsav = -1.0; }
                     }
-                    temp = ssq - (BQA(su, i) - BQA(xopt, i)) * (BQA(su, i) - BQA(xopt, i));
+                    temp = ssq - (su_[i] - xopt_[i]) * (su_[i] - xopt_[i]);
                     if (temp > 0.0) {
                         temp = sqrt(temp) + s[i];
                         if (angbd * temp > tempb) { angbd = tempb / temp; iact = i + 1; xsav = 1.0; }
@@ -414,20 +462,34 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             hess_mul(B, s, hs);
             shs = 0.0; dhs = 0.0; dhd = 0.0;
             for (int i = 0; i < 3; i++)
-                if (xbdi[i] == 0.0) { shs += s[i] * hs[i]; dhs += BQA(d, i) * hs[i]; dhd += BQA(d, i) * hred[i]; }
+                if (xbdi[i] == 0.0) { shs += s[i] * hs[i]; dhs += d_[i] * hs[i]; dhd += d_[i] * hred[i]; }
+            BQ_PROF_END(tai_, 18);
+            BQ_PROF_BEGIN(tan_);
             redmax = 0.0; isav = 0; redsav = 0.0;
             iu = (int)(angbd * 17. + 3.1);
-            BQ_PROF_COUNT(29, 1);
-            BQ_PROF_COUNT(30, iu);
-            for (int i = 1; i <= iu; i++) {
-                angt = angbd * (double)i / (double)iu;
-                sth = (angt + angt) / (1.0 + angt * angt);
-                temp = shs + angt * (angt * dhd - dhs - dhs);
-                rednew = sth * (angt * dredg - sredg - 0.5 * sth * temp);
-                if (rednew > redmax) { redmax = rednew; isav = i; rdprev = redsav; }
-                else if (i == isav + 1) rdnext = rednew;
-                redsav = rednew;
+            BQ_PROF_COUNT(57, 1);
+            BQ_PROF_COUNT(58, iu);
+#define BQ_ANGLE_STEP(i_, angt_, sth_)                                                        \
+    {                                                                                         \
+        temp = shs + (angt_) * ((angt_) * dhd - dhs - dhs);                                   \
+        rednew = (sth_) * ((angt_) * dredg - sredg - 0.5 * (sth_) * temp);                    \
+        if (rednew > redmax) { redmax = rednew; isav = (i_); rdprev = redsav; }              \
+        else if ((i_) == isav + 1) rdnext = rednew;                                           \
+        redsav = rednew;                                                                      \
+    }
+            if (angbd == 1.0) {  // iu == 20: tabulated angles, unrolled so that they are literals
+#pragma unroll
+                for (int i = 1; i <= 20; i++) BQ_ANGLE_STEP(i, kAngleTable.angt[i - 1], kAngleTable.sth[i - 1])
+                angt = kAngleTable.angt[19];
+            } else {
+                for (int i = 1; i <= iu; i++) {
+                    angt = angbd * (double)i / (double)iu;
+                    sth = (angt + angt) / (1.0 + angt * angt);
+                    BQ_ANGLE_STEP(i, angt, sth)
+                }
             }
+#undef BQ_ANGLE_STEP
+            BQ_PROF_END(tan_, 19);
             if (isav == 0) { st = FINISH; continue; }
             if (isav < iu) {
                 temp = (rdnext - rdprev) / (redmax + redmax - rdprev - rdnext);
@@ -440,11 +502,11 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             if (sdec <= 0.0) { st = FINISH; continue; }
             dredg = 0.0; gredsq = 0.0;
             for (int i = 0; i < 3; i++) {
-                BQA(gnew, i) = BQA(gnew, i) + (cth - 1.0) * hred[i] + sth * hs[i];
+                gnew_[i] = gnew_[i] + (cth - 1.0) * hred[i] + sth * hs[i];
                 if (xbdi[i] == 0.0) {
-                    BQA(d, i) = cth * BQA(d, i) + sth * s[i];
-                    dredg += BQA(d, i) * BQA(gnew, i);
-                    gredsq += BQA(gnew, i) * BQA(gnew, i);
+                    d_[i] = cth * d_[i] + sth * s[i];
+                    dredg += d_[i] * gnew_[i];
+                    gredsq += gnew_[i] * gnew_[i];
                 }
                 hred[i] = cth * hred[i] + sth * hs[i];
             }
@@ -455,15 +517,17 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
         }
         if (st == FINISH) break;
     }
-    BQ_PROF_COUNT(31, 1);
-    BQS(dsq) = 0.0;
+    BQ_PROF_COUNT(59, 1);
+    double dsq = 0.0;
     for (int i = 0; i < 3; i++) {
-        BQA(xnew, i) = mx(mn(BQA(xopt, i) + BQA(d, i), BQA(su, i)), BQA(sl, i));
-        if (xbdi[i] == -1.0) BQA(xnew, i) = BQA(sl, i);
-        if (xbdi[i] == 1.0) BQA(xnew, i) = BQA(su, i);
-        BQA(d, i) = BQA(xnew, i) - BQA(xopt, i);
-        BQS(dsq) += BQA(d, i) * BQA(d, i);
+        double xn = mx(mn(xopt_[i] + d_[i], su_[i]), sl_[i]);
+        if (xbdi[i] == -1.0) xn = sl_[i];
+        if (xbdi[i] == 1.0) xn = su_[i];
+        d_[i] = xn - xopt_[i];
+        dsq += d_[i] * d_[i];
+        BQA(xnew, i) = xn; BQA(d, i) = d_[i]; BQA(gnew, i) = gnew_[i];
     }
+    BQS(dsq) = dsq;
     BQS(crvmin) = crvmin;
 }
 

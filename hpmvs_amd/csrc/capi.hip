@@ -221,8 +221,8 @@ int hpmvs_scene_commit(hpmvs_scene* s) {
     HIPCHK(hipMemcpy(s->dcovis_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&s->dcovis, sizeof(int32_t) * flat.size()));
     HIPCHK(hipMemcpy(s->dcovis, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)&s->dqueue, 512));
-    HIPCHK(hipMemset(s->dqueue, 0, 512));
+    HIPCHK(hipMalloc((void**)&s->dqueue, 1024));
+    HIPCHK(hipMemset(s->dqueue, 0, 1024));
     s->bytes += sizeof(DevView) * (size_t)s->n_views + sizeof(int32_t) * (off.size() + flat.size());
     s->committed = true;
     return HPMVS_OK;
@@ -405,7 +405,7 @@ int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_pat
     const DevOptions d = make_dev_options(o);
     {
         std::lock_guard<std::mutex> lk(s->mu);  // one work-queue counter + one event pair per scene
-        HIPCHK(hipMemsetAsync(s->dqueue, 0, 512, st));
+        HIPCHK(hipMemsetAsync(s->dqueue, 0, 1024, st));
         HIPCHK(hipEventRecord(s->ev0, st));
         launch_optimize(dev_scene(s), d, sg.d, s->dqueue, s->n_cus, st);
         HIPCHK(hipGetLastError());
@@ -465,7 +465,7 @@ int hpmvs_init_patches_batch(const hpmvs_scene* s, const hpmvs_options* o, int s
         std::lock_guard<std::mutex> lk(s->mu);
         launch_seed_init(dev_scene(s), d, start_level, n_points, dxyz, doff, dimg, sg.d, st);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemsetAsync(s->dqueue, 0, 512, st));
+        HIPCHK(hipMemsetAsync(s->dqueue, 0, 1024, st));
         HIPCHK(hipEventRecord(s->ev0, st));
         launch_optimize(dev_scene(s), d, sg.d, s->dqueue, s->n_cus, st);
         HIPCHK(hipGetLastError());
@@ -547,7 +547,7 @@ int hpmvs_debug_counters(const hpmvs_scene* s, unsigned long long* out4) {
     if (!s || !out4) return fail(HPMVS_ERR_ARG, "debug_counters: null argument");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out4, (char*)s->dqueue + 16, 288, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out4, (char*)s->dqueue + 16, 544, hipMemcpyDeviceToHost));
     return HPMVS_OK;
 }
 

@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
 
 #ifdef HPMVS_PROFILE_PHASES
     long long tA = 0, tB = 0, nrounds = 0, nreq = 0, t0 = clock64();
-    if (lane < 32) s_prof[lane] = 0ull;
+    s_prof[lane] = 0ull;
     __syncthreads();
 #endif
     for (;;) {
@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
         atomicAdd(&dbg[1], (unsigned long long)tB);
         atomicAdd(&dbg[2], (unsigned long long)nrounds);
         atomicAdd(&dbg[3], (unsigned long long)nreq);
-        for (int k = 0; k < 32; k++) atomicAdd(&dbg[4 + k], s_prof[k]);
+        for (int k = 0; k < 64; k++) atomicAdd(&dbg[4 + k], s_prof[k]);
     }
 #endif
 }

@@ -4,6 +4,6 @@
 #pragma once
 #if defined(HPMVS_PROFILE_PHASES) && defined(__HIPCC__)
 #include <hip/hip_runtime.h>
-static __device__ unsigned long long g_bqprof[32];
-static __shared__ unsigned long long s_prof[32];
+static __device__ unsigned long long g_bqprof[64];
+static __shared__ unsigned long long s_prof[64];
 #endif

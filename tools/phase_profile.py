@@ -11,7 +11,7 @@ b=api.Batch.from_seeds(seeds)
 api.optimize_batch(g,b)
 b=api.Batch.from_seeds(seeds)
 api.optimize_batch(g,b)
-out=(C.c_ulonglong*36)()
+out=(C.c_ulonglong*68)()
 L.hpmvs_debug_counters.argtypes=[C.c_void_p,C.POINTER(C.c_ulonglong)]
 L.hpmvs_debug_counters(g.h,out)
 tA,tB,nr,nq=[int(v) for v in out[:4]]
@@ -19,7 +19,9 @@ names=['trsbox','altmov','update','bq_step','L20','L60(trsbox+)','L90(shift)','L
 for i,nm in enumerate(names):
     tot,cnt=int(out[4+2*i]),int(out[5+2*i])
     print(nm,'lane-calls',cnt,'avg cycles per call %.0f'%(tot/max(cnt,1)))
-print('trsbox per-lane: calls',int(out[4+31]),'CG iters/call %.2f'%(int(out[4+28])/max(int(out[4+31]),1)),'ALT iters/call %.2f'%(int(out[4+29])/max(int(out[4+31]),1)),'angle steps per ALT iter %.1f'%(int(out[4+30])/max(int(out[4+29]),1)))
+for i,nm in [(16,'trs:CG block'),(17,'trs:ALT setup'),(18,'trs:ALT iter pre-angle'),(19,'trs:angle loop')]:
+    tot,cnt=int(out[4+2*i]),int(out[5+2*i]); print(nm,'wave-passes',cnt,'avg cycles %.0f'%(tot/max(cnt,1)),'total %.3g'%tot)
+print('trsbox per-lane: calls',int(out[4+59]),'CG iters/call %.2f'%(int(out[4+56])/max(int(out[4+59]),1)),'ALT iters/call %.2f'%(int(out[4+57])/max(int(out[4+59]),1)),'angle steps per ALT iter %.1f'%(int(out[4+58])/max(int(out[4+57]),1)))
 print('kernel ms',g.last_kernel_ms(),'phaseA cycles',tA,'phaseB cycles',tB,'rounds',nr,'requests',nq)
 print('A share %.2f  cycles/round A %.0f  B per request %.0f  req/round %.2f'%(tA/(tA+tB), tA/nr, tB/max(nq,1), nq/nr))
 print('evals mean', b.nevals[b.nevals>0].mean(), 'ok', b.ok.mean(), 'nevals hist', np.percentile(b.nevals,[50,90,99,100]))
