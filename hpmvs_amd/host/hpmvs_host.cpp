@@ -8,13 +8,16 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iomanip>
 #include <iostream>
+#include <strings.h>
 
 #include <hpmvs/Camera.h>
 #include <hpmvs/HpmvsOptions.h>
 #include <hpmvs/Image.h>
 #include <hpmvs/Patch3d.h>
 #include <hpmvs/PatchOptimizer.h>
+#include <hpmvs/PlyWriter.h>
 #include <hpmvs/Scene.h>
 
 #include "../../include/hpmvs_amd.h"
@@ -129,6 +132,123 @@ bool Image::load() {
     if (!in) return false;
     width_ = w; height_ = h;
     return true;
+}
+
+// ---------------------------------------------------------------- NVM_V3 I/O (reference src/hpmvs/NVMReader.cpp:31-182)
+static bool read_model(std::istream& in, NVM_Model& m) {
+    int nc = 0, np = 0;
+    if (!(in >> nc)) return false;
+    m.cameras.resize(nc > 0 ? nc : 0);
+    for (int i = 0; i < nc; i++) {
+        NVM_Camera& c = m.cameras[i];
+        int check = 0;
+        in >> c.filename >> c.f >> c.rq[0] >> c.rq[1] >> c.rq[2] >> c.rq[3] >> c.c[0] >> c.c[1] >> c.c[2] >> c.r >> check;
+        for (char& ch : c.filename) if (ch == '"') ch = ' ';
+    }
+    if (nc > 0) in >> np;
+    m.points.resize(np > 0 ? np : 0);
+    for (int i = 0; i < np; i++) {
+        NVM_Point& p = m.points[i];
+        int nm = 0;
+        in >> p.xyz[0] >> p.xyz[1] >> p.xyz[2] >> p.rgb[0] >> p.rgb[1] >> p.rgb[2] >> nm;
+        p.measurements.resize(nm > 0 ? nm : 0);
+        for (int k = 0; k < nm; k++)
+            in >> p.measurements[k].imgIndex >> p.measurements[k].featIndex >> p.measurements[k].xy[0] >> p.measurements[k].xy[1];
+    }
+    return true;
+}
+
+void NVMReader::readFile(const char* path, std::vector<NVM_Model>& models, bool fixPath) {
+    models.clear();
+    std::ifstream in(path);
+    if (!in.good()) { std::cerr << "cannot read from <" << path << ">" << std::endl; return; }
+    std::string folder(path);
+    const size_t slash = folder.find_last_of('/');
+    folder = (slash == std::string::npos) ? std::string() : folder.substr(0, slash + 1);
+    std::string header;
+    in >> header;
+    if (strcasecmp("NVM_V3", header.c_str()) != 0) { std::cerr << "<" << path << "> is no valid nvm file" << std::endl; return; }
+    do {
+        models.emplace_back();
+        if (!read_model(in, models.back())) break;
+        if (fixPath)
+            for (NVM_Camera& c : models.back().cameras)
+                if (!c.filename.empty() && c.filename[0] != '/') c.filename = folder + c.filename;
+    } while (in.good() && models.back().cameras.size() > 0);
+    if (!models.empty()) models.pop_back();  // the terminating empty model
+}
+
+void NVMReader::saveNVM(const char* path, const std::vector<NVM_Model>& models) {
+    std::ofstream out(path);
+    if (!out.good()) { std::cerr << "cannot write to <" << path << ">" << std::endl; return; }
+    out << std::setprecision(12);
+    out << "NVM_V3" << std::endl;
+    for (const NVM_Model& m : models) {
+        out << std::endl << m.cameras.size() << std::endl;
+        for (const NVM_Camera& c : m.cameras)
+            out << c.filename << " " << c.f << " " << c.rq[0] << " " << c.rq[1] << " " << c.rq[2] << " " << c.rq[3] << " "
+                << c.c[0] << " " << c.c[1] << " " << c.c[2] << " " << c.r << " " << 0 << std::endl;
+        if (!m.cameras.empty()) out << std::endl << m.points.size() << std::endl;
+        for (const NVM_Point& p : m.points) {
+            out << p.xyz[0] << " " << p.xyz[1] << " " << p.xyz[2] << " " << (int)p.rgb[0] << " " << (int)p.rgb[1] << " "
+                << (int)p.rgb[2] << " " << p.measurements.size();
+            for (const NVM_Measurement& q : p.measurements)
+                out << " " << q.imgIndex << " " << q.featIndex << " " << q.xy[0] << " " << q.xy[1];
+            out << std::endl;
+        }
+    }
+    out << "0";
+}
+
+// ---------------------------------------------------------------- extended PLY (reference include/hpmvs/doctree.h:526-622)
+bool writeExtPly(const char* name, const std::vector<Ppatch3d>& patches, bool binary, bool normal, bool scale,
+                 bool visibility) {
+    {
+        std::ofstream h(name, std::ofstream::out);
+        if (!h.good()) return false;
+        h << "ply" << std::endl;
+        h << (binary ? "format binary_little_endian 1.0" : "format ascii 1.0") << std::endl;
+        h << "element vertex " << (int)patches.size() << std::endl;
+        h << "property float x" << std::endl << "property float y" << std::endl << "property float z" << std::endl;
+        if (normal) h << "property float nx" << std::endl << "property float ny" << std::endl << "property float nz" << std::endl;
+        h << "property uchar red" << std::endl << "property uchar green" << std::endl << "property uchar blue" << std::endl;
+        if (scale) h << "property float scalar_scale" << std::endl;
+        if (visibility) {
+            h << "element point_visibility " << (int)patches.size() << std::endl;
+            h << "property list uint uint visible_cameras" << std::endl;
+        }
+        h << "end_header" << std::endl;
+    }
+    std::ofstream d(name, binary ? std::ofstream::binary | std::ofstream::app : std::ofstream::app);
+    for (const Ppatch3d& p : patches) {
+        const unsigned char col[3] = {(unsigned char)p->color_[0], (unsigned char)p->color_[1], (unsigned char)p->color_[2]};
+        if (binary) {
+            const float v[3] = {p->x(), p->y(), p->z()};
+            d.write((const char*)v, sizeof(v));
+            if (normal) { const float nn[3] = {p->normal_[0], p->normal_[1], p->normal_[2]}; d.write((const char*)nn, sizeof(nn)); }
+            d.write((const char*)col, 3);
+            if (scale) d.write((const char*)&p->scale_3dx_, sizeof(float));
+        } else {
+            d << p->x() << " " << p->y() << " " << p->z() << " ";
+            if (normal) d << p->normal_[0] << " " << p->normal_[1] << " " << p->normal_[2] << " ";
+            d << (int)col[0] << " " << (int)col[1] << " " << (int)col[2] << " ";
+            if (scale) d << p->scale_3dx_ << " ";
+            d << std::endl;
+        }
+    }
+    if (visibility)
+        for (const Ppatch3d& p : patches) {
+            if (binary) {
+                const uint32_t n = (uint32_t)p->images_.size();
+                d.write((const char*)&n, 4);
+                for (int id : p->images_) { const uint32_t u = (uint32_t)id; d.write((const char*)&u, 4); }
+            } else {
+                d << (int)p->images_.size() << " ";
+                for (int id : p->images_) d << (uint32_t)id << " ";
+                d << std::endl;
+            }
+        }
+    return d.good();
 }
 
 // ---------------------------------------------------------------- Scene view

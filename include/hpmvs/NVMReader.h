@@ -16,5 +16,15 @@ struct NVM_Camera {
     double r;             // radial distortion
 };
 struct NVM_Model { std::vector<NVM_Camera> cameras; std::vector<NVM_Point> points; };
+
+// VisualSFM NVM_V3 text files (reference include/hpmvs/NVMReader.h:57-66, src/hpmvs/NVMReader.cpp:31-182):
+//   NVM_V3 / <nCameras> / per camera "name f qw qx qy qz cx cy cz r 0" / <nPoints> /
+//   per point "x y z r g b nMeas {img feat u v}" / ... / a model with 0 cameras ends the file.
+class NVMReader {
+public:
+    // fixPath: make relative image names relative to the folder of the .nvm file
+    static void readFile(const char* path, std::vector<NVM_Model>& models, bool fixPath = false);
+    static void saveNVM(const char* path, const std::vector<NVM_Model>& models);
+};
 }  // namespace mo3d
 #endif
