@@ -16,6 +16,12 @@
 
 using namespace hpmvs;
 
+// Each optimize launch gets its own work-queue counter block, handed out round-robin, so that launches
+// issued concurrently from several host threads / streams (the reference runs one PatchOptimizer per
+// OpenMP thread against one shared Scene: src/hpmvs/Scene.cpp:94-96,166-167) never share a counter.
+static constexpr int kQueueSlots = 64;
+static constexpr size_t kQueueSlotBytes = 1024;
+
 static thread_local std::string g_err;
 
 static int fail(int code, const std::string& msg) {
@@ -42,7 +48,9 @@ struct hpmvs_scene {
     DevView* dviews = nullptr;
     int32_t* dcovis_off = nullptr;
     int32_t* dcovis = nullptr;
-    int32_t* dqueue = nullptr;
+    int32_t* dqueue = nullptr;          // kQueueSlots work-queue counter blocks (1 KB each), one per in-flight launch
+    mutable unsigned next_slot = 0;
+    mutable int32_t* last_queue = nullptr;
     size_t bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     mutable std::mutex mu;
@@ -221,8 +229,8 @@ int hpmvs_scene_commit(hpmvs_scene* s) {
     HIPCHK(hipMemcpy(s->dcovis_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&s->dcovis, sizeof(int32_t) * flat.size()));
     HIPCHK(hipMemcpy(s->dcovis, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)&s->dqueue, 1024));
-    HIPCHK(hipMemset(s->dqueue, 0, 1024));
+    HIPCHK(hipMalloc((void**)&s->dqueue, kQueueSlots * kQueueSlotBytes));
+    HIPCHK(hipMemset(s->dqueue, 0, kQueueSlots * kQueueSlotBytes));
     s->bytes += sizeof(DevView) * (size_t)s->n_views + sizeof(int32_t) * (off.size() + flat.size());
     s->committed = true;
     return HPMVS_OK;
@@ -404,13 +412,18 @@ int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_pat
     if (rc) return rc;
     const DevOptions d = make_dev_options(o);
     {
-        std::lock_guard<std::mutex> lk(s->mu);  // one work-queue counter + one event pair per scene
-        HIPCHK(hipMemsetAsync(s->dqueue, 0, 1024, st));
-        HIPCHK(hipEventRecord(s->ev0, st));
-        launch_optimize(dev_scene(s), d, sg.d, s->dqueue, s->n_cus, st);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(s->ev1, st));
-        s->timed = true;
+        int32_t* q;
+        {
+            std::lock_guard<std::mutex> lk(s->mu);  // counter slot + the scene's single event pair
+            q = (int32_t*)((char*)s->dqueue + (size_t)(s->next_slot++ % kQueueSlots) * kQueueSlotBytes);
+            s->last_queue = q;
+            HIPCHK(hipMemsetAsync(q, 0, kQueueSlotBytes, st));
+            HIPCHK(hipEventRecord(s->ev0, st));
+            launch_optimize(dev_scene(s), d, sg.d, q, s->n_cus, st);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(s->ev1, st));
+            s->timed = true;
+        }
         if (!on_device) HIPCHK(hipStreamSynchronize(st));
     }
     if (!on_device) {
@@ -462,17 +475,21 @@ int hpmvs_init_patches_batch(const hpmvs_scene* s, const hpmvs_options* o, int s
     }
     const DevOptions d = make_dev_options(o);
     {
-        std::lock_guard<std::mutex> lk(s->mu);
-        launch_seed_init(dev_scene(s), d, start_level, n_points, dxyz, doff, dimg, sg.d, st);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemsetAsync(s->dqueue, 0, 1024, st));
-        HIPCHK(hipEventRecord(s->ev0, st));
-        launch_optimize(dev_scene(s), d, sg.d, s->dqueue, s->n_cus, st);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(s->ev1, st));
-        s->timed = true;
-        launch_drift_gate(n_points, dxyz, sg.d, st);
-        HIPCHK(hipGetLastError());
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            int32_t* q = (int32_t*)((char*)s->dqueue + (size_t)(s->next_slot++ % kQueueSlots) * kQueueSlotBytes);
+            s->last_queue = q;
+            launch_seed_init(dev_scene(s), d, start_level, n_points, dxyz, doff, dimg, sg.d, st);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemsetAsync(q, 0, kQueueSlotBytes, st));
+            HIPCHK(hipEventRecord(s->ev0, st));
+            launch_optimize(dev_scene(s), d, sg.d, q, s->n_cus, st);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(s->ev1, st));
+            s->timed = true;
+            launch_drift_gate(n_points, dxyz, sg.d, st);
+            HIPCHK(hipGetLastError());
+        }
         if (!on_device) HIPCHK(hipStreamSynchronize(st));
     }
     if (!on_device) {
@@ -547,7 +564,8 @@ int hpmvs_debug_counters(const hpmvs_scene* s, unsigned long long* out4) {
     if (!s || !out4) return fail(HPMVS_ERR_ARG, "debug_counters: null argument");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out4, (char*)s->dqueue + 16, 544, hipMemcpyDeviceToHost));
+    if (!s->last_queue) return fail(HPMVS_ERR_STATE, "debug_counters: no launch yet");
+    HIPCHK(hipMemcpy(out4, (char*)s->last_queue + 16, 544, hipMemcpyDeviceToHost));
     return HPMVS_OK;
 }
 

@@ -2,6 +2,7 @@
 // CellProcessor::extend, src/hpmvs/CellProcessor.cpp:129): build the scene, construct
 // mo3d::PatchOptimizer(options, &scene), call optimize(patch) and read the patch back.
 // Input: a binary dump written by tests/test_gpu_cpp_interface.py.  Output: one text line per patch.
+#include <omp.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -72,6 +73,22 @@ int main(int argc, char** argv) {
         const bool ok = optimizers[i % 2].optimize(copy);
         printf("single %d %d %.9g %.9g %.9g %.9g %.9g %.9g %zu\n", i, ok ? 1 : 0, copy.center_[0], copy.center_[1],
                copy.center_[2], copy.normal_[0], copy.normal_[1], copy.normal_[2], copy.images_.size());
+    }
+    // (1b) the reference's data-parallel form (src/hpmvs/Scene.cpp:94-96,114,166-167): one optimizer per OpenMP
+    //      thread, all calling optimize() concurrently against the one shared scene
+    {
+        const int nthreads = 4;
+        std::vector<mo3d::PatchOptimizer> pool;
+        for (int i = 0; i < nthreads; i++) pool.emplace_back(options, &scene);
+        std::vector<mo3d::Patch3d> copies;
+        for (int i = 0; i < np; i++) copies.emplace_back(*patches[i]);
+        std::vector<int> okv(np, 0);
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 4)
+        for (int i = 0; i < np; i++) okv[i] = pool[omp_get_thread_num()].optimize(copies[i]) ? 1 : 0;
+        for (int i = 0; i < np; i++)
+            printf("omp %d %d %.9g %.9g %.9g %.9g %.9g %.9g %zu\n", i, okv[i], copies[i].center_[0], copies[i].center_[1],
+                   copies[i].center_[2], copies[i].normal_[0], copies[i].normal_[1], copies[i].normal_[2],
+                   copies[i].images_.size());
     }
     // (2) the additive batch entry
     std::vector<mo3d::Patch3d*> raw;
