@@ -2,22 +2,22 @@
 //
 // Mapping (MI355X-first, not a translation of the reference's one-thread-per-patch OpenMP loop):
 //
-//   * A persistent grid of single-wave workgroups pulls patches from a global work queue.
-//   * Lanes 0..kP-1 of a wave each own one patch ("slot") and run that patch's control
-//     logic as plain SIMT code: the optimize() pipeline of the reference
+//   * A persistent grid of single-wave workgroups (8 per CU, bounded by LDS) pulls patches from a
+//     global work queue.
+//   * Lanes 0..kP-1 of a wave each own one patch ("slot") and run that patch's control logic as
+//     plain SIMT code: the optimize() pipeline of the reference
 //     (src/hpmvs/PatchOptimizer.cpp:48-103: addImages / filterImagesNCC / sortImages /
 //     assureImageAngles / optimizePatch / ... / setRefImage) and the BOBYQA state machine
 //     (bobyqa3.hpp).  This is "phase A"; it ends when the lane needs photometric data.
 //   * Photometric work is done by the WHOLE WAVE for one patch at a time ("phase B"): the wave
 //     loops over the lanes that posted a request, broadcasts the request (centre, normal, scale,
-//     image list) with v_readlane, and evaluates it with wave_eval_rt (photometric.hpp): lane v
-//     prepares image v, lanes 0..48 fetch the 7x7 window texels, DPP reductions give mean /
-//     variance / NCC.  The scalar result goes back to the requesting lane.
+//     patch axes, image list) with v_readlane, and evaluates it with wave_eval_exact
+//     (photometric.hpp): lane v prepares image v, lanes 0..48 fetch the 7x7 window texels, and the
+//     reference's sequential float32 sums are formed lane-per-image from LDS-staged values.  The
+//     scalar result goes back to the requesting lane.
 //
-//   So the optimiser algebra (float64, ~1-2 kflop per iteration) costs 1/64 of a wave per patch
-//   instead of a whole wave, and the texture sampling keeps 49 of 64 lanes busy with coalescable
-//   8-byte taps.  Patches finish at different times (40-1000 evaluations); a finished lane
-//   immediately pulls the next patch from the queue, so lanes stay busy until the queue drains.
+//   Patches finish at different times (40-1000 evaluations); a finished lane immediately pulls the
+//   next patch from the queue, so slots stay busy until the queue drains.
 //
 //   The per-patch optimiser state (177 float64 + 12 int32) and image lists (uint16 ids, padded
 //   rows) live in LDS as [index][slot], so the kP lanes touch consecutive words and none of it goes

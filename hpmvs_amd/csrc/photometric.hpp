@@ -3,23 +3,27 @@
 // Two kinds of code live here:
 //   * per-lane scalar helpers (patch axes, optimiser-variable <-> centre/normal maps, the
 //     per-image gates/level/projection "prep"): plain SIMT code, one patch or one image per lane;
-//   * the wave-cooperative evaluator `wave_eval`: ONE wavefront evaluates ONE patch against its
-//     whole image list.  Lane v < nimg prepares image v (gates, pyramid level, projected window
-//     geometry); then for every image the 49 texels of the 7x7 window are fetched by lanes 0..48
-//     (lane = yy*7+xx, two 8-byte loads per lane covering the 2x2x3 bilinear taps), and the means,
-//     the variance and the NCC dot product are DPP wave reductions.  The reference texture lives
-//     in three registers per lane; nothing goes through LDS.
+//   * the wave-cooperative evaluator `wave_eval_exact`: ONE wavefront evaluates ONE patch against
+//     its whole image list.  Lane v < nimg prepares image v (gates, pyramid level, projected window
+//     geometry); per chunk of <= 8 images lanes 0..48 fetch the 7x7 window texels (lane = yy*7+xx,
+//     two 8-byte loads per lane covering the 2x2x3 bilinear taps, all loads of the chunk in flight
+//     together); means, variance and the NCC dot product are formed in the REFERENCE'S SEQUENTIAL
+//     float32 summation order by single lanes (one per image / channel) reading LDS-staged values,
+//     all images of the chunk in parallel.  Every float operation is the one the CPU reference
+//     executes (the TU is built with -ffp-contract=off), so objective values are bit-identical.
 //
 // Reference functions restated here (file:line relative to the reference root):
 //   calc_patch_axes        <- PatchOptimizer::calculatePatchAxis   src/hpmvs/PatchOptimizer.cpp:532-548
-//   prep_image + grab      <- PatchOptimizer::sampleTexture        src/hpmvs/PatchOptimizer.cpp:476-529
+//   prep_image, issue_taps,
+//   texel                  <- PatchOptimizer::sampleTexture        src/hpmvs/PatchOptimizer.cpp:476-529
 //                             Camera::project / getLeveli          include/hpmvs/Camera.h:45-62, src/hpmvs/Camera.cpp:92-99
 //                             Image::getColor                      include/hpmvs/Image.h:89-115
-//                             Patch2d::normalize / dot             include/hpmvs/Patch2d.hpp:37-84
-//   wave_eval<true>        <- PatchOptimizer::objective_fn         src/hpmvs/PatchOptimizer.cpp:286-311
-//   wave_eval<false>       <- PatchOptimizer::setINCCs             src/hpmvs/PatchOptimizer.cpp:448-474
+//   seq_sum + the staging  <- Patch2d::normalize / dot             include/hpmvs/Patch2d.hpp:37-84
+//   wave_eval_exact(obj)   <- PatchOptimizer::objective_fn         src/hpmvs/PatchOptimizer.cpp:286-311
+//   wave_eval_exact(!obj)  <- PatchOptimizer::setINCCs             src/hpmvs/PatchOptimizer.cpp:448-474
 //   set_optimization_fields, set_center_norm, parameters_from_center_norm
 //                          <- src/hpmvs/PatchOptimizer.cpp:384-446
+//   asinf_glibc            <- glibc 2.35 __ieee754_asinf (what std::asin(float) is on the host)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -40,25 +44,6 @@ namespace hpmvs {
 // wave64 helpers
 
 __device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
-    return v + __int_as_float(t);
-}
-
-// Sum over the 64 lanes; the result is wave-uniform (broadcast from lane 63 through an SGPR).
-// quad_perm xor1, xor2, row_half_mirror, row_mirror leave every lane of a 16-lane row holding the
-// row sum; row_bcast:15 / row_bcast:31 (GFX9 DPP) fold the four rows into lane 63.
-__device__ __forceinline__ float wave_sum(float v) {
-    v = dpp_add<0xB1, 0xF>(v);   // quad_perm:[1,0,3,2]
-    v = dpp_add<0x4E, 0xF>(v);   // quad_perm:[2,3,0,1]
-    v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
-    v = dpp_add<0x140, 0xF>(v);  // row_mirror
-    v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 -> rows 1,3
-    v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
 
 __device__ __forceinline__ float bcast_f(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
@@ -194,43 +179,6 @@ __device__ __forceinline__ uint2 load8(const uint8_t* p) {
     return v;
 }
 
-// Lanes 0..48 fetch one texel each (Image::getColor, Image.h:89-115) at
-// tl + yy*dy + xx*dx; then Patch2d::normalize (Patch2d.hpp:46-84) across the wave.
-// Outputs the lane's normalised (r,g,b); lanes >= 49 get zeros.  All arguments except fx, fy,
-// active are wave-uniform.
-__device__ __forceinline__ void grab_normalized(float tlx, float tly, float dxx, float dxy, float dyx, float dyy,
-                                                const uint8_t* pix, int W, float fx, float fy, bool active,
-                                                float& n0, float& n1, float& n2) {
-    const float x = (tlx + fy * dyx) + fx * dxx;
-    const float y = (tly + fy * dyy) + fx * dxy;
-    const int lx = (int)x, ly = (int)y;
-    const uint8_t* p0 = pix + 3 * (ly * W + lx);
-    const uint8_t* p1 = p0 + 3 * W;
-    const uint2 a = load8(p0);
-    const uint2 b = load8(p1);
-    const float dx1 = x - (float)lx, dx0 = 1.0f - dx1;
-    const float dy1 = y - (float)ly, dy0 = 1.0f - dy1;
-    const float f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
-    float r = (float)(a.x & 0xff) * f00 + (float)(b.x & 0xff) * f01;
-    float g = (float)((a.x >> 8) & 0xff) * f00 + (float)((b.x >> 8) & 0xff) * f01;
-    float bl = (float)((a.x >> 16) & 0xff) * f00 + (float)((b.x >> 16) & 0xff) * f01;
-    r += (float)(a.x >> 24) * f10 + (float)(b.x >> 24) * f11;
-    g += (float)(a.y & 0xff) * f10 + (float)(b.y & 0xff) * f11;
-    bl += (float)((a.y >> 8) & 0xff) * f10 + (float)((b.y >> 8) & 0xff) * f11;
-    if (!active) { r = 0.0f; g = 0.0f; bl = 0.0f; }
-    const float a0 = wave_sum(r) / 49.0f;
-    const float a1 = wave_sum(g) / 49.0f;
-    const float a2 = wave_sum(bl) / 49.0f;
-    const float e0 = a0 - r, e1 = a1 - g, e2 = a2 - bl;
-    float sq = (e0 * e0 + e1 * e1) + e2 * e2;
-    if (!active) sq = 0.0f;
-    float ave2 = sqrtf(wave_sum(sq) / 147.0f);
-    if (ave2 == 0.0f) ave2 = 1.0f;
-    n0 = active ? (r - a0) / ave2 : 0.0f;
-    n1 = active ? (g - a1) / ave2 : 0.0f;
-    n2 = active ? (bl - a2) / ave2 : 0.0f;
-}
-
 __device__ __forceinline__ float robustincc(float rhs) { return rhs / (1 + 3 * rhs); }  // PatchOptimizer.h:92-94
 
 struct EvalResult {
@@ -239,90 +187,6 @@ struct EvalResult {
     float incc_sum;   // INCC: sequential float sum of inccs (std::accumulate, PatchOptimizer.cpp:165)
     int ngrabs;       // grabs that passed the gates
 };
-
-// One wavefront evaluates one patch.  Everything passed in is wave-uniform; `list` holds the
-// attached image ids (LDS uint16 rows in the refinement kernel, global int32 rows elsewhere).
-//   obj_mode != 0: objective_fn  (z axis of the angle gate = normalised normal, plateau 2.0)
-//   obj_mode == 0: setINCCs(ref_slot, robust) (z axis = the raw normal)
-// The reference texture is grabbed first, then the others in list order (one grab call site).
-template <typename ListT>
-__device__ __forceinline__ EvalResult wave_eval_rt(const DevScene& sc, const DevOptions& o, const ListT* list,
-                                                   int nimg, int ref_slot, const float* c, const float* n,
-                                                   float scale, int obj_mode, int robust) {
-    EvalResult res;
-    res.obj = 2.0; res.incc_lane = 2.0f; res.incc_sum = 0.0f; res.ngrabs = 0;
-    const int lane = lane_id();
-    const int sl = lane < kTexPix ? lane : kTexPix - 1;
-    const float fy = (float)(sl / kTex), fx = (float)(sl % kTex);
-    const bool active = lane < kTexPix;
-
-    // patch axes from the reference image's camera (uniform)
-    const DevView& RV = sc.views[(int)list[ref_slot]];
-    float px[3], py[3], pz[3];
-    calc_patch_axes(RV.xaxis, RV.yaxis, n, scale, px, py, pz);
-    float zax[3];
-    for (int k = 0; k < 3; k++) zax[k] = obj_mode ? pz[k] : n[k];
-
-    // lane v prepares image v
-    Prep P;
-    P.ok = 0; P.tlx = P.tly = P.dxx = P.dxy = P.dyx = P.dyy = 0.0f; P.pix = nullptr; P.W = 0;
-    if (lane < nimg) P = prep_image(sc.views[(int)list[lane]], o, c, scale, px, py, zax);
-
-    if (!bcast_i(P.ok, ref_slot)) {
-        // objective: 2.0; setINCCs: every entry 2.0
-        if (!obj_mode) {
-            float s = 0.0f;
-            for (int k = 0; k < nimg; k++) s += 2.0f;
-            res.incc_sum = s;
-        }
-        return res;
-    }
-    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
-    int ngr = 0, nok = 0;
-    double val = 0.0;
-    float mine = 2.0f;
-    // per-image raw values, delivered to lane v; the sequential float sum is formed afterwards
-    for (int it = 0; it < nimg; it++) {
-        const int v = (it == 0) ? ref_slot : ((it - 1 < ref_slot) ? it - 1 : it);
-        if (!bcast_i(P.ok, v)) continue;  // entry stays 2.0 (setINCCs) / skipped (objective)
-        float c0, c1, c2;
-        grab_normalized(bcast_f(P.tlx, v), bcast_f(P.tly, v), bcast_f(P.dxx, v), bcast_f(P.dxy, v),
-                        bcast_f(P.dyx, v), bcast_f(P.dyy, v), bcast_p(P.pix, v), bcast_i(P.W, v), fx, fy,
-                        active, c0, c1, c2);
-        ngr++;
-        if (it == 0) {
-            r0 = c0; r1 = c1; r2 = c2;
-            if (lane == v) mine = 0.0f;
-            continue;
-        }
-        const float dot = wave_sum((r0 * c0 + r1 * c1) + r2 * c2) / 147.0f;
-        const float raw = 1.0f - dot;
-        if (obj_mode) {
-            val += (double)robustincc(raw);
-            nok++;
-        } else if (lane == v) {
-            mine = robust ? robustincc(raw) : raw;
-        }
-    }
-    res.ngrabs = ngr;
-    if (obj_mode) {
-        res.obj = (nok < o.MIN_IMAGES_PER_PATCH - 1) ? 2.0 : val / (double)nok;
-    } else {
-        res.incc_lane = mine;
-        // std::accumulate(incc.begin(), incc.end(), 0.0f) in index order (PatchOptimizer.cpp:165)
-        float s = 0.0f;
-        for (int k = 0; k < nimg; k++) s += bcast_f(mine, k);
-        res.incc_sum = s;
-    }
-    return res;
-}
-
-template <bool OBJ, typename ListT>
-__device__ __forceinline__ EvalResult wave_eval(const DevScene& sc, const DevOptions& o, const ListT* list, int nimg,
-                                                int ref_slot, const float* c, const float* n, float scale,
-                                                int robust) {
-    return wave_eval_rt(sc, o, list, nimg, ref_slot, c, n, scale, OBJ ? 1 : 0, robust);
-}
 
 // ------------------------------------------------------------------------------------------
 // EXACT-ORDER evaluator.
