@@ -172,3 +172,38 @@ def test_init_patches_batch_matches_oracle(tiny_scene, oracle_scene, gpu_scene):
             if p.stage == 0 or p.stage == 12:
                 assert np.array_equal(np.array(p.normal[:], dtype=np.float32), batch.normal[k]), k
                 assert list(p.images[:p.n_images]) == list(batch.images[k, :batch.n_images[k]])
+
+
+def test_many_views_multi_chunk_is_bit_identical():
+    """20 views, patches with 9-20 attached images: exercises the chunked evaluation (more than 8 images per
+    patch), setINCCs with a non-zero reference slot and the O(V^2) setRefImage pass."""
+    import torch
+    from hpmvs_amd import api, synth
+    from oracle import oracle as orc
+    scene = synth.make_scene(20, 640, 360, n_waves=16, device=torch.device("cuda", 0))
+    g = api.Scene(scene)
+    osc = orc.OracleScene(scene)
+    seeds = synth.make_seeds(scene, 160, start_level=1, max_images=64, max_seed_images=20, seed=synth.SEED + 5)
+    idx = np.nonzero(seeds.n_images >= 9)[0]
+    assert len(idx) >= 40
+    batch = api.Batch.from_seeds(seeds, idx)
+    P = orc.patches_from_seeds(seeds, idx)
+    x0 = np.array([orc.initial_parameters(osc, P[k]) for k in range(len(idx))])
+    fg, grabs = api.objective_batch(g, batch, x0)
+    fc = np.array([orc.objective_at(osc, P[k], x0[k]) for k in range(len(idx))])
+    assert np.array_equal(fg, fc) and grabs.max() > 8
+    inc = api.inccs_batch(g, batch, 3, 1)
+    for k in range(len(idx)):
+        assert np.array_equal(inc[k, :P[k].n_images], orc.inccs(osc, P[k], 3, 1))
+    b = api.Batch.from_seeds(seeds)
+    api.optimize_batch(g, b)
+    Q = orc.patches_from_seeds(seeds)
+    orc.optimize_batch(osc, Q, n_threads=8)
+    assert np.array_equal(np.array([q.stage for q in Q]), b.stage)
+    both = np.nonzero(b.ok)[0]
+    assert len(both) >= 100 and b.n_images[both].max() >= 9
+    for k in both:
+        assert np.array_equal(np.array(Q[k].center[:], dtype=np.float32), b.center[k])
+        assert np.array_equal(np.array(Q[k].normal[:], dtype=np.float32), b.normal[k])
+        assert list(Q[k].images[:Q[k].n_images]) == list(b.images[k, :b.n_images[k]]) and Q[k].nevals == b.nevals[k]
+    g.close()
