@@ -142,11 +142,22 @@ enum {  // int32 slots
 #ifndef BQ_P
 #error "define BQ_P (patches per wavefront) together with BQ_STATE_LDS"
 #endif
+#if defined(BQ_LAYOUT_SLOT_MAJOR)
+// [slot][index]: one slot's state is contiguous (wide ds_read_b128 of neighbouring elements); the slot
+// stride of 178 doubles = 356 dwords = 36 (mod 64) keeps the lanes of a wave on disjoint LDS banks
+#define BQ_DSTRIDE 178
+__shared__ double bq_lds_d[BQ_DSTRIDE * BQ_P];
+__shared__ int bq_lds_i[BQ_NI * BQ_P];
+struct Bobyqa3 { int slot; };
+#define BQ_D(i) bq_lds_d[B.slot * BQ_DSTRIDE + (i)]
+#define BQ_I(i) bq_lds_i[(i) * BQ_P + B.slot]
+#else
 __shared__ double bq_lds_d[BQ_ND * BQ_P];
 __shared__ int bq_lds_i[BQ_NI * BQ_P];
 struct Bobyqa3 { int slot; };
 #define BQ_D(i) bq_lds_d[(i) * BQ_P + B.slot]
 #define BQ_I(i) bq_lds_i[(i) * BQ_P + B.slot]
+#endif
 #else
 struct Bobyqa3 { double dd[BQ_ND]; int ii[BQ_NI]; };
 #define BQ_D(i) B.dd[(i)]
