@@ -25,9 +25,8 @@
 //   altmov            <- altmov_    bobyqa.c:744-1160
 //   update            <- update_    bobyqa.c:18-141
 //   run / after_eval  <- bobyqb_    bobyqa.c:1954-3055
-// rescue_ (bobyqa.c:143-742) is NOT restated: where the reference would call it the run stops
-// with rc = BQ_NEED_RESCUE and the caller reports the patch as failed with that distinct code
-// (measured frequency on the benchmark scenes: see DESIGN.md).
+//   rescue_*          <- rescue_    bobyqa.c:143-742 (never needed on the photometric objective in
+//                        1.1 M benchmark patches, pinned on synthetic ill-conditioned objectives)
 //
 // Indexing: the accessor macros are 1-based like the mathematics; storage is dense 0-based.
 #pragma once
@@ -120,7 +119,11 @@ enum {  // float64 slots: arrays first (names as in Powell's paper / bobyqb_), t
     O_fbeg = 174,
     O_stepa = 175,
     O_stepb = 176,
-    BQ_ND = 177
+    O_ptsaux = 177,
+    O_ptsid = 183,
+    O_fbase_r = 190,
+    O_vquad_r = 191,
+    BQ_ND = 192
 };
 enum {  // int32 slots
     I_rc = 0,
@@ -135,7 +138,8 @@ enum {  // int32 slots
     I_nfsav = 9,
     I_nf = 10,
     I_phase = 11,
-    BQ_NI = 12
+    I_kpt = 12,
+    BQ_NI = 13
 };
 
 #if defined(BQ_STATE_LDS)
@@ -145,7 +149,7 @@ enum {  // int32 slots
 #if defined(BQ_LAYOUT_SLOT_MAJOR)
 // [slot][index]: one slot's state is contiguous (wide ds_read_b128 of neighbouring elements); the slot
 // stride of 178 doubles = 356 dwords = 36 (mod 64) keeps the lanes of a wave on disjoint LDS banks
-#define BQ_DSTRIDE 178
+#define BQ_DSTRIDE 194
 __shared__ double bq_lds_d[BQ_DSTRIDE * BQ_P];
 __shared__ int bq_lds_i[BQ_NI * BQ_P];
 struct Bobyqa3 { int slot; };
@@ -175,6 +179,8 @@ struct Bobyqa3 { double dd[BQ_ND]; int ii[BQ_NI]; };
 #define BQ_PQ(k) BQ_D(O_pq + (k) - 1)
 #define BQ_HQ(ih) BQ_D(O_hq + (ih) - 1)
 #define BQ_V(a, i) BQ_D(O_##a + (i) - 1)
+#define BQ_PA(i, j) BQ_D(O_ptsaux + ((j) - 1) * 2 + ((i) - 1))  // PTSAUX(i,j) of rescue_
+#define BQ_PTSID(k) BQ_D(O_ptsid + (k) - 1)
 
 namespace bq {
 
@@ -200,8 +206,8 @@ BQ_HD double mn(double a, double b) { return a <= b ? a : b; }
 BQ_HD double mx(double a, double b) { return a >= b ? a : b; }
 BQ_HD bool is_inf(double v) { return fabs(v) >= HUGE_VAL * 0.99; }
 
-enum { PH_PRELIM = 0, PH_MAIN = 1, PH_DONE = 2 };
-enum { L20 = 0, L60, L90, L210, L230, L360, L650, L680, L720, LRET_CONT, LRET_DONE };
+enum { PH_PRELIM = 0, PH_MAIN = 1, PH_DONE = 2, PH_RESCUE = 3 };
+enum { L20 = 0, L60, L90, L210, L230, L360, L650, L680, L720, L190, LRET_CONT, LRET_DONE };
 
 // x (scaled) for the interpolation point / trial step `p` (relative to xbase), bounds respected
 // exactly as bobyqb_ does before each calfun (bobyqa.c:2560-2575, 1871-1883)
@@ -755,6 +761,280 @@ BQ_HD void pick_knew(Bobyqa3& B, int from_off, bool skip_kopt, double& scaden, d
     }
 }
 
+// ---------------------------------------------------------------- rescue_ (bobyqa.c:143-742)
+// Called (label L190) when rounding errors have damaged the denominator of the updating formula:
+// xbase moves to xopt, BMAT/ZMAT are rebuilt from provisional points along the coordinate directions,
+// original interpolation points are reinstated while the denominators stay healthy, and the remaining
+// provisional points are evaluated (one objective evaluation each, hence the resumable loop).
+
+BQ_HD int rescue_finish(Bobyqa3& B, int rc2) {  // bobyqa.c:2340-2365
+    BQS(xoptsq) = 0.0;
+    if (BQN(kopt) != BQN(kbase)) {
+        for (int i = 1; i <= 3; i++) {
+            BQ_V(xopt, i) = BQ_XPT(BQN(kopt), i);
+            BQS(xoptsq) += BQ_V(xopt, i) * BQ_V(xopt, i);
+        }
+    }
+    if (rc2 != BQ_SUCCESS) { BQN(rc) = rc2; return L720; }
+    BQN(nresc) = BQN(nevals);
+    if (BQN(nfsav) < BQN(nevals)) { BQN(nfsav) = BQN(nevals); return L20; }
+    if (BQN(ntrits) > 0) return L60;
+    return L210;
+}
+
+// the L260 loop of rescue_ (bobyqa.c:560-651): next provisional point that still needs a value
+BQ_HD_NOINLINE int rescue_next(Bobyqa3& B) {
+    for (; BQN(kpt) <= 7; BQN(kpt)++) {
+        const int kpt = BQN(kpt);
+        if (BQ_PTSID(kpt) == 0.0) continue;
+        if (BQN(maxeval) > 0 && BQN(nevals) >= BQN(maxeval)) return rescue_finish(B, BQ_MAXEVAL_REACHED);
+        double w[3];
+        int ih = 0;
+        for (int j = 1; j <= 3; j++) {
+            w[j - 1] = BQ_XPT(kpt, j);
+            BQ_XPT(kpt, j) = 0.0;
+            const double temp = BQ_PQ(kpt) * w[j - 1];
+            for (int i = 1; i <= j; i++) { ++ih; BQ_HQ(ih) += temp * w[i - 1]; }
+        }
+        BQ_PQ(kpt) = 0.0;
+        const int ip = (int)BQ_PTSID(kpt);
+        const int iq = (int)(4.0 * BQ_PTSID(kpt) - (double)(ip * 4));
+        double xp = 0.0, xq = 0.0;
+        if (ip > 0) { xp = BQ_PA(1, ip); BQ_XPT(kpt, ip) = xp; }
+        if (iq > 0) {
+            xq = BQ_PA(1, iq);
+            if (ip == 0) xq = BQ_PA(2, iq);
+            BQ_XPT(kpt, iq) = xq;
+        }
+        // value of the current model at the new point
+        double vquad = BQS(fbase_r);
+        int ihp = 0, ihq = 0;
+        if (ip > 0) {
+            ihp = (ip + ip * ip) / 2;
+            vquad += xp * (BQ_V(gopt, ip) + 0.5 * xp * BQ_HQ(ihp));
+        }
+        if (iq > 0) {
+            ihq = (iq + iq * iq) / 2;
+            vquad += xq * (BQ_V(gopt, iq) + 0.5 * xq * BQ_HQ(ihq));
+            if (ip > 0) {
+                const int dd = ip - iq;
+                const int iw = (ihp >= ihq ? ihp : ihq) - (dd < 0 ? -dd : dd);
+                vquad += xp * xq * BQ_HQ(iw);
+            }
+        }
+        for (int k = 1; k <= 7; k++) {
+            double temp = 0.0;
+            if (ip > 0) temp += xp * BQ_XPT(k, ip);
+            if (iq > 0) temp += xq * BQ_XPT(k, iq);
+            vquad += 0.5 * BQ_PQ(k) * temp * temp;
+        }
+        BQS(vquad_r) = vquad;
+        set_x_from(B, O_xpt + (kpt - 1) * 3);
+        BQN(nevals)++;
+        BQN(phase) = PH_RESCUE;
+        return LRET_CONT;
+    }
+    return rescue_finish(B, BQ_SUCCESS);
+}
+
+// after the evaluation of provisional point kpt (bobyqa.c:652-700)
+BQ_HD_NOINLINE int rescue_consume(Bobyqa3& B, double f) {
+    const int kpt = BQN(kpt);
+    BQ_FVAL(kpt) = f;
+    if (f < BQ_FVAL(BQN(kopt))) BQN(kopt) = kpt;
+    if (BQN(maxeval) > 0 && BQN(nevals) >= BQN(maxeval)) return rescue_finish(B, BQ_MAXEVAL_REACHED);
+    const double diff = f - BQS(vquad_r);
+    for (int i = 1; i <= 3; i++) BQ_V(gopt, i) += diff * BQ_BMAT(kpt, i);
+    for (int k = 1; k <= 7; k++) {
+        double sum = 0.0;
+        for (int j = 1; j <= 3; j++) sum += BQ_ZMAT(k, j) * BQ_ZMAT(kpt, j);
+        const double temp = diff * sum;
+        if (BQ_PTSID(k) == 0.0) {
+            BQ_PQ(k) += temp;
+        } else {
+            const int ip = (int)BQ_PTSID(k);
+            const int iq = (int)(4.0 * BQ_PTSID(k) - (double)(ip * 4));
+            const int ihq = (iq * iq + iq) / 2;
+            if (ip == 0) {
+                BQ_HQ(ihq) += temp * (BQ_PA(2, iq) * BQ_PA(2, iq));
+            } else {
+                const int ihp = (ip * ip + ip) / 2;
+                BQ_HQ(ihp) += temp * (BQ_PA(1, ip) * BQ_PA(1, ip));
+                if (iq > 0) {
+                    BQ_HQ(ihq) += temp * (BQ_PA(1, iq) * BQ_PA(1, iq));
+                    const int dd = iq - ip;
+                    const int iw = (ihp >= ihq ? ihp : ihq) - (dd < 0 ? -dd : dd);
+                    BQ_HQ(iw) += temp * BQ_PA(1, ip) * BQ_PA(1, iq);
+                }
+            }
+        }
+    }
+    BQ_PTSID(kpt) = 0.0;
+    BQN(kpt) = kpt + 1;
+    return rescue_next(B);
+}
+
+// everything of rescue_ before its evaluation loop (bobyqa.c:240-558)
+#ifndef BQ_ON_RESCUE
+#define BQ_ON_RESCUE() do { } while (0)  // test hook (tests/native/bq_host.cpp counts the calls)
+#endif
+BQ_HD_NOINLINE int rescue_begin(Bobyqa3& B) {
+    BQ_ON_RESCUE();
+    const double sfrac = 0.5 / 4.0;
+    BQN(nfsav) = BQN(nevals);
+    BQN(kbase) = BQN(kopt);
+    const int kopt = BQN(kopt);
+    const int knew_main = BQN(knew);  // bobyqb_'s KNEW survives the call (rescue_ has its own)
+    double wd[8], w[4], wv[4], ww[8];
+    double sumpq = 0.0, winc = 0.0;
+    for (int k = 1; k <= 7; k++) {
+        double distsq = 0.0;
+        for (int j = 1; j <= 3; j++) {
+            BQ_XPT(k, j) -= BQ_V(xopt, j);
+            distsq += BQ_XPT(k, j) * BQ_XPT(k, j);
+        }
+        sumpq += BQ_PQ(k);
+        wd[k] = distsq;
+        winc = mx(winc, distsq);
+        for (int j = 1; j <= 3; j++) BQ_ZMAT(k, j) = 0.0;
+    }
+    int ih = 0;
+    for (int j = 1; j <= 3; j++) {
+        w[j] = 0.5 * sumpq * BQ_V(xopt, j);
+        for (int k = 1; k <= 7; k++) w[j] += BQ_PQ(k) * BQ_XPT(k, j);
+        for (int i = 1; i <= j; i++) {
+            ++ih;
+            BQ_HQ(ih) = BQ_HQ(ih) + w[i] * BQ_V(xopt, j) + w[j] * BQ_V(xopt, i);
+        }
+    }
+    for (int j = 1; j <= 3; j++) {
+        BQ_V(xbase, j) += BQ_V(xopt, j);
+        BQ_V(sl, j) -= BQ_V(xopt, j);
+        BQ_V(su, j) -= BQ_V(xopt, j);
+        BQ_V(xopt, j) = 0.0;
+        BQ_PA(1, j) = mn(BQS(delta), BQ_V(su, j));
+        BQ_PA(2, j) = mx(-BQS(delta), BQ_V(sl, j));
+        if (BQ_PA(1, j) + BQ_PA(2, j) < 0.0) {
+            const double temp = BQ_PA(1, j);
+            BQ_PA(1, j) = BQ_PA(2, j);
+            BQ_PA(2, j) = temp;
+        }
+        if (fabs(BQ_PA(2, j)) < 0.5 * fabs(BQ_PA(1, j))) BQ_PA(2, j) = 0.5 * BQ_PA(1, j);
+        for (int i = 1; i <= 10; i++) BQ_BMAT(i, j) = 0.0;
+    }
+    BQS(fbase_r) = BQ_FVAL(kopt);
+    BQ_PTSID(1) = sfrac;
+    for (int j = 1; j <= 3; j++) {
+        const int jp = j + 1, jpn = jp + 3;  // jpn <= npt always holds for npt = 2n+1
+        BQ_PTSID(jp) = (double)j + sfrac;
+        BQ_PTSID(jpn) = (double)j / 4.0 + sfrac;
+        const double temp = 1.0 / (BQ_PA(1, j) - BQ_PA(2, j));
+        BQ_BMAT(jp, j) = -temp + 1.0 / BQ_PA(1, j);
+        BQ_BMAT(jpn, j) = temp + 1.0 / BQ_PA(2, j);
+        BQ_BMAT(1, j) = -BQ_BMAT(jp, j) - BQ_BMAT(jpn, j);
+        BQ_ZMAT(1, j) = sqrt(2.) / fabs(BQ_PA(1, j) * BQ_PA(2, j));
+        BQ_ZMAT(jp, j) = BQ_ZMAT(1, j) * BQ_PA(2, j) * temp;
+        BQ_ZMAT(jpn, j) = -BQ_ZMAT(1, j) * BQ_PA(1, j) * temp;
+    }
+    // (npt = 2n+1: no further provisional points with two non-zero coordinates)
+    int nrem = 7, kold = 1, knew = kopt;
+    bool reinstate = true;  // enter at label 80
+    for (;;) {
+        if (reinstate) {  // label 80: exchange PTSID(KOLD) with PTSID(KNEW)
+            for (int j = 1; j <= 3; j++) {
+                double temp = BQ_BMAT(kold, j); BQ_BMAT(kold, j) = BQ_BMAT(knew, j); BQ_BMAT(knew, j) = temp;
+                temp = BQ_ZMAT(kold, j); BQ_ZMAT(kold, j) = BQ_ZMAT(knew, j); BQ_ZMAT(knew, j) = temp;
+            }
+            BQ_PTSID(kold) = BQ_PTSID(knew);
+            BQ_PTSID(knew) = 0.0;
+            wd[knew] = 0.0;
+            --nrem;
+            if (knew != kopt) {
+                const double temp = BQ_V(vlag, kold);
+                BQ_V(vlag, kold) = BQ_V(vlag, knew);
+                BQ_V(vlag, knew) = temp;
+                BQN(knew) = knew;  // update() reads knew / beta / denom from the state
+                update(B);
+                if (nrem == 0) break;  // label 350
+                for (int k = 1; k <= 7; k++) wd[k] = fabs(wd[k]);
+            }
+        }
+        // label 120: nearest original point not yet reinstated
+        double dsqmin = 0.0;
+        for (int k = 1; k <= 7; k++)
+            if (wd[k] > 0.0)
+                if (dsqmin == 0.0 || wd[k] < dsqmin) { knew = k; dsqmin = wd[k]; }
+        if (dsqmin == 0.0) {  // label 260
+            BQN(knew) = knew_main;
+            BQN(kpt) = 1;
+            return rescue_next(B);
+        }
+        for (int j = 1; j <= 3; j++) wv[j] = BQ_XPT(knew, j);
+        for (int k = 1; k <= 7; k++) {
+            double sum = 0.0;
+            if (k == kopt) {
+            } else if (BQ_PTSID(k) == 0.0) {
+                for (int j = 1; j <= 3; j++) sum += wv[j] * BQ_XPT(k, j);
+            } else {
+                const int ip = (int)BQ_PTSID(k);
+                if (ip > 0) sum = wv[ip] * BQ_PA(1, ip);
+                const int iq = (int)(4.0 * BQ_PTSID(k) - (double)(ip * 4));
+                if (iq > 0) {
+                    const int iw = (ip == 0) ? 2 : 1;
+                    sum += wv[iq] * BQ_PA(iw, iq);
+                }
+            }
+            ww[k] = 0.5 * sum * sum;
+        }
+        for (int k = 1; k <= 7; k++) {
+            double sum = 0.0;
+            for (int j = 1; j <= 3; j++) sum += BQ_BMAT(k, j) * wv[j];
+            BQ_V(vlag, k) = sum;
+        }
+        double beta = 0.0;
+        for (int j = 1; j <= 3; j++) {
+            double sum = 0.0;
+            for (int k = 1; k <= 7; k++) sum += BQ_ZMAT(k, j) * ww[k];
+            beta -= sum * sum;
+            for (int k = 1; k <= 7; k++) BQ_V(vlag, k) += sum * BQ_ZMAT(k, j);
+        }
+        double bsum = 0.0, distsq = 0.0;
+        for (int j = 1; j <= 3; j++) {
+            double sum = 0.0;
+            for (int k = 1; k <= 7; k++) sum += BQ_BMAT(k, j) * ww[k];
+            const int jp = j + 7;
+            bsum += sum * wv[j];
+            for (int ip = 8; ip <= 10; ip++) sum += BQ_BMAT(ip, j) * wv[ip - 7];
+            bsum += sum * wv[j];
+            BQ_V(vlag, jp) = sum;
+            distsq += BQ_XPT(knew, j) * BQ_XPT(knew, j);
+        }
+        beta = 0.5 * distsq * distsq + beta - bsum;
+        BQ_V(vlag, kopt) += 1.0;
+        double denom = 0.0, vlmxsq = 0.0;
+        for (int k = 1; k <= 7; k++) {
+            if (BQ_PTSID(k) != 0.0) {
+                double hdiag = 0.0;
+                for (int j = 1; j <= 3; j++) hdiag += BQ_ZMAT(k, j) * BQ_ZMAT(k, j);
+                const double den = beta * hdiag + BQ_V(vlag, k) * BQ_V(vlag, k);
+                if (den > denom) { kold = k; denom = den; }
+            }
+            vlmxsq = mx(vlmxsq, BQ_V(vlag, k) * BQ_V(vlag, k));
+        }
+        if (denom <= vlmxsq * .01) {
+            wd[knew] = -wd[knew] - winc;
+            reinstate = false;  // back to label 120
+            continue;
+        }
+        BQS(beta) = beta;
+        BQS(denom) = denom;
+        reinstate = true;  // label 80
+    }
+    // label 350: every original point was reinstated, nothing to evaluate
+    BQN(knew) = knew_main;
+    return rescue_finish(B, BQ_SUCCESS);
+}
+
 // ---------------------------------------------------------------- bobyqb_ main loop (bobyqa.c:2143-3055)
 // Runs from `label` until the next objective evaluation is needed (returns BQ_CONTINUE with
 // B.xeval set) or the run ends (BQ_DONE).
@@ -925,14 +1205,16 @@ BQ_HD_NOINLINE int step_label(Bobyqa3& B, int label) {
                     return L230;
                 }
                 if (BQS(denom) <= 0.5 * (vk * vk)) {
-                    BQN(rc) = (BQN(nevals) > BQN(nresc)) ? BQ_NEED_RESCUE : BQ_ROUNDOFF_LIMITED;
+                    if (BQN(nevals) > BQN(nresc)) return L190;
+                    BQN(rc) = BQ_ROUNDOFF_LIMITED;
                     return L720;
                 }
             } else {
                 double scaden, biglsq;
                 pick_knew(B, O_xopt, true, scaden, biglsq);
                 if (scaden <= 0.5 * biglsq) {
-                    BQN(rc) = (BQN(nevals) > BQN(nresc)) ? BQ_NEED_RESCUE : BQ_ROUNDOFF_LIMITED;
+                    if (BQN(nevals) > BQN(nresc)) return L190;
+                    BQN(rc) = BQ_ROUNDOFF_LIMITED;
                     return L720;
                 }
             }
@@ -986,6 +1268,8 @@ BQ_HD_NOINLINE int step_label(Bobyqa3& B, int label) {
             if (BQN(ntrits) == -1) { return L360; }
             return L720;
         }
+        case L190:  // rescue_ (bobyqa.c:2331-2365)
+            return rescue_begin(B);
         case L720:
         default: {  // return the best point (bobyqa.c:3042-3054)
             for (int i = 1; i <= 3; i++) {
@@ -1020,6 +1304,7 @@ BQ_HD int run(Bobyqa3& B, int label) {
         else if (__any(live && label == L650)) pick = L650;
         else if (__any(live && label == L680)) pick = L680;
         else if (__any(live && label == L720)) pick = L720;
+        else if (__any(live && label == L190)) pick = L190;
         else if (__any(live && label == L360)) pick = L360;
         else if (__any(live && label == L60)) pick = L60;
         else if (__any(live && label == L210)) pick = L210;
@@ -1295,6 +1580,8 @@ BQ_HD_NOINLINE int bq_step_(Bobyqa3& B, double f) {
         }
     } else if (BQN(phase) == bq::PH_MAIN) {
         label = bq::after_eval(B, f);
+    } else if (BQN(phase) == bq::PH_RESCUE) {
+        label = bq::rescue_consume(B, f);
     }
     return bq::run(B, label);
 }

@@ -30,6 +30,5 @@ extern "C" int orc_port_bobyqa(int n, int npt, double *x, const double *lb, cons
     for (int i = 0; i < 3; i++) x[i] = BQA(xfinal, i);
     *minf = BQS(minf);
     *nevals = BQN(nevals);
-    const int rc = BQN(rc);
-    return rc == BQ_NEED_RESCUE ? -4 : rc; /* the reference would have entered rescue_; report as roundoff-limited */
+    return BQN(rc);
 }

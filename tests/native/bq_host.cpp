@@ -2,6 +2,8 @@
 // interface, so CPU tests can pin it against the genuine NLopt library (oracle/_ref).
 #include <cstring>
 #include <vector>
+static int g_rescue_calls = 0;
+#define BQ_ON_RESCUE() (++g_rescue_calls)
 #include "../../hpmvs_amd/csrc/bobyqa3.hpp"
 
 using namespace hpmvs;
@@ -25,3 +27,5 @@ extern "C" int bq3_minimize(obj_fn f, void* data, double* x, const double* lb, c
     *nevals = BQN(nevals);
     return BQN(rc);
 }
+
+extern "C" int bq3_rescue_calls(void) { return g_rescue_calls; }

@@ -218,3 +218,33 @@ def test_oracle_port_optimizer_matches_goldens():
         if e["ok"]:
             assert list(p.center) == e["center"] and list(p.normal) == e["normal"] and p.fmin == e["fmin"]
             assert list(p.images[:p.n_images]) == e["images"] and list(p.x) == e["x"]
+
+
+RESCUE_CASES = [  # (kind, a, s, noise, x0): ill-conditioned objectives on which NLopt's BOBYQA enters rescue_
+    (4, [-1.9039880916551473, 1.69248636262446, -1.369685985881047], [6.152572925353623, 56.517241772889946, 0.0002489585797884542], 3.0317759218000194e-16, [0.0, 19.4813337423983, 12.695605723116252]),
+    (1, [-0.3992117566688811, -2.606732510890745, 2.8005725554735585], [6.884420230043341e-05, 34648.52026624286, 2.0117775241722318], 2.66867639208926e-12, [0.0, -16.793670915947114, 2.5967343902664624]),
+    (1, [-1.2579546175189715, -2.874309151748932, 1.3936987839033321], [346721.3776461717, 54678.82911979567, 2.834553713842278e-06], 2.927378988442418e-10, [0.0, -12.364892581734033, -7.867755115566602]),
+    (4, [-2.433986742035881, 1.6288267275663912, -0.3393601747456314], [4427.927587161197, 1.4976780209465711e-06, 1016.401587583033], 5.725719474515975e-11, [0.0, 18.77833087914778, -9.93920264250701]),
+    (4, [0.5088616765616165, 1.1174748253028914, -0.056809479498919124], [0.20493953744179375, 0.02510084323688204, 1.1206323127137545], 1.8458239266018465e-13, [0.0, -19.189624956172324, 16.606295267485464]),
+    (4, [2.7660534135211163, -0.10595690236464961, 2.9627016286266548], [542.349530812418, 4.2357497219462275e-06, 178271.61866778892], 0.000550553199579394, [0.0, -3.173586577067468, -19.08561686857814]),
+]
+
+
+@pytest.mark.skipif(not _has_ref(), reason="oracle/_ref (genuine NLopt BOBYQA) not built on this box")
+@pytest.mark.parametrize("case", range(len(RESCUE_CASES)))
+def test_rescue_path_is_bit_identical_to_genuine_bobyqa(case):
+    """rescue_ (bobyqa.c:143-742) never triggers on the photometric objective (0 of 1.1 M benchmark patches), so
+    it is pinned on ill-conditioned synthetic objectives where the genuine library does call it."""
+    import ctypes as C
+    from helpers import bq_host
+    kind, a, s, noise, x0 = RESCUE_CASES[case]
+    if kind == 1:
+        f = lambda x: sum(s[i] * (x[i] - a[i]) ** 2 for i in range(3)) + noise * math.sin(1e6 * x[0] + 1e5 * x[1])
+    else:
+        f = lambda x: math.exp(min(50, s[0] * 1e-3 * (x[0] - a[0]))) + (x[1] * x[2] - a[1]) ** 2
+    H = bq_host()
+    H.bq3_rescue_calls.restype = C.c_int
+    before = H.bq3_rescue_calls()
+    (ref, mine), (tr0, tr1) = minimize_both(f, x0)
+    assert H.bq3_rescue_calls() > before, "case no longer exercises rescue_"
+    assert ref == mine and [t[0] for t in tr0] == [t[0] for t in tr1]
