@@ -62,7 +62,6 @@ enum { BQ_CONTINUE = 0, BQ_DONE = 1 };
 enum {
     BQ_FAILURE = -1, BQ_INVALID_ARGS = -2, BQ_ROUNDOFF_LIMITED = -4,
     BQ_SUCCESS = 1, BQ_XTOL_REACHED = 4, BQ_MAXEVAL_REACHED = 5,
-    BQ_NEED_RESCUE = -100
 };
 
 // ---- state storage ------------------------------------------------------------------------

@@ -27,6 +27,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "cr_acos.hpp"
 #include "dev_types.h"
 
 #include "prof.h"
@@ -551,7 +552,7 @@ __device__ __forceinline__ void parameters_from_center_norm(const OptFields& F, 
         const double cosa = (double)(-fz / cosb);
         double u = (-1.0 < cosa) ? cosa : -1.0;
         u = (u < 1.0) ? u : 1.0;
-        x[1] = acos(u);
+        x[1] = cra::acos_cr(u, acos(u));  // rounded to nearest like the host libm (cr_acos.hpp)
         if (sina < 0.0) x[1] = -x[1];
     }
     x[1] /= (double)o.angle_scale;

@@ -4,6 +4,7 @@
 #include <vector>
 static int g_rescue_calls = 0;
 #define BQ_ON_RESCUE() (++g_rescue_calls)
+#include "../../hpmvs_amd/csrc/cr_acos.hpp"
 #include "../../hpmvs_amd/csrc/bobyqa3.hpp"
 
 using namespace hpmvs;
@@ -29,3 +30,8 @@ extern "C" int bq3_minimize(obj_fn f, void* data, double* x, const double* lb, c
 }
 
 extern "C" int bq3_rescue_calls(void) { return g_rescue_calls; }
+
+// host build of the device's round-to-nearest acos (hpmvs_amd/csrc/cr_acos.hpp)
+extern "C" void cr_acos_host(const double* u, const double* y0, double* out, long n) {
+    for (long i = 0; i < n; i++) out[i] = cra::acos_cr(u[i], y0[i]);
+}

@@ -248,3 +248,35 @@ def test_rescue_path_is_bit_identical_to_genuine_bobyqa(case):
     (ref, mine), (tr0, tr1) = minimize_both(f, x0)
     assert H.bq3_rescue_calls() > before, "case no longer exercises rescue_"
     assert ref == mine and [t[0] for t in tr0] == [t[0] for t in tr1]
+
+
+def test_cr_acos_matches_host_libm():
+    """The device rounds acos to nearest (hpmvs_amd/csrc/cr_acos.hpp) so that the BOBYQA start point
+    x[1] = acos(u)/angleScale (reference PatchOptimizer.cpp:438) equals what the host libm gives the
+    reference.  Host build of the same header, started from values up to 2 ulp off: it must land on
+    the host libm's acos for >= 99.9% of arguments (glibc's own error bound is 0.5x ulp, i.e. it is
+    not correctly rounded for a few arguments in ten thousand) and never be more than 1 ulp away."""
+    import ctypes as C
+    from helpers import bq_host
+    H = bq_host()
+    H.cr_acos_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+    rng = np.random.default_rng(5)
+    n = 400000
+    u = rng.uniform(-1, 1, n)
+    u[::7] = u[::7].astype(np.float32)                  # float-valued ratios like -fz/cosb
+    u[::11] = 1.0 - np.abs(u[::11]) * 1e-6              # near the clamp
+    u[::13] = -1.0 + np.abs(u[::13]) * 1e-6
+    u[:4] = [1.0, -1.0, 0.0, 0.5]
+    g = np.array([math.acos(t) for t in u])            # the C library's acos (numpy may use a SIMD one)
+    y0 = g.copy()
+    steps = (np.arange(n) % 5) - 2
+    for k in (1, 2):
+        y0 = np.where(steps >= k, np.nextafter(y0, 4.0), y0)
+        y0 = np.where(steps <= -k, np.nextafter(y0, -4.0), y0)
+    out = np.empty(n)
+    H.cr_acos_host(u.ctypes.data, y0.ctypes.data, out.ctypes.data, n)
+    same = out == g
+    assert same.mean() >= 0.999, same.mean()
+    bad = ~same
+    assert np.all((out[bad] == np.nextafter(g[bad], 4.0)) | (out[bad] == np.nextafter(g[bad], -4.0)))
+    assert out[0] == 0.0 and out[1] == np.pi and out[2] == np.pi / 2
