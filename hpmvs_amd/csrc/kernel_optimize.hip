@@ -394,27 +394,18 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
         { const long long t1 = clock64(); tA += t1 - t0; t0 = t1; nrounds++; nreq += __popcll(pending); }
 #endif
         if (pending == 0ull) break;  // every lane idle and nothing posted: queue drained
-        while (pending) {
-            const int p = __ffsll((long long)pending) - 1;
-            pending &= pending - 1ull;
-            const int opp = bcast_i(op, p);
-            const float pc[3] = {bcast_f(c[0], p), bcast_f(c[1], p), bcast_f(c[2], p)};
-            const float pn[3] = {bcast_f(n[0], p), bcast_f(n[1], p), bcast_f(n[2], p)};
-            const float pscale = bcast_f(scale, p);
-            const int pnimg = bcast_i(nimg, p);
-            const int pref = (opp == OP_OBJ) ? 0 : bcast_i(req_ref, p);
-            const int prob = bcast_i(req_robust, p);
-            const uint16_t* prow = &lists[p * kRow];
-            const float pax[3] = {bcast_f(ax[0], p), bcast_f(ax[1], p), bcast_f(ax[2], p)};
-            const float pay[3] = {bcast_f(ay[0], p), bcast_f(ay[1], p), bcast_f(ay[2], p)};
-            const float paz[3] = {bcast_f(az[0], p), bcast_f(az[1], p), bcast_f(az[2], p)};
-            const EvalResult r = wave_eval_exact(sc, o, prow, pnimg, pref, pc, pn, pscale, pax, pay, paz,
-                                                 opp == OP_OBJ ? 1 : 0, prob, evlds);
-            const float thr = bcast_f(req_thr, p);
-            unsigned long long keep = __ballot(r.incc_lane < 1.0f - thr);
-            if (lane == p) {
+        {
+            PackedReq q;
+            q.obj_mode = (op == OP_OBJ) ? 1 : 0;
+            q.ref = req_ref; q.robust = req_robust; q.nimg = nimg; q.thr = req_thr;
+            q.scale = scale;
+            for (int k = 0; k < 3; k++) { q.c[k] = c[k]; q.zax[k] = (op == OP_OBJ) ? az[k] : n[k]; q.px[k] = ax[k]; q.py[k] = ay[k]; }
+            PackedRes r;
+            r.obj = 2.0; r.keep = 0ull; r.incc_sum = 0.0f; r.ngrabs = 0;
+            wave_eval_packed<kRow>(sc, o, lists, pending, q, r, evlds);
+            if (op != OP_NONE) {
                 res_f = r.obj;
-                res_mask = keep;
+                res_mask = r.keep;
                 res_sum = r.incc_sum;
                 ngrabs += r.ngrabs;
                 op = OP_NONE;

@@ -356,7 +356,8 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
         }
         wave_lds_sync();
         PH_T(t4);
-        
+        PH_ADD(t3, t4, 14);
+
         // ---- 2. channel means (Patch2d.hpp:51-58): lane m*3+c adds the 49 texels of plane c of slot m in order
         {
             const int m = lane / 3, ch = lane - 3 * m;
@@ -381,7 +382,8 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
         }
         wave_lds_sync();
         PH_T(t5);
-        
+        PH_ADD(t4, t5, 15);
+
         // ---- 4. normalise (Patch2d.hpp:75-83) in registers; products with the reference texture
         //         (Patch2d.hpp:41) staged in the reference's element order (pixel*3 + channel)
 #pragma unroll
@@ -401,12 +403,14 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
         }
         wave_lds_sync();
         PH_T(t6);
-        
+        PH_ADD(t5, t6, 20);
+
         // ---- 5. NCC: lane m adds the 147 products in order (Patch2d.hpp:37-44)
         float raw = 2.0f;
         if (lane >= 1 && lane <= nm) raw = 1.0f - seq_sum<147>(&L.buf[lane * kTexStride]) / 147.0f;
         PH_T(t7);
-        
+        PH_ADD(t6, t7, 21);
+
         // ---- deliver in ascending image order
         for (int s = 1; s <= nm; s++) {
             const int v = bcast_i(member, s);
@@ -421,6 +425,8 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
         }
         wave_lds_sync();
         first = false;
+        PH_T(t8);
+        PH_ADD(t7, t8, 22);
     }
     res.ngrabs = ngr;
     if (obj_mode) {
@@ -432,6 +438,266 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
         res.incc_sum = s;
     }
     return res;
+}
+
+// ------------------------------------------------------------------------------------------
+// PACKED exact-order evaluator: every request a wave has pending, in one pass.
+//
+// wave_eval_exact serves ONE request and leaves most lanes idle: a typical objective_fn request has
+// 3-4 usable images, i.e. 3-4 of the 8 staging slots, 3-4 lanes on the sequential sums, 3-4 lanes of
+// prep_image.  All of that is latency, not throughput (profiles/r02: 17 k cycles per request with
+// the wave alone on its CU).  Here the (request, image) pairs of ALL pending requests become "jobs":
+//   1. one lane per job runs prep_image (request data fetched from the requesting lane with
+//      ds_bpermute);
+//   2. the usable jobs are laid out as one sequence -- per request: reference image first, then the
+//      other images in ascending index -- and cut into chunks of 8 staging slots, regardless of
+//      request boundaries (the normalised reference texel and the per-request accumulators live in
+//      registers and simply persist across a cut);
+//   3. each chunk runs the same five steps as wave_eval_exact (fetch+stage, channel means, variance,
+//      normalise+products, 147-term sum); results are delivered per request in image order.
+// Per image the float32 operations and their order are exactly those of wave_eval_exact (and of the
+// reference); only the interleaving of independent images changes.
+struct PackedReq {   // registers of the requesting lane (valid where its `pending` bit is set)
+    int obj_mode;    // 1: objective_fn (reference image = list[0]); 0: setINCCs against list[ref]
+    int ref, robust, nimg;
+    float thr;       // filterImagesNCC threshold (INCC requests)
+    float c[3], zax[3], scale, px[3], py[3];  // zax: patch z axis (OBJ) or the raw normal (INCC), as sampleTexture's angle gate uses them
+};
+struct PackedRes {
+    double obj;               // OBJ
+    unsigned long long keep;  // INCC: bit v set <=> inccs[v] < 1 - thr
+    float incc_sum;           // INCC: sequential float sum of inccs
+    int ngrabs;               // added to
+};
+
+__device__ __forceinline__ float shfl_f(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ int shfl_i(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+
+// lists: LDS rows of ROW uint16 image ids, row p belongs to lane p.  Must be called by all 64 lanes.
+template <int ROW>
+__device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOptions& o, const uint16_t* lists,
+                                                 unsigned long long pending, const PackedReq& q, PackedRes& out,
+                                                 EvalLds& L) {
+    constexpr int S = kChunk + 1;  // staging slots
+    const int lane = lane_id();
+    const bool active = lane < kTexPix;
+    const int sl = active ? lane : kTexPix - 1;
+    const int iyy = sl / kTex, ixx = sl % kTex;
+    const int q_refsel = q.obj_mode ? 0 : q.ref;
+
+    unsigned long long rem = pending;
+    while (rem) {
+        // ---- a batch of requests whose jobs fit the 64 lanes (at least one request)
+        unsigned long long batch = 0ull;
+        int J = 0;
+        for (unsigned long long t = rem; t; t &= t - 1ull) {
+            const int p = __ffsll((long long)t) - 1;
+            const int np = bcast_i(q.nimg, p);
+            if (batch && J + np > 64) break;
+            batch |= 1ull << p;
+            J += np;
+        }
+        rem &= ~batch;
+        PH_T(t1);
+        // ---- job of this lane: (request myp, image index myi)
+        int myp = -1, myi = 0;
+        {
+            int off = 0;
+            for (unsigned long long t = batch; t; t &= t - 1ull) {
+                const int p = __ffsll((long long)t) - 1;
+                const int np = bcast_i(q.nimg, p);
+                if (lane >= off && lane < off + np) { myp = p; myi = lane - off; }
+                off += np;
+            }
+        }
+        const int src = myp >= 0 ? myp : 0;
+        float c[3], zax[3], pxa[3], pya[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            c[k] = shfl_f(q.c[k], src); zax[k] = shfl_f(q.zax[k], src);
+            pxa[k] = shfl_f(q.px[k], src); pya[k] = shfl_f(q.py[k], src);
+        }
+        const float scale = shfl_f(q.scale, src);
+        Prep P;
+        P.ok = 0; P.tlx = P.tly = P.dxx = P.dxy = P.dyx = P.dyy = 0.0f; P.pix = nullptr; P.W = 0;
+        if (myp >= 0) P = prep_image(sc.views[(int)lists[myp * ROW + myi]], o, c, scale, pxa, pya, zax);
+        const unsigned long long okmask = __ballot(P.ok != 0);
+        PH_T(t2);
+        PH_ADD(t1, t2, 13);
+
+        // ---- position of every usable job in the slot sequence
+        int pos = -1;
+        bool isref = false;
+        int E = 0;
+        unsigned long long refok = 0ull;  // requests whose reference image passed the gates
+        {
+            int off = 0;
+            for (unsigned long long t = batch; t; t &= t - 1ull) {
+                const int p = __ffsll((long long)t) - 1;
+                const int np = bcast_i(q.nimg, p);
+                const int refp = bcast_i(q_refsel, p);
+                if (np > 0 && ((okmask >> (off + refp)) & 1ull)) {
+                    refok |= 1ull << p;
+                    const unsigned long long R = (np >= 64 ? ~0ull : ((1ull << np) - 1ull)) << off;
+                    const unsigned long long okr = okmask & R;
+                    const unsigned long long others = okr & ~(1ull << (off + refp));
+                    if (myp == p && P.ok) {
+                        if (myi == refp) { pos = E; isref = true; }
+                        else pos = E + 1 + __popcll(others & ((1ull << lane) - 1ull));
+                    }
+                    E += __popcll(okr);
+                }
+                off += np;
+            }
+        }
+        const unsigned long long refjobs = __ballot(isref);
+
+        // ---- per-request running state (persists across chunk cuts)
+        int cur = -1, cur_obj = 0, cur_rob = 0, nok = 0, ngr = 0;
+        double val = 0.0;
+        float mine = 2.0f;
+        float refn0 = 0.0f, refn1 = 0.0f, refn2 = 0.0f;
+        auto finalize = [&]() {
+            if (cur_obj) {
+                const double f = (nok < o.MIN_IMAGES_PER_PATCH - 1) ? 2.0 : val / (double)nok;
+                if (lane == cur) { out.obj = f; out.ngrabs += ngr; }
+            } else {
+                const int np = bcast_i(q.nimg, cur);
+                float s = 0.0f;
+                for (int k = 0; k < np; k++) s += bcast_f(mine, k);
+                const float thr = bcast_f(q.thr, cur);
+                const unsigned long long keep = __ballot(mine < 1.0f - thr);
+                if (lane == cur) { out.keep = keep; out.incc_sum = s; out.ngrabs += ngr; }
+            }
+        };
+
+        for (int cb = 0; cb < E; cb += S) {
+            const int ns = (E - cb < S) ? E - cb : S;
+            PH_T(t3);
+            // job lane of every slot (wave-uniform), also kept per lane for the dynamic delivery loop
+            int jl[S];
+            int jlv = 0;
+            unsigned int refslots = 0u;
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                const unsigned long long m = __ballot(pos == cb + s);
+                jl[s] = m ? __ffsll((long long)m) - 1 : 0;
+                if (lane == s) jlv = jl[s];
+                if (s < ns && ((refjobs >> jl[s]) & 1ull)) refslots |= 1u << s;
+            }
+            // ---- 1. fetch + stage
+            Taps taps[S];
+            float rr[S], gg[S], bb[S];
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                if (s < ns) {
+                    const int v = jl[s];
+                    taps[s] = issue_taps(bcast_f(P.tlx, v), bcast_f(P.tly, v), bcast_f(P.dxx, v), bcast_f(P.dxy, v),
+                                         bcast_f(P.dyx, v), bcast_f(P.dyy, v), bcast_p(P.pix, v), bcast_i(P.W, v), ixx, iyy);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                rr[s] = gg[s] = bb[s] = 0.0f;
+                if (s < ns) {
+                    texel(taps[s], rr[s], gg[s], bb[s]);
+                    if (active) {
+                        float* bp = &L.buf[s * kTexStride];
+                        bp[lane] = rr[s]; bp[kPlane + lane] = gg[s]; bp[2 * kPlane + lane] = bb[s];
+                    }
+                }
+            }
+            wave_lds_sync();
+            PH_T(t4);
+            PH_ADD(t3, t4, 14);
+            // ---- 2. channel means
+            {
+                const int m = lane / 3, ch = lane - 3 * m;
+                if (m < ns) L.ave[m * 4 + ch] = seq_sum<49>(&L.buf[m * kTexStride + ch * kPlane]) / 49.0f;
+            }
+            wave_lds_sync();
+            // ---- 3. variance
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                if (s < ns && active) {
+                    const float4 av = *reinterpret_cast<const float4*>(&L.ave[s * 4]);
+                    const float f0 = av.x - rr[s], f1 = av.y - gg[s], f2 = av.z - bb[s];
+                    L.buf[s * kTexStride + lane] = f0 * f0 + f1 * f1 + f2 * f2;
+                }
+            }
+            wave_lds_sync();
+            if (lane < ns) {
+                float v2 = sqrtf(seq_sum<49>(&L.buf[lane * kTexStride]) / 147.0f);
+                if (v2 == 0.0f) v2 = 1.0f;
+                L.ave[lane * 4 + 3] = v2;
+            }
+            wave_lds_sync();
+            PH_T(t5);
+            PH_ADD(t4, t5, 15);
+            // ---- 4. normalise; products with the request's reference texel
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                if (s < ns) {
+                    const float4 av = *reinterpret_cast<const float4*>(&L.ave[s * 4]);
+                    float r = rr[s], g = gg[s], b = bb[s];
+                    r -= av.x; r /= av.w;
+                    g -= av.y; g /= av.w;
+                    b -= av.z; b /= av.w;
+                    if ((refslots >> s) & 1u) { refn0 = r; refn1 = g; refn2 = b; }
+                    else if (active) {
+                        float* bp = &L.buf[s * kTexStride + 3 * lane];
+                        bp[0] = refn0 * r; bp[1] = refn1 * g; bp[2] = refn2 * b;
+                    }
+                }
+            }
+            wave_lds_sync();
+            PH_T(t6);
+            PH_ADD(t5, t6, 20);
+            // ---- 5. NCC sums
+            float raw = 2.0f;
+            if (lane < ns && !((refslots >> lane) & 1u)) raw = 1.0f - seq_sum<147>(&L.buf[lane * kTexStride]) / 147.0f;
+            PH_T(t7);
+            PH_ADD(t6, t7, 21);
+            // ---- deliver in sequence order
+            for (int s = 0; s < ns; s++) {
+                const int v = bcast_i(jlv, s);
+                if ((refslots >> s) & 1u) {
+                    if (cur >= 0) finalize();
+                    cur = bcast_i(myp, v);
+                    cur_obj = bcast_i(q.obj_mode, cur);
+                    cur_rob = bcast_i(q.robust, cur);
+                    const int refi = bcast_i(myi, v);
+                    val = 0.0; nok = 0; ngr = 1;
+                    mine = (lane == refi) ? 0.0f : 2.0f;
+                } else {
+                    const float e = bcast_f(raw, s);
+                    ngr++;
+                    if (cur_obj) { val += (double)robustincc(e); nok++; }
+                    else if (lane == bcast_i(myi, v)) mine = cur_rob ? robustincc(e) : e;
+                }
+            }
+            wave_lds_sync();
+            PH_T(t8);
+            PH_ADD(t7, t8, 22);
+        }
+        if (cur >= 0) finalize();
+        // ---- requests whose reference image failed the gates (sampleTexture false for image `ref`)
+        for (unsigned long long t = batch & ~refok; t; t &= t - 1ull) {
+            const int p = __ffsll((long long)t) - 1;
+            const int np = bcast_i(q.nimg, p);
+            if (lane == p) {
+                if (q.obj_mode) out.obj = 2.0;
+                else {
+                    float s = 0.0f;
+                    for (int k = 0; k < np; k++) s += 2.0f;
+                    out.keep = 0ull;
+                    out.incc_sum = s;
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
