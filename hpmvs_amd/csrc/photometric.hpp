@@ -180,6 +180,16 @@ __device__ __forceinline__ uint2 load8(const uint8_t* p) {
     return v;
 }
 
+// Correctly rounded float32 division through float64.  For float a, w the quotient a/w lies at a relative
+// distance > 2^-49 from every rounding boundary of the float32 format (a 25-bit midpoint m would need
+// a = m*w, i.e. |a - m*w| >= 1 unit of a 49-bit product), while (double)a * RN(1/(double)w) is within
+// 2^-52 of a/w: rounding it to float32 therefore gives exactly RN(a/w), the value the CPU's divss
+// returns -- with one reciprocal per DIVISOR instead of a ~11-instruction IEEE division sequence per
+// quotient (the divisor is shared by 147 texels, or is a constant).  Results stay far from the
+// denormal range here (|a| is 0 or >= 2^-20, w <= 256).
+__device__ __forceinline__ double recip64(float w) { return 1.0 / (double)w; }
+__device__ __forceinline__ float div_by(float a, double inv_w) { return (float)((double)a * inv_w); }
+
 __device__ __forceinline__ float robustincc(float rhs) { return rhs / (1 + 3 * rhs); }  // PatchOptimizer.h:92-94
 
 struct EvalResult {
@@ -214,6 +224,7 @@ constexpr int kTexStride = 164;      // floats per staging slot (16-byte multipl
 struct alignas(16) EvalLds {
     float buf[(kChunk + 1) * kTexStride];  // slot 0: reference image, slots 1..kChunk: chunk members
     float ave[(kChunk + 1) * 4];           // per slot: channel means, then sqrt(variance)
+    double inv[kChunk + 1];                // per slot: 1 / sqrt(variance) in float64 (see div_by)
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -251,11 +262,13 @@ struct Taps { uint2 a, b; float f00, f01, f10, f11; };
 // c += dx per column, PatchOptimizer.cpp:511-526), and the two tap loads
 __device__ __forceinline__ Taps issue_taps(float tlx, float tly, float dxx, float dxy, float dyx, float dyy,
                                            const uint8_t* pix, int W, int ixx, int iyy) {
+    // x += step taken `iyy` / `ixx` times: fma(m, step, x) with m in {0, 1} is the same single rounding
+    // as x + step (m*step is exact) and leaves x untouched for m = 0
     float x = tlx, y = tly;
 #pragma unroll
-    for (int k = 0; k < kTex - 1; k++) { if (k < iyy) { x += dyx; y += dyy; } }
+    for (int k = 0; k < kTex - 1; k++) { const float m = (k < iyy) ? 1.0f : 0.0f; x = __builtin_fmaf(m, dyx, x); y = __builtin_fmaf(m, dyy, y); }
 #pragma unroll
-    for (int k = 0; k < kTex - 1; k++) { if (k < ixx) { x += dxx; y += dxy; } }
+    for (int k = 0; k < kTex - 1; k++) { const float m = (k < ixx) ? 1.0f : 0.0f; x = __builtin_fmaf(m, dxx, x); y = __builtin_fmaf(m, dxy, y); }
     const int lx = (int)x, ly = (int)y;
     const uint8_t* p0 = pix + 3 * (ly * W + lx);
     Taps t;
@@ -361,7 +374,7 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
         // ---- 2. channel means (Patch2d.hpp:51-58): lane m*3+c adds the 49 texels of plane c of slot m in order
         {
             const int m = lane / 3, ch = lane - 3 * m;
-            if (m >= s0 && m <= nm) L.ave[m * 4 + ch] = seq_sum<49>(&L.buf[m * kTexStride + ch * kPlane]) / 49.0f;
+            if (m >= s0 && m <= nm) L.ave[m * 4 + ch] = div_by(seq_sum<49>(&L.buf[m * kTexStride + ch * kPlane]), 1.0 / 49.0);
         }
         wave_lds_sync();
         // ---- 3. squared deviations per pixel (Patch2d.hpp:62-69), computed by the pixel lanes ...
@@ -376,9 +389,9 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
         wave_lds_sync();
         // ---- ... and summed in pixel order by lane m
         if (lane >= s0 && lane <= nm) {
-            float v2 = sqrtf(seq_sum<49>(&L.buf[lane * kTexStride]) / 147.0f);
+            float v2 = sqrtf(div_by(seq_sum<49>(&L.buf[lane * kTexStride]), 1.0 / 147.0));
             if (v2 == 0.0f) v2 = 1.0f;
-            L.ave[lane * 4 + 3] = v2;
+            L.inv[lane] = recip64(v2);
         }
         wave_lds_sync();
         PH_T(t5);
@@ -391,9 +404,10 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
             if (s >= s0 && s <= nm) {
                 const float4 av = *reinterpret_cast<const float4*>(&L.ave[s * 4]);
                 float r = rr[s], g = gg[s], b = bb[s];
-                r -= av.x; r /= av.w;
-                g -= av.y; g /= av.w;
-                b -= av.z; b /= av.w;
+                const double iv = L.inv[s];
+                r -= av.x; r = div_by(r, iv);
+                g -= av.y; g = div_by(g, iv);
+                b -= av.z; b = div_by(b, iv);
                 if (s == 0) { refn0 = r; refn1 = g; refn2 = b; }
                 else if (active) {
                     float* bp = &L.buf[s * kTexStride + 3 * lane];
@@ -407,7 +421,7 @@ __device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const 
 
         // ---- 5. NCC: lane m adds the 147 products in order (Patch2d.hpp:37-44)
         float raw = 2.0f;
-        if (lane >= 1 && lane <= nm) raw = 1.0f - seq_sum<147>(&L.buf[lane * kTexStride]) / 147.0f;
+        if (lane >= 1 && lane <= nm) raw = 1.0f - div_by(seq_sum<147>(&L.buf[lane * kTexStride]), 1.0 / 147.0);
         PH_T(t7);
         PH_ADD(t6, t7, 21);
 
@@ -615,7 +629,7 @@ __device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOp
             // ---- 2. channel means
             {
                 const int m = lane / 3, ch = lane - 3 * m;
-                if (m < ns) L.ave[m * 4 + ch] = seq_sum<49>(&L.buf[m * kTexStride + ch * kPlane]) / 49.0f;
+                if (m < ns) L.ave[m * 4 + ch] = div_by(seq_sum<49>(&L.buf[m * kTexStride + ch * kPlane]), 1.0 / 49.0);
             }
             wave_lds_sync();
             // ---- 3. variance
@@ -629,9 +643,9 @@ __device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOp
             }
             wave_lds_sync();
             if (lane < ns) {
-                float v2 = sqrtf(seq_sum<49>(&L.buf[lane * kTexStride]) / 147.0f);
+                float v2 = sqrtf(div_by(seq_sum<49>(&L.buf[lane * kTexStride]), 1.0 / 147.0));
                 if (v2 == 0.0f) v2 = 1.0f;
-                L.ave[lane * 4 + 3] = v2;
+                L.inv[lane] = recip64(v2);
             }
             wave_lds_sync();
             PH_T(t5);
@@ -642,9 +656,10 @@ __device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOp
                 if (s < ns) {
                     const float4 av = *reinterpret_cast<const float4*>(&L.ave[s * 4]);
                     float r = rr[s], g = gg[s], b = bb[s];
-                    r -= av.x; r /= av.w;
-                    g -= av.y; g /= av.w;
-                    b -= av.z; b /= av.w;
+                    const double iv = L.inv[s];
+                    r -= av.x; r = div_by(r, iv);
+                    g -= av.y; g = div_by(g, iv);
+                    b -= av.z; b = div_by(b, iv);
                     if ((refslots >> s) & 1u) { refn0 = r; refn1 = g; refn2 = b; }
                     else if (active) {
                         float* bp = &L.buf[s * kTexStride + 3 * lane];
@@ -657,7 +672,8 @@ __device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOp
             PH_ADD(t5, t6, 20);
             // ---- 5. NCC sums
             float raw = 2.0f;
-            if (lane < ns && !((refslots >> lane) & 1u)) raw = 1.0f - seq_sum<147>(&L.buf[lane * kTexStride]) / 147.0f;
+            if (lane < ns && !((refslots >> lane) & 1u)) raw = 1.0f - div_by(seq_sum<147>(&L.buf[lane * kTexStride]), 1.0 / 147.0);
+            const float rob = robustincc(raw);  // lane-parallel: one division for the whole chunk
             PH_T(t7);
             PH_ADD(t6, t7, 21);
             // ---- deliver in sequence order
@@ -672,10 +688,9 @@ __device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOp
                     val = 0.0; nok = 0; ngr = 1;
                     mine = (lane == refi) ? 0.0f : 2.0f;
                 } else {
-                    const float e = bcast_f(raw, s);
                     ngr++;
-                    if (cur_obj) { val += (double)robustincc(e); nok++; }
-                    else if (lane == bcast_i(myi, v)) mine = cur_rob ? robustincc(e) : e;
+                    if (cur_obj) { val += (double)bcast_f(rob, s); nok++; }
+                    else if (lane == bcast_i(myi, v)) mine = cur_rob ? bcast_f(rob, s) : bcast_f(raw, s);
                 }
             }
             wave_lds_sync();
