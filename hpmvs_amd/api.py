@@ -50,6 +50,7 @@ EXPORTS = [
     "hpmvs_scene_create", "hpmvs_scene_set_view", "hpmvs_scene_set_covis", "hpmvs_scene_commit",
     "hpmvs_scene_destroy", "hpmvs_scene_get_level", "hpmvs_scene_bytes", "hpmvs_build_pyramid",
     "hpmvs_optimize_batch", "hpmvs_init_patches_batch", "hpmvs_objective_batch", "hpmvs_inccs_batch", "hpmvs_last_kernel_ms",
+    "hpmvs_expand_batch", "hpmvs_expand_directions",
 ]
 
 _lib = None
@@ -85,6 +86,9 @@ def lib():
     L.hpmvs_inccs_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(PatchBatch), C.c_int, C.c_int,
                                     C.c_void_p, C.c_int, C.c_void_p]
     L.hpmvs_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.hpmvs_expand_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.POINTER(PatchBatch), C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.POINTER(PatchBatch), C.c_int, C.c_void_p]
+    L.hpmvs_expand_directions.argtypes = [C.c_int, C.c_void_p]
     _lib = L
     return L
 
@@ -234,6 +238,37 @@ def init_patches_batch(scene: Scene, xyz, meas_off, meas_img, start_level=4, max
     _chk(lib().hpmvs_init_patches_batch(scene.h, C.byref(o), start_level, n, xyz.ctypes.data, off.ctypes.data,
                                         img.ctypes.data if len(img) else None, C.byref(b), 0, None))
     return batch
+
+
+EXPAND_EXTEND, EXPAND_BRANCH = 0, 1
+
+
+def expand_directions(mode: int) -> np.ndarray:
+    """(cos, sin) pairs of the candidate directions the expansion kernels use; needs no GPU."""
+    out = np.zeros(12, dtype=np.float32)
+    n = lib().hpmvs_expand_directions(mode, out.ctypes.data)
+    if n < 0:
+        _chk(n)
+    return out[:2 * n].reshape(n, 2)
+
+
+def expand_batch(scene: Scene, mode: int, parents: Batch, cell_center, cell_width, skip=None,
+                 options: Options | None = None) -> Batch:
+    """CellProcessor::extend (mode 0, 6 candidates) / ::branch (mode 1, 4 candidates) for a frontier of parent
+    cells (reference CellProcessor.cpp:84-178, 210-262): candidates built, optimized and gated on the GPU.
+    Returns the batch of n*N candidates (candidate k of parent i at i*N + k)."""
+    o = options or default_options()
+    N = 6 if mode == EXPAND_EXTEND else 4
+    n = parents.n
+    cc = np.ascontiguousarray(cell_center, dtype=np.float32).reshape(n, 3)
+    cw = np.ascontiguousarray(cell_width, dtype=np.float32).reshape(n)
+    sk = None if skip is None else np.ascontiguousarray(skip, dtype=np.uint8).reshape(n * N)
+    out = Batch(np.zeros((n * N, 4), np.float32), np.zeros((n * N, 4), np.float32), np.zeros(n * N, np.float32),
+                np.zeros(n * N, np.int32), np.full((n * N, parents.max_images), -1, np.int32))
+    pb, ob = parents.c_struct(), out.c_struct()
+    _chk(lib().hpmvs_expand_batch(scene.h, C.byref(o), mode, C.byref(pb), cc.ctypes.data, cw.ctypes.data,
+                                  None if sk is None else sk.ctypes.data, C.byref(ob), 0, None))
+    return out
 
 
 def objective_batch(scene: Scene, batch: Batch, x: np.ndarray, options: Options | None = None):

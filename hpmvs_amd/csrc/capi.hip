@@ -502,6 +502,71 @@ int hpmvs_init_patches_batch(const hpmvs_scene* s, const hpmvs_options* o, int s
     return HPMVS_OK;
 }
 
+int hpmvs_expand_directions(int mode, float* dxdy) {
+    if ((mode != HPMVS_EXPAND_EXTEND && mode != HPMVS_EXPAND_BRANCH) || !dxdy) return fail(HPMVS_ERR_ARG, "expand_directions: bad mode/pointer");
+    const int N = expand_fanout(mode);
+    for (int k = 0; k < 2 * N; k++) dxdy[k] = expand_direction_table(mode)[k];
+    return N;
+}
+
+int hpmvs_expand_batch(const hpmvs_scene* s, const hpmvs_options* o, int mode, const hpmvs_patch_batch* parents,
+                       const float* cell_center, const float* cell_width, const uint8_t* skip, hpmvs_patch_batch* out,
+                       int on_device, void* stream) {
+    if (mode != HPMVS_EXPAND_EXTEND && mode != HPMVS_EXPAND_BRANCH) return fail(HPMVS_ERR_ARG, "expand_batch: bad mode");
+    int rc = check_batch(s, o, parents);
+    if (rc) return rc;
+    if ((rc = check_batch_shape(s, o, out))) return rc;
+    const int N = expand_fanout(mode);
+    if (out->n != parents->n * N) return fail(HPMVS_ERR_ARG, "expand_batch: out->n must be parents->n * fan-out");
+    if (out->max_images != parents->max_images) return fail(HPMVS_ERR_ARG, "expand_batch: max_images mismatch");
+    if (parents->n > 0 && (!cell_center || !cell_width || !out->center || !out->normal || !out->scale || !out->n_images ||
+                           !out->images || !out->ok))
+        return fail(HPMVS_ERR_ARG, "expand_batch: missing array");
+    if (parents->n == 0) return HPMVS_OK;
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    Staged sp, sg;
+    if ((rc = stage_batch(sp, parents, on_device != 0, false))) return rc;
+    if ((rc = stage_batch(sg, out, on_device != 0, true, /*copy_inputs=*/false))) return rc;
+    const size_t n = (size_t)parents->n;
+    const float *dcc = cell_center, *dcw = cell_width;
+    const uint8_t* dskip = skip;
+    if (!on_device) {
+        float *tc = nullptr, *tw = nullptr;
+        uint8_t* ts = nullptr;
+        if ((rc = stage_in(sp, tc, cell_center, 3 * n, true))) return rc;
+        if ((rc = stage_in(sp, tw, cell_width, n, true))) return rc;
+        if ((rc = stage_in(sp, ts, skip, n * N, true))) return rc;
+        dcc = tc; dcw = tw; dskip = ts;
+    }
+    const DevOptions d = make_dev_options(o);
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        int32_t* q = (int32_t*)((char*)s->dqueue + (size_t)(s->next_slot++ % kQueueSlots) * kQueueSlotBytes);
+        s->last_queue = q;
+        launch_expand_init(dev_scene(s), mode, parents->n, sp.d, dcc, dcw, dskip, sg.d, st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemsetAsync(q, 0, kQueueSlotBytes, st));
+        HIPCHK(hipEventRecord(s->ev0, st));
+        launch_optimize(dev_scene(s), d, sg.d, q, s->n_cus, st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(s->ev1, st));
+        s->timed = true;
+        launch_expand_gate(mode, parents->n, sp.d, dcc, dcw, sg.d, st);
+        HIPCHK(hipGetLastError());
+    }
+    if (!on_device) {
+        HIPCHK(hipStreamSynchronize(st));
+        const DevBatch& D = sg.d;
+        const size_t m = (size_t)out->n;
+        if ((rc = stage_out(out->center, D.center, 4 * m))) return rc;
+        if ((rc = stage_out(out->normal, D.normal, 4 * m))) return rc;
+        if ((rc = stage_out(out->scale, D.scale, m))) return rc;
+        if ((rc = copy_outputs(out, D))) return rc;
+    }
+    return HPMVS_OK;
+}
+
 int hpmvs_objective_batch(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_patch_batch* b, const double* x,
                           double* f_out, int32_t* ngrabs_out, int on_device, void* stream) {
     int rc = check_batch(s, o, b);

@@ -207,4 +207,111 @@ void launch_drift_gate(int n, const double* xyz, const DevBatch& b, hipStream_t 
     hipLaunchKernelGGL(drift_gate_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, xyz, b);
 }
 
+// ------------------------------------------------------------------------------------------
+// Frontier expansion (reference src/hpmvs/CellProcessor.cpp:84-178 extend, :210-262 branch).
+//
+// Candidate directions: dx = std::cos(angle), dy = std::sin(angle) with the FLOAT angle
+// (float)(2*pi/N*i) (extend, N = 6) or (float)(2*pi/N*i + pi/4) (branch, N = 4), i.e. the C library's
+// cosf/sinf.  They are constants, tabulated here as the host libm (glibc 2.35) returns them;
+// tests/test_cpu_abi.py checks the table against the oracle's libm values.
+static const float kExtendDir[12] = {0x1p+0f, 0x0p+0f, 0x1.fffffep-2f, 0x1.bb67bp-1f, -0x1.000002p-1f, 0x1.bb67aep-1f,
+                                     -0x1p+0f, -0x1.777a5cp-24f, -0x1.fffffap-2f, -0x1.bb67bp-1f, 0x1.fffffap-2f, -0x1.bb67bp-1f};
+static const float kBranchDir[8] = {0x1.6a09e6p-1f, 0x1.6a09e6p-1f, -0x1.6a09e6p-1f, 0x1.6a09e6p-1f,
+                                    -0x1.6a09e8p-1f, -0x1.6a09e4p-1f, 0x1.6a09e2p-1f, -0x1.6a09eap-1f};
+struct DirTable { float d[12]; };
+
+int expand_fanout(int mode) { return mode == 0 ? 6 : 4; }
+const float* expand_direction_table(int mode) { return mode == 0 ? kExtendDir : kBranchDir; }
+
+// Cell::contains (doctree.cpp:38-42)
+__device__ __forceinline__ bool cell_contains(const float* cc, float width, const float* p) {
+    const float hw = (float)((double)width / 2.0);
+    return p[0] > cc[0] - hw && p[1] > cc[1] - hw && p[2] > cc[2] - hw && p[0] <= cc[0] + hw && p[1] <= cc[1] + hw &&
+           p[2] <= cc[2] + hw;
+}
+
+// one thread per candidate (CellProcessor.cpp:93-118, 218-244)
+__global__ void __launch_bounds__(256) expand_init_kernel(DevScene sc, int mode, int N, DirTable dirs, int n, DevBatch par,
+                                                          const float* __restrict__ cell_center,
+                                                          const float* __restrict__ cell_width,
+                                                          const uint8_t* __restrict__ skip, DevBatch out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * N) return;
+    const int i = t / N, k = t - i * N;
+    const float pc[4] = {par.center[4 * i], par.center[4 * i + 1], par.center[4 * i + 2], par.center[4 * i + 3]};
+    const float pn[4] = {par.normal[4 * i], par.normal[4 * i + 1], par.normal[4 * i + 2], par.normal[4 * i + 3]};
+    const int nimg = par.n_images[i];
+    const int32_t* prow = par.images + (size_t)i * par.max_images;
+    int32_t* row = out.images + (size_t)t * out.max_images;
+    int why = 0;
+    float c[3] = {pc[0], pc[1], pc[2]};
+    const float width = cell_width[i];
+    if (nimg <= 0 || nimg > out.max_images || prow[0] < 0 || prow[0] >= sc.n_views) why = 20;
+    else {
+        const DevView& V = sc.views[prow[0]];
+        float t0[3], yaxis[3], xaxis[3];
+        cross3f(pn, V.xaxis, t0);
+        normalized3f(t0, yaxis);
+        cross3f(yaxis, pn, xaxis);
+        const float dx = dirs.d[2 * k], dy = dirs.d[2 * k + 1];
+        const float ext = (mode == 0) ? width : (float)((double)width / 4.0);
+        for (int j = 0; j < 3; j++) c[j] = pc[j] + (dx * xaxis[j] + dy * yaxis[j]) * ext;
+        for (int j = 0; j < nimg; j++) row[j] = prow[j];
+        if (skip && skip[t]) why = 20;
+        if (mode == 1 && !cell_contains(cell_center + 3 * i, width, c)) why = 20;
+    }
+    out.center[4 * t] = c[0]; out.center[4 * t + 1] = c[1]; out.center[4 * t + 2] = c[2]; out.center[4 * t + 3] = pc[3];
+    out.normal[4 * t] = pn[0]; out.normal[4 * t + 1] = pn[1]; out.normal[4 * t + 2] = pn[2]; out.normal[4 * t + 3] = pn[3];
+    out.scale[t] = (float)((double)width * (mode == 0 ? 0.9 : 0.45) / 2.0);
+    out.n_images[t] = why ? -why : nimg;  // negative: not optimized, the refinement kernel reports -n as stage
+    out.ok[t] = 0;
+}
+
+// acceptance gates after optimize() (CellProcessor.cpp:131-133, 257)
+__global__ void __launch_bounds__(256) expand_gate_kernel(int mode, int N, int n, DevBatch par,
+                                                          const float* __restrict__ cell_center,
+                                                          const float* __restrict__ cell_width, DevBatch out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * N) return;
+    const int i = t / N;
+    if (out.ok[t]) {
+        const float width = cell_width[i];
+        const float c[3] = {out.center[4 * t], out.center[4 * t + 1], out.center[4 * t + 2]};
+        int why = 0;
+        if (mode == 0) {
+            const double s2 = (double)out.scale[t] * 2.0;
+            if (!(s2 < (double)width && s2 > (double)width / 2.0)) why = 21;
+            else {
+                const float d[3] = {c[0] - par.center[4 * i], c[1] - par.center[4 * i + 1], c[2] - par.center[4 * i + 2]};
+                const float w = out.center[4 * t + 3] - par.center[4 * i + 3];
+                const float nrm = sqrtf(dot3f(d, d) + w * w);  // Vector4f::norm()
+                if (!((double)nrm < (double)width * 1.5)) why = 22;
+            }
+        } else if (!cell_contains(cell_center + 3 * i, width, c)) why = 22;
+        if (why) {
+            out.ok[t] = 0;
+            if (out.stage) out.stage[t] = why;
+        }
+    }
+    if (out.n_images[t] < 0) out.n_images[t] = 0;
+}
+
+void launch_expand_init(const DevScene& sc, int mode, int n, const DevBatch& parents, const float* cell_center,
+                        const float* cell_width, const uint8_t* skip, const DevBatch& out, hipStream_t st) {
+    if (n <= 0) return;
+    const int N = expand_fanout(mode);
+    DirTable dt;
+    for (int k = 0; k < 12; k++) dt.d[k] = k < 2 * N ? expand_direction_table(mode)[k] : 0.0f;
+    hipLaunchKernelGGL(expand_init_kernel, dim3((n * N + 255) / 256), dim3(256), 0, st, sc, mode, N, dt, n, parents,
+                       cell_center, cell_width, skip, out);
+}
+
+void launch_expand_gate(int mode, int n, const DevBatch& parents, const float* cell_center, const float* cell_width,
+                        const DevBatch& out, hipStream_t st) {
+    if (n <= 0) return;
+    const int N = expand_fanout(mode);
+    hipLaunchKernelGGL(expand_gate_kernel, dim3((n * N + 255) / 256), dim3(256), 0, st, mode, N, n, parents, cell_center,
+                       cell_width, out);
+}
+
 }  // namespace hpmvs

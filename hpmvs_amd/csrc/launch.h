@@ -14,6 +14,13 @@ void launch_inccs(const DevScene& sc, const DevOptions& o, const DevBatch& b, in
 void launch_seed_init(const DevScene& sc, const DevOptions& o, int start_level, int n, const double* xyz,
                       const int32_t* meas_off, const int32_t* meas_img, const DevBatch& b, hipStream_t st);
 void launch_drift_gate(int n, const double* xyz, const DevBatch& b, hipStream_t st);
+// CellProcessor::extend / ::branch candidates (mode 0 / 1): parents -> out (n * N patches), and the gates after optimize
+int expand_fanout(int mode);
+const float* expand_direction_table(int mode);
+void launch_expand_init(const DevScene& sc, int mode, int n, const DevBatch& parents, const float* cell_center,
+                        const float* cell_width, const uint8_t* skip, const DevBatch& out, hipStream_t st);
+void launch_expand_gate(int mode, int n, const DevBatch& parents, const float* cell_center, const float* cell_width,
+                        const DevBatch& out, hipStream_t st);
 // workspace: one int32 work-queue counter (zeroed by the launcher on `st`)
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* queue_counter,
                      int n_cus, hipStream_t st);

@@ -432,4 +432,70 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
     return good;
 }
 
+int PatchOptimizer::expandBatch(ExpandMode mode, const mo3d::Patch3d* const* parents, const CellRef* cells, size_t n,
+                                const uint8_t* skip, std::vector<mo3d::Patch3d>& candidates,
+                                std::vector<uint8_t>& accepted) {
+    const int N = (mode == EXTEND) ? 6 : 4;
+    candidates.clear();
+    accepted.assign(n * N, 0);
+    lastF_.assign(n * N, 0.0);
+    lastEvals_.assign(n * N, 0);
+    if (n == 0) return N;
+    hpmvs_scene* dev = scene_p->deviceScene();
+    if (!dev) return N;
+    const int stride = HPMVS_MAX_IMAGES;
+    const size_t m = n * N;
+    std::vector<float> pc(4 * n), pn(4 * n), ps(n), cc(3 * n), cw(n);
+    std::vector<int32_t> pnimg(n), pimg(n * stride, -1);
+    for (size_t i = 0; i < n; i++) {
+        const Patch3d& p = *parents[i];
+        for (int k = 0; k < 4; k++) { pc[4 * i + k] = p.center_[k]; pn[4 * i + k] = p.normal_[k]; }
+        ps[i] = p.scale_3dx_;
+        pnimg[i] = (int32_t)p.images_.size();
+        for (size_t k = 0; k < p.images_.size() && k < (size_t)stride; k++) pimg[i * stride + k] = p.images_[k];
+        for (int k = 0; k < 3; k++) cc[3 * i + k] = cells[i].c[k];
+        cw[i] = cells[i].width;
+    }
+    std::vector<float> center(4 * m), normal(4 * m), scale(m), color(3 * m), ncc(m);
+    std::vector<int32_t> nimg(m), images(m * stride, -1), evals(m);
+    std::vector<double> fmin(m);
+    hpmvs_options o;
+    o.MAXLEVEL = options_p->MAXLEVEL; o.MINLEVEL = options_p->MINLEVEL;
+    o.MAX_ANGLE = options_p->MAX_ANGLE; o.MIN_ANGLE = options_p->MIN_ANGLE;
+    o.MAX_IMAGES_PER_PATCH = options_p->MAX_IMAGES_PER_PATCH; o.MIN_IMAGES_PER_PATCH = options_p->MIN_IMAGES_PER_PATCH;
+    o.NCC_ALPHA_1 = options_p->NCC_ALPHA_1; o.NCC_ALPHA_2 = options_p->NCC_ALPHA_2;
+    hpmvs_patch_batch pb, ob;
+    memset(&pb, 0, sizeof(pb));
+    memset(&ob, 0, sizeof(ob));
+    pb.n = (int32_t)n; pb.max_images = stride;
+    pb.center = pc.data(); pb.normal = pn.data(); pb.scale = ps.data(); pb.n_images = pnimg.data(); pb.images = pimg.data();
+    ob.n = (int32_t)m; ob.max_images = stride;
+    ob.center = center.data(); ob.normal = normal.data(); ob.scale = scale.data(); ob.n_images = nimg.data();
+    ob.images = images.data(); ob.ok = accepted.data(); ob.color = color.data(); ob.ncc = ncc.data();
+    ob.fmin = fmin.data(); ob.nevals = evals.data();
+    if (hpmvs_expand_batch(dev, &o, (int)mode, &pb, cc.data(), cw.data(), skip, &ob, 0, nullptr) != HPMVS_OK) {
+        std::cerr << "frontier expansion failed: <" << hpmvs_last_error() << ">" << std::endl;
+        accepted.assign(m, 0);
+        return N;
+    }
+    candidates.resize(m);
+    for (size_t t = 0; t < m; t++) {
+        Patch3d& q = candidates[t];
+        q = *parents[t / N];  // *newP = *p (CellProcessor.cpp:113, 238)
+        q.expanded_ = false;
+        q.flatness_ = -1.0f;
+        for (int k = 0; k < 4; k++) { q.center_[k] = center[4 * t + k]; q.normal_[k] = normal[4 * t + k]; }
+        q.scale_3dx_ = scale[t];
+        lastF_[t] = fmin[t];
+        lastEvals_[t] = evals[t];
+        if (!accepted[t] && nimg[t] <= 0) continue;  // never optimized: keeps the parent's image list
+        if (accepted[t]) {
+            q.images_.assign(images.begin() + t * stride, images.begin() + t * stride + nimg[t]);
+            q.ncc_ = ncc[t];
+            q.color_ = Eigen::Vector3f(color[3 * t], color[3 * t + 1], color[3 * t + 2]);
+        }
+    }
+    return N;
+}
+
 }  // namespace mo3d

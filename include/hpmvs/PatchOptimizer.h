@@ -21,6 +21,18 @@ public:
     bool optimize(mo3d::Patch3d& patch);
     // ok[i] = result of optimize(*patches[i]); returns the number of successes
     size_t optimizeBatch(mo3d::Patch3d* const* patches, size_t n, uint8_t* ok);
+    // Frontier expansion: the candidate loops of CellProcessor::extend (mode EXTEND, 6 candidates per
+    // parent, reference src/hpmvs/CellProcessor.cpp:84-142) and CellProcessor::branch (mode BRANCH, 4
+    // candidates, :210-262) for many cells in one GPU call: candidates are constructed exactly as the
+    // reference does (*newP = *p, new centre/scale, expanded_ = false, flatness_ = -1), optimized, and
+    // the geometric gates applied.  cells[i] = (leaf centre, leaf width) of parents[i]; skip (optional,
+    // n*N flags) marks candidates whose target leaf the caller already found occupied (:120-124).
+    // candidates receives n*N patches (candidate k of parent i at i*N + k), accepted[i*N + k] != 0 where
+    // the candidate passed; the depth tests and the octree insertion stay with the caller.  Returns N.
+    enum ExpandMode { EXTEND = 0, BRANCH = 1 };
+    struct CellRef { Eigen::Vector3f c; float width; };
+    int expandBatch(ExpandMode mode, const mo3d::Patch3d* const* parents, const CellRef* cells, size_t n,
+                    const uint8_t* skip, std::vector<mo3d::Patch3d>& candidates, std::vector<uint8_t>& accepted);
     // diagnostics of the last optimize()/optimizeBatch() call that the reference computes and drops
     // (final mean robust INCC f*, PatchOptimizer.cpp:365,376): one entry per patch
     const std::vector<double>& lastObjective() const { return lastF_; }

@@ -143,6 +143,36 @@ int hpmvs_init_patches_batch(const hpmvs_scene *s, const hpmvs_options *o, int s
                              const double *xyz, const int32_t *meas_off, const int32_t *meas_img,
                              hpmvs_patch_batch *b, int on_device, void *stream);
 
+/* Frontier expansion: the candidate loops of CellProcessor::extend (reference
+ * src/hpmvs/CellProcessor.cpp:84-178) and CellProcessor::branch (:210-262) for a whole frontier of
+ * octree cells in one call -- candidate construction, optimize() and the geometric acceptance gates.
+ *   mode HPMVS_EXPAND_EXTEND : 6 candidates per parent on a hexagon of radius cell_width around the parent
+ *        centre in the parent's tangent plane (x axis from the reference camera), scale = 0.9 * width / 2;
+ *        accepted if optimize() succeeds, width/2 < 2*scale < width (:131-132) and the centre moved less
+ *        than 1.5 * width from the PARENT centre (:133).
+ *   mode HPMVS_EXPAND_BRANCH : 4 candidates at radius width/4 on the diagonals, scale = 0.45 * width / 2;
+ *        only candidates inside the parent's cell are optimized (:247) and they must still be inside it
+ *        afterwards (:257).
+ * parents: n patches (center, normal, n_images, images are read; images[.][0] is the reference image);
+ * cell_center[n][3], cell_width[n]: the octree leaf of each parent (Cell::c_, Cell::width_);
+ * skip (optional, n*N bytes): nonzero = the caller already knows the candidate is not wanted (extend: the
+ *   target leaf is occupied or finer, :120-124) -> it is built but not optimized;
+ * out: batch of n*N patches, candidate k of parent i at index i*N + k, max_images = parents->max_images.
+ *   ok = accepted; stage = 0, the optimize() stage 1..9/100, 20 = skipped / outside the cell before optimize,
+ *   21 = scale gate, 22 = drift gate (extend) or left the cell (branch).  A candidate that fails keeps its
+ *   constructed centre/scale (optimize() leaves failed patches untouched).
+ * The depth / view-block / free-pixel tests (:135-142) and the octree insertion read and write scene state
+ * that is order dependent in the reference; they stay with the caller.  Host or device pointers as for
+ * hpmvs_optimize_batch. */
+#define HPMVS_EXPAND_EXTEND 0
+#define HPMVS_EXPAND_BRANCH 1
+int hpmvs_expand_batch(const hpmvs_scene *s, const hpmvs_options *o, int mode, const hpmvs_patch_batch *parents,
+                       const float *cell_center, const float *cell_width, const uint8_t *skip,
+                       hpmvs_patch_batch *out, int on_device, void *stream);
+/* the (cos, sin) pairs of the candidate directions the kernels use: dxdy[2*N], N = 6 (extend) or 4 (branch);
+ * returns N.  (std::cos/std::sin of the float angle 2*pi/N*i [+ pi/4], CellProcessor.cpp:107-109, 233-235.) */
+int hpmvs_expand_directions(int mode, float *dxdy);
+
 /* objective_fn at optimiser variables x[n][3] for each patch's current image list, with
  * refCenter_/refRay_/axes taken from the patch as optimizePatch does.  f_out[n]. */
 int hpmvs_objective_batch(const hpmvs_scene *s, const hpmvs_options *o, const hpmvs_patch_batch *b,

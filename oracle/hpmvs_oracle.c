@@ -793,6 +793,73 @@ void orc_init_patches(const orc_scene *s, const orc_options *o, int start_level,
     }
 }
 
+/* ---- CellProcessor::extend / ::branch candidate loops ------------------------------------ */
+
+/* Cell::contains, src/hpmvs/doctree.cpp:38-42 */
+static int cell_contains(const float *cc, float width, const float *p) {
+    const float hw = width / 2.0;
+    return p[0] > cc[0] - hw && p[1] > cc[1] - hw && p[2] > cc[2] - hw && p[0] <= cc[0] + hw && p[1] <= cc[1] + hw &&
+           p[2] <= cc[2] + hw;
+}
+
+int orc_expand_directions(int mode, float *dxdy) {
+    const int N = mode == 0 ? 6 : 4;
+    for (int ii = 0; ii < N; ii++) {
+        /* CellProcessor.cpp:107-109 / 233-235: `const float angle = ...; cos(angle)` with `using namespace std`
+         * in scope resolves to std::cos(float) */
+        const float angle = mode == 0 ? 2.0 * M_PI / N * ii : 2.0 * M_PI / N * ii + M_PI / 4;
+        dxdy[2 * ii] = cosf(angle);
+        dxdy[2 * ii + 1] = sinf(angle);
+    }
+    return N;
+}
+
+int orc_expand(const orc_scene *s, const orc_options *o, int mode, const orc_patch *parent, const float cell_center[3],
+               float cell_width, const unsigned char *skip, orc_patch *out, int which) {
+    const int N = mode == 0 ? 6 : 4;
+    float dxdy[12];
+    orc_expand_directions(mode, dxdy);
+    const orc_patch *p = parent;
+    for (int ii = 0; ii < N; ii++) {
+        orc_patch *q = &out[ii];
+        *q = *p; /* *newP = *p */
+        q->stage = 0; q->fmin = 0.0; q->nevals = 0; q->nlopt_result = 0; q->ngrabs = 0; q->ngrabs_all = 0;
+        q->x[0] = q->x[1] = q->x[2] = 0.0;
+        if (p->n_images <= 0) { q->stage = 20; continue; }
+        /* CellProcessor.cpp:97-101 / 223-227 */
+        const float *imgX = s->cams[p->images[0]].xaxis;
+        float t[3], yaxis[3], xaxis[3];
+        cross3(p->normal, imgX, t);
+        normalized3(t, yaxis);
+        cross3(yaxis, p->normal, xaxis);
+        const float extend = mode == 0 ? cell_width : (float)(cell_width / 4.0);
+        const float dx = dxdy[2 * ii], dy = dxdy[2 * ii + 1];
+        for (int k = 0; k < 3; k++) q->center[k] = p->center[k] + (dx * xaxis[k] + dy * yaxis[k]) * extend;
+        q->scale = mode == 0 ? cell_width * 0.9 / 2.0 : cell_width * 0.45 / 2.0;
+        if (skip && skip[ii]) { q->stage = 20; continue; }
+        if (mode == 1 && !cell_contains(cell_center, cell_width, q->center)) { q->stage = 20; continue; } /* :247 */
+        if (!orc_optimize(s, o, q, which)) continue; /* stage set by optimize */
+        if (mode == 0) {
+            /* :131-133 */
+            if (!(q->scale * 2.0 < cell_width && q->scale * 2.0 > cell_width / 2.0)) { q->stage = 21; continue; }
+            float d[4];
+            sub4(q->center, p->center, d);
+            if (!(norm4(d) < cell_width * 1.5)) { q->stage = 22; continue; }
+        } else if (!cell_contains(cell_center, cell_width, q->center)) { q->stage = 22; continue; } /* :257 */
+    }
+    return N;
+}
+
+void orc_expand_batch(const orc_scene *s, const orc_options *o, int mode, int n, const orc_patch *parents,
+                      const float *cell_center, const float *cell_width, const unsigned char *skip, orc_patch *out,
+                      int which, int n_threads) {
+    const int N = mode == 0 ? 6 : 4;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(n_threads > 0 ? n_threads : 1)
+    for (int i = 0; i < n; i++)
+        orc_expand(s, o, mode, &parents[i], cell_center + 3 * i, cell_width[i], skip ? skip + (size_t)i * N : NULL,
+                   out + (size_t)i * N, which);
+}
+
 double orc_objective_at(const orc_scene *s, const orc_options *o, const orc_patch *p, const double x[3]) {
     popt po;
     popt_begin(&po, s, o, p);

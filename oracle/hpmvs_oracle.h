@@ -118,6 +118,21 @@ void orc_optimize_batch(const orc_scene *s, const orc_options *o, orc_patch *p, 
 void orc_init_patches(const orc_scene *s, const orc_options *o, int start_level, int n, const double *xyz,
                       const int *meas_off, const int *meas_img, orc_patch *p, int which_optimizer, int n_threads);
 
+/* Candidate loops of CellProcessor::extend (src/hpmvs/CellProcessor.cpp:84-178) and ::branch (:210-262)
+ * for one parent patch, up to and including the geometric acceptance gates; the octree look-ups
+ * (:120-124 -> `skip`), the depth / view-block / free-pixel tests (:135-142) and the insertion are
+ * the caller's.  mode 0 = extend (6 candidates), 1 = branch (4).  out[k].stage: 0 accepted, 1-9/100
+ * optimize stage, 20 skipped / outside the cell before optimize, 21 scale gate, 22 drift gate /
+ * left the cell.  Returns the fan-out N. */
+int orc_expand(const orc_scene *s, const orc_options *o, int mode, const orc_patch *parent,
+               const float cell_center[3], float cell_width, const unsigned char *skip, orc_patch *out,
+               int which_optimizer);
+void orc_expand_batch(const orc_scene *s, const orc_options *o, int mode, int n, const orc_patch *parents,
+                      const float *cell_center, const float *cell_width, const unsigned char *skip,
+                      orc_patch *out, int which_optimizer, int n_threads);
+/* the candidate directions (cosf, sinf of the float angles) */
+int orc_expand_directions(int mode, float *dxdy);
+
 /* objective_fn at given optimiser variables x (PatchOptimizer.cpp:286-320) for the patch's
  * current image list; the seed centre/normal define refCenter_/refRay_/axes as optimizePatch does. */
 double orc_objective_at(const orc_scene *s, const orc_options *o, const orc_patch *p, const double x[3]);

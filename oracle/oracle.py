@@ -82,6 +82,9 @@ def lib():
                             C.POINTER(C.c_float)]
     L.orc_sample_texture.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Patch), C.c_int, C.c_int,
                                      C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float)]
+    L.orc_expand_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_int, C.POINTER(Patch), C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.POINTER(Patch), C.c_int, C.c_int]
+    L.orc_expand_directions.argtypes = [C.c_int, C.c_void_p]
     L.orc_bobyqa_minimize.argtypes = [C.c_int, C.c_int, OBJ_FN, C.c_void_p, C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_int,
                                       C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -178,6 +181,28 @@ def init_patches(scene: OracleScene, xyz, meas_off, meas_img, start_level=4, whi
     lib().orc_init_patches(scene.h, C.byref(o), start_level, n, xyz.ctypes.data, off.ctypes.data, img.ctypes.data, P,
                            which, n_threads)
     return P
+
+
+def expand_directions(mode: int) -> np.ndarray:
+    out = np.zeros(12, dtype=np.float32)
+    n = lib().orc_expand_directions(mode, out.ctypes.data)
+    return out[:2 * n].reshape(n, 2)
+
+
+def expand_batch(scene: OracleScene, mode, parents, cell_center, cell_width, skip=None, which=None, options=None,
+                 n_threads=1):
+    """CellProcessor::extend / ::branch candidate loops (reference CellProcessor.cpp:84-178, 210-262)."""
+    which = best_optimizer() if which is None else which
+    o = options or default_options()
+    n = len(parents)
+    N = 6 if mode == 0 else 4
+    cc = np.ascontiguousarray(cell_center, dtype=np.float32).reshape(n, 3)
+    cw = np.ascontiguousarray(cell_width, dtype=np.float32).reshape(n)
+    sk = None if skip is None else np.ascontiguousarray(skip, dtype=np.uint8).reshape(n * N)
+    out = (Patch * (n * N))()
+    lib().orc_expand_batch(scene.h, C.byref(o), mode, n, parents, cc.ctypes.data, cw.ctypes.data,
+                           None if sk is None else sk.ctypes.data, out, which, n_threads)
+    return out
 
 
 def objective_at(scene: OracleScene, patch: Patch, x, options=None) -> float:

@@ -103,6 +103,28 @@ int main(int argc, char** argv) {
         for (int id : p.images_) printf(" %d", id);
         printf("\n");
     }
+    // (3) frontier expansion the way CellProcessor::extend would batch it: every refined patch is a parent whose
+    //     leaf is centred on it with width 2*scale/0.9
+    {
+        std::vector<const mo3d::Patch3d*> parents;
+        std::vector<mo3d::PatchOptimizer::CellRef> cells;
+        for (int i = 0; i < np; i++)
+            if (ok[i]) {
+                parents.push_back(patches[i].get());
+                mo3d::PatchOptimizer::CellRef c;
+                c.c = Eigen::Vector3f(patches[i]->center_[0], patches[i]->center_[1], patches[i]->center_[2]);
+                c.width = patches[i]->scale_3dx_ * (2.0f / 0.9f);
+                cells.push_back(c);
+            }
+        std::vector<mo3d::Patch3d> cand;
+        std::vector<unsigned char> acc;
+        const int N = optimizers[1].expandBatch(mo3d::PatchOptimizer::EXTEND, parents.data(), cells.data(), parents.size(),
+                                                nullptr, cand, acc);
+        for (size_t t = 0; t < cand.size(); t++)
+            printf("expand %zu %d %d %.9g %.9g %.9g %.9g %.9g %.9g %.9g %zu %d\n", t, N, (int)acc[t], cand[t].center_[0],
+                   cand[t].center_[1], cand[t].center_[2], cand[t].normal_[0], cand[t].normal_[1], cand[t].normal_[2],
+                   cand[t].scale_3dx_, cand[t].images_.size(), cand[t].expanded_ ? 1 : 0);
+    }
     printf("good %zu\n", good);
     return 0;
 }

@@ -60,3 +60,15 @@ def test_no_cpu_fallback_without_a_device():
     o = api.default_options()
     b = api.PatchBatch()
     assert L.hpmvs_optimize_batch(None, C.byref(o), C.byref(b), 0, None) == -2  # null scene: HPMVS_ERR_ARG
+
+
+def test_expand_direction_table_matches_libm():
+    from hpmvs_amd import api
+    """The candidate directions of CellProcessor::extend / ::branch are std::cos/std::sin of a float angle
+    (reference CellProcessor.cpp:107-109, 233-235).  The kernels use a literal table; it must equal what the
+    host C library returns (the oracle calls cosf/sinf)."""
+    from oracle import oracle as orc
+    for mode, n in ((api.EXPAND_EXTEND, 6), (api.EXPAND_BRANCH, 4)):
+        t = api.expand_directions(mode)
+        assert t.shape == (n, 2)
+        assert np.array_equal(t, orc.expand_directions(mode))

@@ -65,3 +65,18 @@ def test_cpp_patchoptimizer_equals_c_abi(tiny_scene, tiny_seeds, gpu_scene, tmp_
             assert np.array_equal(vals, np.concatenate([batch.center[k, :3], batch.normal[k, :3]]).astype(np.float32))
             assert int(r[9]) == batch.n_images[k]
     assert int(out[-1].split()[1]) == int(batch.ok.sum())
+    # PatchOptimizer::expandBatch (CellProcessor::extend candidates for every refined patch) == hpmvs_expand_batch
+    keep = np.nonzero(batch.ok)[0]
+    par = api.Batch(batch.center[keep], batch.normal[keep], batch.scale[keep], batch.n_images[keep], batch.images[keep])
+    width = (par.scale * np.float32(2.0 / 0.9)).astype(np.float32)
+    want = api.expand_batch(gpu_scene, api.EXPAND_EXTEND, par, par.center[:, :3], width)
+    rows = [l.split() for l in out if l.startswith("expand")]
+    assert len(rows) == want.n and want.n == 6 * len(keep)
+    for r in rows:
+        t = int(r[1])
+        assert int(r[2]) == 6 and int(r[3]) == want.ok[t] and int(r[12]) == 0
+        vals = np.array([float(v) for v in r[4:11]], dtype=np.float32)
+        assert np.array_equal(vals, np.concatenate([want.center[t, :3], want.normal[t, :3], [want.scale[t]]]).astype(np.float32)), t
+        if want.ok[t]:
+            assert int(r[11]) == want.n_images[t]
+    assert want.ok.sum() > 0

@@ -1,0 +1,76 @@
+"""GPU parity of the frontier expansion (hpmvs_expand_batch) against the oracle's restatement of the
+candidate loops of CellProcessor::extend / ::branch (reference src/hpmvs/CellProcessor.cpp:84-178,
+210-262).  Tolerance: identical -- candidate construction is a handful of float32 operations in the
+reference's order, the refinement is the bit-identical optimize() path, the gates are comparisons."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def refined_parents(tiny_scene, tiny_seeds, gpu_scene):
+    from hpmvs_amd import api
+    b = api.Batch.from_seeds(tiny_seeds)
+    api.optimize_batch(gpu_scene, b)
+    keep = np.nonzero(b.ok)[0]
+    assert len(keep) >= 20
+    par = api.Batch(b.center[keep], b.normal[keep], b.scale[keep], b.n_images[keep], b.images[keep])
+    return par
+
+
+def oracle_parents(par):
+    from oracle import oracle as orc
+    P = (orc.Patch * par.n)()
+    for k in range(par.n):
+        P[k].center[:] = par.center[k].tolist()
+        P[k].normal[:] = par.normal[k].tolist()
+        P[k].scale = float(par.scale[k])
+        P[k].n_images = int(par.n_images[k])
+        for j in range(par.n_images[k]):
+            P[k].images[j] = int(par.images[k, j])
+    return P
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_expand_matches_oracle(mode, tiny_scene, tiny_seeds, oracle_scene, gpu_scene):
+    from hpmvs_amd import api
+    from oracle import oracle as orc
+    par = refined_parents(tiny_scene, tiny_seeds, gpu_scene)
+    n, N = par.n, (6 if mode == 0 else 4)
+    rng = np.random.default_rng(3 + mode)
+    # octree leaves: extend keeps the candidate scale near the parent's (width = 2*scale/0.9); branch halves it.
+    width = (par.scale * (2.0 / 0.9) * (1.0 if mode == 0 else 1.6)).astype(np.float32)
+    # leaf centres near the parent centre, offset so that some branch candidates fall outside the leaf
+    cc = (par.center[:, :3] + rng.uniform(-0.3, 0.3, (n, 3)).astype(np.float32) * width[:, None]).astype(np.float32)
+    skip = (rng.uniform(size=n * N) < 0.15).astype(np.uint8) if mode == 0 else None
+    out = api.expand_batch(gpu_scene, mode, par, cc, width, skip)
+    ref = orc.expand_batch(oracle_scene, mode, oracle_parents(par), cc, width, skip, n_threads=8)
+    assert out.n == n * N
+    stage_cpu = np.array([ref[t].stage for t in range(n * N)])
+    assert np.array_equal(stage_cpu, out.stage), (np.nonzero(stage_cpu != out.stage)[0][:10], stage_cpu[:24], out.stage[:24])
+    assert np.array_equal(out.ok.astype(bool), stage_cpu == 0)
+    # every candidate: constructed / refined centre, normal and scale identical
+    for t in range(n * N):
+        assert np.array_equal(np.array(ref[t].center[:], dtype=np.float32), out.center[t]), t
+        assert np.array_equal(np.array(ref[t].normal[:], dtype=np.float32), out.normal[t]), t
+        assert np.float32(ref[t].scale) == out.scale[t], t
+        if stage_cpu[t] == 0:
+            m = ref[t].n_images
+            assert m == out.n_images[t] and list(ref[t].images[:m]) == list(out.images[t, :m]), t
+    acc = int((stage_cpu == 0).sum())
+    assert acc >= 10, f"only {acc} accepted candidates -- test scene too hard"
+    if mode == 0:
+        assert (stage_cpu[skip.astype(bool)] == 20).all()
+    else:
+        assert (stage_cpu == 20).sum() > 0 and (stage_cpu == 20).sum() < n * N  # the pre-gate is exercised both ways
+
+
+def test_expand_rejects_bad_arguments(tiny_scene, tiny_seeds, gpu_scene):
+    from hpmvs_amd import api
+    par = refined_parents(tiny_scene, tiny_seeds, gpu_scene)
+    with pytest.raises(api.HpmvsError):
+        api.expand_batch(gpu_scene, 7, par, par.center[:, :3], par.scale)
+    empty = api.Batch(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32), np.zeros(0, np.float32),
+                      np.zeros(0, np.int32), np.zeros((0, par.max_images), np.int32))
+    out = api.expand_batch(gpu_scene, 0, empty, np.zeros((0, 3), np.float32), np.zeros(0, np.float32))
+    assert out.n == 0
