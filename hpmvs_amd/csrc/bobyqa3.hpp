@@ -167,6 +167,16 @@ struct Bobyqa3 { double dd[BQ_ND]; int ii[BQ_NI]; };
 #define BQ_I(i) B.ii[(i)]
 #endif
 
+// How the state handle travels through function calls.  On the device it is just the slot index and is
+// passed BY VALUE: a reference would be a generic pointer to a scratch copy, and since a generic pointer may
+// alias LDS the compiler has to re-load the slot index from scratch (a flat load, several hundred cycles)
+// after every LDS store.  On the host the handle holds the arrays and is passed by reference.
+#if defined(BQ_STATE_LDS)
+typedef const Bobyqa3 BqRef;
+#else
+typedef Bobyqa3& BqRef;
+#endif
+
 #define BQA(name, idx) BQ_D(O_##name + (idx))   // 0-based element of a named array
 #define BQS(name) BQ_D(O_##name)                // float64 scalar
 #define BQN(name) BQ_I(I_##name)                // int scalar
@@ -210,7 +220,7 @@ enum { L20 = 0, L60, L90, L210, L230, L360, L650, L680, L720, L190, LRET_CONT, L
 
 // x (scaled) for the interpolation point / trial step `p` (relative to xbase), bounds respected
 // exactly as bobyqb_ does before each calfun (bobyqa.c:2560-2575, 1871-1883)
-BQ_HD void set_x_from(Bobyqa3& B, int p_off) {  // p_off: state offset of the 3-vector p
+BQ_HD void set_x_from(BqRef B, int p_off) {  // p_off: state offset of the 3-vector p
     for (int i = 1; i <= 3; i++) {
         const double pi = BQ_D(p_off + i - 1);
         double v = mn(mx(BQ_V(xl, i), BQ_V(xbase, i) + pi), BQ_V(xu, i));
@@ -223,7 +233,7 @@ BQ_HD void set_x_from(Bobyqa3& B, int p_off) {  // p_off: state offset of the 3-
 
 // ---------------------------------------------------------------- prelim_ (bobyqa.c:1713-1952)
 // Choose interpolation point nf+1 (1-based after the increment) and put it in B.x / B.xeval.
-BQ_HD void prelim_next_point(Bobyqa3& B) {
+BQ_HD void prelim_next_point(BqRef B) {
     const int nfm = BQN(nf);
     const int nfx = BQN(nf) - 3;
     BQN(nf)++;
@@ -244,7 +254,7 @@ BQ_HD void prelim_next_point(Bobyqa3& B) {
 }
 
 // Absorb f at point nf into the initial model.
-BQ_HD void prelim_consume(Bobyqa3& B, double f) {
+BQ_HD void prelim_consume(BqRef B, double f) {
     const int nf = BQN(nf), nfm = nf - 1, nfx = nf - 1 - 3;
     const double rhosq = BQS(rhobeg) * BQS(rhobeg);
     BQ_FVAL(nf) = f;
@@ -282,7 +292,7 @@ BQ_HD void prelim_consume(Bobyqa3& B, double f) {
 }
 
 // ---------------------------------------------------------------- H times s (bobyqa.c:1676-1700)
-BQ_HD void hess_mul(const Bobyqa3& B, const double* s, double* hs) {
+BQ_HD void hess_mul(BqRef B, const double* s, double* hs) {
     int ih = 0;
     for (int j = 1; j <= 3; j++) {
         hs[j - 1] = 0.0;
@@ -327,8 +337,17 @@ BQ_HD void hess_mul_local(const double* hq, const double* pq, const double* xpt,
 // Approximately minimise the model within ||d|| <= delta and the bounds: truncated conjugate
 // gradients with restarts on newly active bounds, then 2-D searches on the boundary.
 // Sets B.xnew, B.d, B.gnew, BQS(dsq), BQS(crvmin).
-BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
-    double xbdi[3], s[3] = {0, 0, 0}, hs[3], hred[3] = {0, 0, 0};
+// three float64 values held as named scalars: with a per-lane (divergent) index the compiler would turn a
+// local array into scratch memory; the accessors compile to selects, or to nothing for constant indices
+struct Vec3Regs {
+    double v0, v1, v2;
+    BQ_HD double get(int i) const { return i == 0 ? v0 : (i == 1 ? v1 : v2); }
+    BQ_HD void set(int i, double x) { if (i == 0) v0 = x; else if (i == 1) v1 = x; else v2 = x; }
+};
+
+BQ_HD_NOINLINE void trsbox(BqRef B) {
+    Vec3Regs xbdi;  // +-1 for variables fixed at a bound, else 0
+    double s[3] = {0, 0, 0}, hs[3], hred[3] = {0, 0, 0};
     // read-only model data and the working vectors are held in registers for the whole call
     // (one batch of LDS reads at entry, one write-back of d / gnew / xnew at exit)
     double xopt_[3], sl_[3], su_[3], d_[3], gnew_[3];
@@ -338,13 +357,14 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
                   sdec, ggsav = 0.0, dredsq = 0.0, dredg = 0.0, sredg = 0.0, angbd = 0.0, xsav = 0.0, ssq, tempa,
                   tempb, dhs, dhd, redmax, redsav, angt = 0.0, sth, cth, rednew, rdprev = 0.0, rdnext = 0.0;
     for (int i = 0; i < 3; i++) {
-        xbdi[i] = 0.0;
+        double xb = 0.0;
         if (xopt_[i] <= sl_[i]) {
-            if (BQA(gopt, i) >= 0.0) xbdi[i] = -1.0;
+            if (BQA(gopt, i) >= 0.0) xb = -1.0;
         } else if (xopt_[i] >= su_[i]) {
-            if (BQA(gopt, i) <= 0.0) xbdi[i] = 1.0;
+            if (BQA(gopt, i) <= 0.0) xb = 1.0;
         }
-        if (xbdi[i] != 0.0) ++nact;
+        xbdi.set(i, xb);
+        if (xb != 0.0) ++nact;
         d_[i] = 0.0;
         gnew_[i] = BQA(gopt, i);
     }
@@ -358,7 +378,7 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
         if (st == CG_NEXT) {
             stepsq = 0.0;
             for (int i = 0; i < 3; i++) {
-                if (xbdi[i] != 0.0) s[i] = 0.0;
+                if (xbdi.get(i) != 0.0) s[i] = 0.0;
                 else if (beta == 0.0) s[i] = -gnew_[i];
                 else s[i] = beta * s[i] - gnew_[i];
                 stepsq += s[i] * s[i];
@@ -370,7 +390,7 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             BQ_PROF_COUNT(56, 1);
             resid = delsq; ds = 0.0; shs = 0.0;
             for (int i = 0; i < 3; i++)
-                if (xbdi[i] == 0.0) { resid -= d_[i] * d_[i]; ds += s[i] * d_[i]; shs += s[i] * hs[i]; }
+                if (xbdi.get(i) == 0.0) { resid -= d_[i] * d_[i]; ds += s[i] * d_[i]; shs += s[i] * hs[i]; }
             if (resid <= 0.0) { st = BOUNDARY; continue; }
             temp = sqrt(stepsq * resid + ds * ds);
             if (ds < 0.0) blen = (temp - ds) / stepsq;
@@ -397,7 +417,7 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
                 gredsq = 0.0;
                 for (int i = 0; i < 3; i++) {
                     gnew_[i] += stplen * hs[i];
-                    if (xbdi[i] == 0.0) gredsq += gnew_[i] * gnew_[i];
+                    if (xbdi.get(i) == 0.0) gredsq += gnew_[i] * gnew_[i];
                     d_[i] += stplen * s[i];
                 }
                 sdec = mx(stplen * (ggsav - 0.5 * stplen * shs), 0.0);
@@ -405,9 +425,11 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             }
             if (iact > 0) {
                 ++nact;
-                xbdi[iact - 1] = 1.0;
-                if (s[iact - 1] < 0.0) xbdi[iact - 1] = -1.0;
-                delsq -= d_[iact - 1] * d_[iact - 1];
+                for (int i = 0; i < 3; i++)  // index iact-1 differs per lane: selects keep the arrays in registers
+                    if (i == iact - 1) {
+                        xbdi.set(i, (s[i] < 0.0) ? -1.0 : 1.0);
+                        delsq -= d_[i] * d_[i];
+                    }
                 if (delsq <= 0.0) { st = BOUNDARY; continue; }
                 st = CG_RESTART;
                 continue;
@@ -428,7 +450,7 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             if (nact >= 2) { st = FINISH; continue; }
             dredsq = 0.0; dredg = 0.0; gredsq = 0.0;
             for (int i = 0; i < 3; i++) {
-                if (xbdi[i] == 0.0) {
+                if (xbdi.get(i) == 0.0) {
                     dredsq += d_[i] * d_[i];
                     dredg += d_[i] * gnew_[i];
                     gredsq += gnew_[i] * gnew_[i];
@@ -448,7 +470,7 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             if (temp <= qred * 1e-4 * qred) { st = FINISH; continue; }
             temp = sqrt(temp);
             for (int i = 0; i < 3; i++) {
-                if (xbdi[i] == 0.0) s[i] = (dredg * d_[i] - dredsq * gnew_[i]) / temp;
+                if (xbdi.get(i) == 0.0) s[i] = (dredg * d_[i] - dredsq * gnew_[i]) / temp;
                 else s[i] = 0.0;
             }
             sredg = -temp;
@@ -456,11 +478,11 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             iact = 0;
             bool refix = false;
             for (int i = 0; i < 3; i++) {
-                if (xbdi[i] == 0.0) {
+                if (xbdi.get(i) == 0.0) {
                     tempa = xopt_[i] + d_[i] - sl_[i];
                     tempb = su_[i] - xopt_[i] - d_[i];
-                    if (tempa <= 0.0) { ++nact; xbdi[i] = -1.0; refix = true; break; }
-                    else if (tempb <= 0.0) { ++nact; xbdi[i] = 1.0; refix = true; break; }
+                    if (tempa <= 0.0) { ++nact; xbdi.set(i, -1.0); refix = true; break; }
+                    else if (tempb <= 0.0) { ++nact; xbdi.set(i, 1.0); refix = true; break; }
                     ssq = d_[i] * d_[i] + s[i] * s[i];
                     temp = ssq - (xopt_[i] - sl_[i]) * (xopt_[i] - sl_[i]);
                     if (temp > 0.0) {
@@ -478,7 +500,7 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             hess_mul(B, s, hs);
             shs = 0.0; dhs = 0.0; dhd = 0.0;
             for (int i = 0; i < 3; i++)
-                if (xbdi[i] == 0.0) { shs += s[i] * hs[i]; dhs += d_[i] * hs[i]; dhd += d_[i] * hred[i]; }
+                if (xbdi.get(i) == 0.0) { shs += s[i] * hs[i]; dhs += d_[i] * hs[i]; dhd += d_[i] * hred[i]; }
             BQ_PROF_END(tai_, 18);
             BQ_PROF_BEGIN(tan_);
             redmax = 0.0; isav = 0; redsav = 0.0;
@@ -519,7 +541,7 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
             dredg = 0.0; gredsq = 0.0;
             for (int i = 0; i < 3; i++) {
                 gnew_[i] = gnew_[i] + (cth - 1.0) * hred[i] + sth * hs[i];
-                if (xbdi[i] == 0.0) {
+                if (xbdi.get(i) == 0.0) {
                     d_[i] = cth * d_[i] + sth * s[i];
                     dredg += d_[i] * gnew_[i];
                     gredsq += gnew_[i] * gnew_[i];
@@ -527,7 +549,12 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
                 hred[i] = cth * hred[i] + sth * hs[i];
             }
             qred += sdec;
-            if (iact > 0 && isav == iu) { ++nact; xbdi[iact - 1] = xsav; st = ALT_SETUP; continue; }
+            if (iact > 0 && isav == iu) {
+                ++nact;
+                for (int i = 0; i < 3; i++) if (i == iact - 1) xbdi.set(i, xsav);
+                st = ALT_SETUP;
+                continue;
+            }
             if (sdec > qred * .01) { st = ALT_ITER; continue; }
             st = FINISH;
         }
@@ -537,8 +564,8 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
     double dsq = 0.0;
     for (int i = 0; i < 3; i++) {
         double xn = mx(mn(xopt_[i] + d_[i], su_[i]), sl_[i]);
-        if (xbdi[i] == -1.0) xn = sl_[i];
-        if (xbdi[i] == 1.0) xn = su_[i];
+        if (xbdi.get(i) == -1.0) xn = sl_[i];
+        if (xbdi.get(i) == 1.0) xn = su_[i];
         d_[i] = xn - xopt_[i];
         dsq += d_[i] * d_[i];
         BQA(xnew, i) = xn; BQA(d, i) = d_[i]; BQA(gnew, i) = gnew_[i];
@@ -550,7 +577,7 @@ BQ_HD_NOINLINE void trsbox(Bobyqa3& B) {
 // ---------------------------------------------------------------- altmov_ (bobyqa.c:744-1160)
 // Geometry-improving step for interpolation point knew: B.xnew (line through xopt and another
 // point), B.xalt (constrained Cauchy step), BQS(alpha), BQS(cauchy).
-BQ_HD_NOINLINE void altmov(Bobyqa3& B) {
+BQ_HD_NOINLINE void altmov(BqRef B) {
     const double cst = 1.0 + sqrt(2.);
     double glag[3], hcol[7], w[3], wsave[3] = {0, 0, 0};
     const int knew = BQN(knew), kopt = BQN(kopt);
@@ -560,7 +587,11 @@ BQ_HD_NOINLINE void altmov(Bobyqa3& B) {
         const double temp = BQ_ZMAT(knew, j);
         for (int k = 1; k <= 7; k++) hcol[k - 1] += temp * BQ_ZMAT(k, j);
     }
-    BQS(alpha) = hcol[knew - 1];
+    {   // = hcol[knew-1] (same operations in the same order), without a per-lane index into a local array
+        double al = 0.0;
+        for (int j = 1; j <= 3; j++) al += BQ_ZMAT(knew, j) * BQ_ZMAT(knew, j);
+        BQS(alpha) = al;
+    }
     const double ha = 0.5 * BQS(alpha);
     for (int i = 1; i <= 3; i++) glag[i - 1] = BQ_BMAT(knew, i);
     for (int k = 1; k <= 7; k++) {
@@ -696,7 +727,7 @@ BQ_HD_NOINLINE void altmov(Bobyqa3& B) {
 
 // ---------------------------------------------------------------- update_ (bobyqa.c:18-141)
 // Update BMAT and ZMAT for the move of interpolation point knew (uses vlag, beta, denom).
-BQ_HD_NOINLINE void update(Bobyqa3& B) {
+BQ_HD_NOINLINE void update(BqRef B) {
     const int knew = BQN(knew);
     double w[10];
     double ztest = 0.0;
@@ -717,7 +748,7 @@ BQ_HD_NOINLINE void update(Bobyqa3& B) {
         BQ_ZMAT(knew, j) = 0.0;
     }
     for (int i = 1; i <= 7; i++) w[i - 1] = BQ_ZMAT(knew, 1) * BQ_ZMAT(i, 1);
-    const double alpha = w[knew - 1];
+    const double alpha = BQ_ZMAT(knew, 1) * BQ_ZMAT(knew, 1);  // = w[knew-1], without a per-lane index into a local array
     const double tau = BQ_V(vlag, knew);
     BQ_V(vlag, knew) -= 1.0;
     double temp = sqrt(BQS(denom));
@@ -739,7 +770,7 @@ BQ_HD_NOINLINE void update(Bobyqa3& B) {
 // Select the interpolation point to drop for a trust-region step (bobyqa.c:2497-2545, 2648-2690):
 // maximise max(1, (dist/delta)^4) * |denominator|.  `from` is xopt before the evaluation and
 // xnew after an improving one.
-BQ_HD void pick_knew(Bobyqa3& B, int from_off, bool skip_kopt, double& scaden, double& biglsq) {
+BQ_HD void pick_knew(BqRef B, int from_off, bool skip_kopt, double& scaden, double& biglsq) {
     const double delsq = BQS(delta) * BQS(delta);
     scaden = 0.0; biglsq = 0.0;
     BQN(knew) = 0;
@@ -766,7 +797,7 @@ BQ_HD void pick_knew(Bobyqa3& B, int from_off, bool skip_kopt, double& scaden, d
 // original interpolation points are reinstated while the denominators stay healthy, and the remaining
 // provisional points are evaluated (one objective evaluation each, hence the resumable loop).
 
-BQ_HD int rescue_finish(Bobyqa3& B, int rc2) {  // bobyqa.c:2340-2365
+BQ_HD int rescue_finish(BqRef B, int rc2) {  // bobyqa.c:2340-2365
     BQS(xoptsq) = 0.0;
     if (BQN(kopt) != BQN(kbase)) {
         for (int i = 1; i <= 3; i++) {
@@ -782,7 +813,7 @@ BQ_HD int rescue_finish(Bobyqa3& B, int rc2) {  // bobyqa.c:2340-2365
 }
 
 // the L260 loop of rescue_ (bobyqa.c:560-651): next provisional point that still needs a value
-BQ_HD_NOINLINE int rescue_next(Bobyqa3& B) {
+BQ_HD_NOINLINE int rescue_next(BqRef B) {
     for (; BQN(kpt) <= 7; BQN(kpt)++) {
         const int kpt = BQN(kpt);
         if (BQ_PTSID(kpt) == 0.0) continue;
@@ -837,7 +868,7 @@ BQ_HD_NOINLINE int rescue_next(Bobyqa3& B) {
 }
 
 // after the evaluation of provisional point kpt (bobyqa.c:652-700)
-BQ_HD_NOINLINE int rescue_consume(Bobyqa3& B, double f) {
+BQ_HD_NOINLINE int rescue_consume(BqRef B, double f) {
     const int kpt = BQN(kpt);
     BQ_FVAL(kpt) = f;
     if (f < BQ_FVAL(BQN(kopt))) BQN(kopt) = kpt;
@@ -877,7 +908,7 @@ BQ_HD_NOINLINE int rescue_consume(Bobyqa3& B, double f) {
 #ifndef BQ_ON_RESCUE
 #define BQ_ON_RESCUE() do { } while (0)  // test hook (tests/native/bq_host.cpp counts the calls)
 #endif
-BQ_HD_NOINLINE int rescue_begin(Bobyqa3& B) {
+BQ_HD_NOINLINE int rescue_begin(BqRef B) {
     BQ_ON_RESCUE();
     const double sfrac = 0.5 / 4.0;
     BQN(nfsav) = BQN(nevals);
@@ -1037,7 +1068,7 @@ BQ_HD_NOINLINE int rescue_begin(Bobyqa3& B) {
 // ---------------------------------------------------------------- bobyqb_ main loop (bobyqa.c:2143-3055)
 // Runs from `label` until the next objective evaluation is needed (returns BQ_CONTINUE with
 // B.xeval set) or the run ends (BQ_DONE).
-BQ_HD_NOINLINE int step_label(Bobyqa3& B, int label) {
+BQ_HD_NOINLINE int step_label(BqRef B, int label) {
     double w[14];
     {
         switch (label) {
@@ -1292,7 +1323,7 @@ BQ_HD_NOINLINE int step_label(Bobyqa3& B, int label) {
 // (trsbox, altmov) once per straggler.  The wave-aware scheduler below executes ONE label per
 // iteration for all lanes waiting on it, cheap transition labels first and the expensive ones only
 // when nobody can advance otherwise, so each expensive block runs ~once per round for all lanes.
-BQ_HD int run(Bobyqa3& B, int label) {
+BQ_HD int run(BqRef B, int label) {
 #if defined(__HIP_DEVICE_COMPILE__)
     for (;;) {
         const bool live = (label != LRET_CONT && label != LRET_DONE);
@@ -1324,7 +1355,7 @@ BQ_HD int run(Bobyqa3& B, int label) {
 
 // Code after an evaluation at xbase + xnew in the main loop (bobyqa.c:2583-2970)
 // returns the label to continue at (or LRET_DONE)
-BQ_HD_NOINLINE int after_eval(Bobyqa3& B, double f) {
+BQ_HD_NOINLINE int after_eval(BqRef B, double f) {
     double w[10];
     if (BQN(ntrits) == -1) {
         BQS(fsave) = f;
@@ -1493,7 +1524,7 @@ BQ_HD void bq_default_step(const double* x, const double* lb, const double* ub, 
 
 // bobyqa() front end (bobyqa.c:3073-3268) + the start of prelim_.  Returns BQ_CONTINUE with the
 // first point in B.xeval, or BQ_DONE with BQN(rc) = BQ_INVALID_ARGS.
-BQ_HD_NOINLINE int bq_start(Bobyqa3& B, const double* x0, const double* lb, const double* ub, const double* dx,
+BQ_HD_NOINLINE int bq_start(BqRef B, const double* x0, const double* lb, const double* ub, const double* dx,
                    double xtol_rel, int maxeval) {
     BQN(nevals) = 0; BQN(rc) = BQ_SUCCESS; BQS(minf) = HUGE_VAL; BQN(maxeval) = maxeval; BQN(phase) = bq::PH_PRELIM;
     for (int i = 0; i < 3; i++) { BQA(xfinal, i) = x0[i]; BQA(xeval, i) = x0[i]; }
@@ -1539,14 +1570,14 @@ BQ_HD_NOINLINE int bq_start(Bobyqa3& B, const double* x0, const double* lb, cons
     return BQ_CONTINUE;
 }
 
-BQ_HD_NOINLINE int bq_step_(Bobyqa3& B, double f);
-BQ_HD int bq_step(Bobyqa3& B, double f) {
+BQ_HD_NOINLINE int bq_step_(BqRef B, double f);
+BQ_HD int bq_step(BqRef B, double f) {
     BQ_PROF_BEGIN(t_);
     const int r = bq_step_(B, f);
     BQ_PROF_END(t_, 3);
     return r;
 }
-BQ_HD_NOINLINE int bq_step_(Bobyqa3& B, double f) {
+BQ_HD_NOINLINE int bq_step_(BqRef B, double f) {
     int label = bq::LRET_DONE;
     if (BQN(phase) == bq::PH_PRELIM) {
         bq::prelim_consume(B, f);

@@ -233,6 +233,34 @@ __device__ __noinline__ void patch_colour(const DevScene& sc, const uint16_t* ro
 
 }  // namespace
 
+// The out-of-line helpers take pointers; handing them the kernel's long-lived per-lane arrays would pin those
+// arrays in scratch memory for the whole kernel (an escaping address defeats register promotion, and every
+// later c[k] / n[k] becomes a scratch access of several hundred cycles).  Short-lived copies escape instead.
+struct F3 { float x, y, z; };
+#define HPMVS_F3(a) F3{(a)[0], (a)[1], (a)[2]}
+__device__ __forceinline__ int add_images_v(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg, F3 c, F3 n, float scale) {
+    const float cc[3] = {c.x, c.y, c.z}, nn[3] = {n.x, n.y, n.z};
+    return add_images(sc, o, row, nimg, cc, nn, scale);
+}
+__device__ __forceinline__ int sort_images_v(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg, F3 c, F3 n, float scale) {
+    const float cc[3] = {c.x, c.y, c.z}, nn[3] = {n.x, n.y, n.z};
+    return sort_images(sc, o, row, nimg, cc, nn, scale);
+}
+__device__ __forceinline__ bool assure_image_angles_v(const DevScene& sc, const DevOptions& o, const uint16_t* row, int nimg, F3 c) {
+    const float cc[3] = {c.x, c.y, c.z};
+    return assure_image_angles(sc, o, row, nimg, cc);
+}
+__device__ __forceinline__ int filter_images_by_angle_v(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg, F3 c, F3 n) {
+    const float cc[3] = {c.x, c.y, c.z}, nn[3] = {n.x, n.y, n.z};
+    return filter_images_by_angle(sc, o, row, nimg, cc, nn);
+}
+__device__ __forceinline__ F3 patch_colour_v(const DevScene& sc, const uint16_t* row, int nimg, F3 c, float scale) {
+    const float cc[3] = {c.x, c.y, c.z};
+    float rgb[3];
+    patch_colour(sc, row, nimg, cc, scale, rgb);
+    return F3{rgb[0], rgb[1], rgb[2]};
+}
+
 #ifndef HPMVS_WAVES_PER_EU
 #define HPMVS_WAVES_PER_EU 2
 #endif
@@ -283,7 +311,7 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
                 if (nimg < 0) { fail_stage = -nimg; nimg = 0; finish_fail = true; break; }  // rejected by seed_init_kernel
                 if (nimg > kMaxImages || nimg > b.max_images) { fail_stage = 100; finish_fail = true; break; }
                 for (int k = 0; k < nimg; k++) row[k] = (uint16_t)b.images[(size_t)idx * b.max_images + k];
-                nimg = add_images(sc, o, row, nimg, c, n, scale);
+                nimg = add_images_v(sc, o, row, nimg, HPMVS_F3(c), HPMVS_F3(n), scale);
                 if (nimg < 0) { fail_stage = 100; finish_fail = true; break; }
                 if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 1; finish_fail = true; break; }
                 op = OP_INCC; req_ref = 0; req_robust = 0; req_thr = o.NCC_ALPHA_1;
@@ -293,8 +321,8 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
             case S_F1: {  // filterImagesNCC(alpha1) result -> sortImages, assureImageAngles, optimizePatch start
                 nimg = apply_keep_mask(row, nimg, res_mask);
                 if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 2; finish_fail = true; break; }
-                nimg = sort_images(sc, o, row, nimg, c, n, scale);
-                if (!assure_image_angles(sc, o, row, nimg, c)) { fail_stage = 3; finish_fail = true; break; }
+                nimg = sort_images_v(sc, o, row, nimg, HPMVS_F3(c), HPMVS_F3(n), scale);
+                if (!assure_image_angles_v(sc, o, row, nimg, HPMVS_F3(c))) { fail_stage = 3; finish_fail = true; break; }
                 if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 4; finish_fail = true; break; }
                 set_optimization_fields(sc.views[row[0]], c, F);
                 double x0[3], dx[3];
@@ -319,7 +347,7 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
                 // SUCCESS / STOPVAL / FTOL / XTOL only (PatchOptimizer.cpp:367-368); negative codes throw
                 if (!(nl_result >= 1 && nl_result <= 4)) { fail_stage = 4; finish_fail = true; break; }
                 { const double xf[3] = {BQA(xfinal, 0), BQA(xfinal, 1), BQA(xfinal, 2)}; set_center_norm(F, o, xf, c, n); }
-                nimg = add_images(sc, o, row, nimg, c, n, scale);
+                nimg = add_images_v(sc, o, row, nimg, HPMVS_F3(c), HPMVS_F3(n), scale);
                 if (nimg < 0) { fail_stage = 100; finish_fail = true; break; }
                 if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 5; finish_fail = true; break; }
                 op = OP_INCC; req_ref = 0; req_robust = 0; req_thr = o.NCC_ALPHA_2;
@@ -329,9 +357,9 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
             case S_F2: {  // filterImagesNCC(alpha2) -> filterImagesByAngle, assureImageAngles, setRefImage start
                 nimg = apply_keep_mask(row, nimg, res_mask);
                 if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 6; finish_fail = true; break; }
-                nimg = filter_images_by_angle(sc, o, row, nimg, c, n);
+                nimg = filter_images_by_angle_v(sc, o, row, nimg, HPMVS_F3(c), HPMVS_F3(n));
                 if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 7; finish_fail = true; break; }
-                if (!assure_image_angles(sc, o, row, nimg, c)) { fail_stage = 8; finish_fail = true; break; }
+                if (!assure_image_angles_v(sc, o, row, nimg, HPMVS_F3(c))) { fail_stage = 8; finish_fail = true; break; }
                 ii = 0; refindex = -1; refbest = 3.402823466e+38f;
                 op = OP_REFSUM; req_ref = 0; req_robust = 1;
                 stage = S_RS;
@@ -368,9 +396,8 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
                     b.n_images[idx] = nimg;
                     for (int k = 0; k < nimg && k < b.max_images; k++) b.images[(size_t)idx * b.max_images + k] = row[k];
                     if (b.color) {
-                        float rgb[3];
-                        patch_colour(sc, row, nimg, c, scale, rgb);
-                        for (int k = 0; k < 3; k++) b.color[3 * idx + k] = rgb[k];
+                        const F3 rgb = patch_colour_v(sc, row, nimg, HPMVS_F3(c), scale);
+                        b.color[3 * idx] = rgb.x; b.color[3 * idx + 1] = rgb.y; b.color[3 * idx + 2] = rgb.z;
                     }
                     if (b.ncc) b.ncc[idx] = 1.4f;  // PatchOptimizer.cpp:95
                 }
