@@ -235,26 +235,28 @@ __device__ __noinline__ void patch_colour(const DevScene& sc, const uint16_t* ro
 
 // The out-of-line helpers take pointers; handing them the kernel's long-lived per-lane arrays would pin those
 // arrays in scratch memory for the whole kernel (an escaping address defeats register promotion, and every
-// later c[k] / n[k] becomes a scratch access of several hundred cycles).  Short-lived copies escape instead.
+// later c[k] / n[k] becomes a scratch access of several hundred cycles).  Short-lived copies escape instead;
+// the same holds for the kernel arguments sc / o, which are copied per call (by-value parameters) so that the
+// kernel's own copies stay in scalar registers.
 struct F3 { float x, y, z; };
 #define HPMVS_F3(a) F3{(a)[0], (a)[1], (a)[2]}
-__device__ __forceinline__ int add_images_v(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg, F3 c, F3 n, float scale) {
+__device__ __forceinline__ int add_images_v(DevScene sc, DevOptions o, uint16_t* row, int nimg, F3 c, F3 n, float scale) {
     const float cc[3] = {c.x, c.y, c.z}, nn[3] = {n.x, n.y, n.z};
     return add_images(sc, o, row, nimg, cc, nn, scale);
 }
-__device__ __forceinline__ int sort_images_v(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg, F3 c, F3 n, float scale) {
+__device__ __forceinline__ int sort_images_v(DevScene sc, DevOptions o, uint16_t* row, int nimg, F3 c, F3 n, float scale) {
     const float cc[3] = {c.x, c.y, c.z}, nn[3] = {n.x, n.y, n.z};
     return sort_images(sc, o, row, nimg, cc, nn, scale);
 }
-__device__ __forceinline__ bool assure_image_angles_v(const DevScene& sc, const DevOptions& o, const uint16_t* row, int nimg, F3 c) {
+__device__ __forceinline__ bool assure_image_angles_v(DevScene sc, DevOptions o, const uint16_t* row, int nimg, F3 c) {
     const float cc[3] = {c.x, c.y, c.z};
     return assure_image_angles(sc, o, row, nimg, cc);
 }
-__device__ __forceinline__ int filter_images_by_angle_v(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg, F3 c, F3 n) {
+__device__ __forceinline__ int filter_images_by_angle_v(DevScene sc, DevOptions o, uint16_t* row, int nimg, F3 c, F3 n) {
     const float cc[3] = {c.x, c.y, c.z}, nn[3] = {n.x, n.y, n.z};
     return filter_images_by_angle(sc, o, row, nimg, cc, nn);
 }
-__device__ __forceinline__ F3 patch_colour_v(const DevScene& sc, const uint16_t* row, int nimg, F3 c, float scale) {
+__device__ __forceinline__ F3 patch_colour_v(DevScene sc, const uint16_t* row, int nimg, F3 c, float scale) {
     const float cc[3] = {c.x, c.y, c.z};
     float rgb[3];
     patch_colour(sc, row, nimg, cc, scale, rgb);

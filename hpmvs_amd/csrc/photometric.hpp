@@ -573,10 +573,12 @@ __device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOp
         double val = 0.0;
         float mine = 2.0f;
         float refn0 = 0.0f, refn1 = 0.0f, refn2 = 0.0f;
+        // OBJ results are parked on the requesting lane and divided once, lane-parallel, after the last chunk
+        double d_val = 0.0;
+        int d_nok = -1;
         auto finalize = [&]() {
             if (cur_obj) {
-                const double f = (nok < o.MIN_IMAGES_PER_PATCH - 1) ? 2.0 : val / (double)nok;
-                if (lane == cur) { out.obj = f; out.ngrabs += ngr; }
+                if (lane == cur) { d_val = val; d_nok = nok; out.ngrabs += ngr; }
             } else {
                 const int np = bcast_i(q.nimg, cur);
                 float s = 0.0f;
@@ -698,6 +700,7 @@ __device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOp
             PH_ADD(t7, t8, 22);
         }
         if (cur >= 0) finalize();
+        if (d_nok >= 0) out.obj = (d_nok < o.MIN_IMAGES_PER_PATCH - 1) ? 2.0 : d_val / (double)d_nok;
         // ---- requests whose reference image failed the gates (sampleTexture false for image `ref`)
         for (unsigned long long t = batch & ~refok; t; t &= t - 1ull) {
             const int p = __ffsll((long long)t) - 1;
