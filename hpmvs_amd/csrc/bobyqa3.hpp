@@ -48,7 +48,7 @@
 #if defined(HPMVS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
 #define BQ_PROF_COUNT(i, n) atomicAdd(&s_prof[(i)], (unsigned long long)(n))
 #define BQ_PROF_BEGIN(v) const long long v = clock64()
-#define BQ_PROF_END(v, i) do { if (__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) { s_prof[2 * (i)] += (unsigned long long)(clock64() - v); s_prof[2 * (i) + 1] += 1ull; } } while (0)
+#define BQ_PROF_END(v, i) do { if (__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) { atomicAdd(&s_prof[2 * (i)], (unsigned long long)(clock64() - v)); atomicAdd(&s_prof[2 * (i) + 1], 1ull); } } while (0)
 #else
 #define BQ_PROF_COUNT(i, n) do { } while (0)
 #define BQ_PROF_BEGIN(v) do { } while (0)
@@ -145,22 +145,15 @@ enum {  // int32 slots
 #ifndef BQ_P
 #error "define BQ_P (patches per wavefront) together with BQ_STATE_LDS"
 #endif
-#if defined(BQ_LAYOUT_SLOT_MAJOR)
-// [slot][index]: one slot's state is contiguous (wide ds_read_b128 of neighbouring elements); the slot
-// stride of 178 doubles = 356 dwords = 36 (mod 64) keeps the lanes of a wave on disjoint LDS banks
-#define BQ_DSTRIDE 194
-__shared__ double bq_lds_d[BQ_DSTRIDE * BQ_P];
-__shared__ int bq_lds_i[BQ_NI * BQ_P];
-struct Bobyqa3 { int slot; };
-#define BQ_D(i) bq_lds_d[B.slot * BQ_DSTRIDE + (i)]
-#define BQ_I(i) bq_lds_i[(i) * BQ_P + B.slot]
-#else
-__shared__ double bq_lds_d[BQ_ND * BQ_P];
-__shared__ int bq_lds_i[BQ_NI * BQ_P];
-struct Bobyqa3 { int slot; };
-#define BQ_D(i) bq_lds_d[(i) * BQ_P + B.slot]
-#define BQ_I(i) bq_lds_i[(i) * BQ_P + B.slot]
+// BQ_SLOTS = slots of the whole workgroup (BQ_P per wavefront x wavefronts per workgroup); B.slot indexes them
+#ifndef BQ_SLOTS
+#define BQ_SLOTS BQ_P
 #endif
+__shared__ double bq_lds_d[BQ_ND * BQ_SLOTS];
+__shared__ int bq_lds_i[BQ_NI * BQ_SLOTS];
+struct Bobyqa3 { int slot; };
+#define BQ_D(i) bq_lds_d[(i) * BQ_SLOTS + B.slot]
+#define BQ_I(i) bq_lds_i[(i) * BQ_SLOTS + B.slot]
 #else
 struct Bobyqa3 { double dd[BQ_ND]; int ii[BQ_NI]; };
 #define BQ_D(i) B.dd[(i)]

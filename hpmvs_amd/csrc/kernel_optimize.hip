@@ -30,8 +30,14 @@
 #include "prof.h"
 #define BQ_STATE_LDS 1
 #ifndef BQ_P
-#define BQ_P 8
+#define BQ_P 10
 #endif
+// wavefronts per workgroup: they share ONE set of texel staging buffers (EvalLds) under a lock, which is what
+// lets 10 instead of 8 patches per wavefront fit the 160 KB of LDS at 8 wavefronts per CU
+#ifndef HPMVS_WG_WAVES
+#define HPMVS_WG_WAVES 2
+#endif
+#define BQ_SLOTS (BQ_P * HPMVS_WG_WAVES)
 #include "bobyqa3.hpp"
 #include "launch.h"
 #include "photometric.hpp"
@@ -41,6 +47,7 @@ namespace hpmvs {
 namespace {
 
 constexpr int kP = BQ_P;  // patches ("slots") per wavefront: lanes 0..kP-1 own one each
+constexpr int kW = HPMVS_WG_WAVES;
 constexpr int kRow = 66;  // uint16 per LDS row: 64 ids + 2 pad -> row stride 33 dwords, conflict-free per lane
 
 enum Op { OP_NONE = 0, OP_OBJ = 1, OP_INCC = 2, OP_REFSUM = 3 };
@@ -266,11 +273,16 @@ __device__ __forceinline__ F3 patch_colour_v(DevScene sc, const uint16_t* row, i
 #ifndef HPMVS_WAVES_PER_EU
 #define HPMVS_WAVES_PER_EU 2
 #endif
-__global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
-    __shared__ uint16_t lists[kP * kRow];
-    __shared__ EvalLds evlds;
+__global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
+    __shared__ uint16_t lists_all[kW * kP * kRow];
+    __shared__ EvalLds evlds;  // shared by the workgroup's wavefronts, guarded by ev_lock
+    __shared__ int ev_lock;
     const int lane = lane_id();
-    uint16_t* row = &lists[lane * kRow];
+    const int wave = (int)(threadIdx.x >> 6);
+    uint16_t* lists = &lists_all[wave * kP * kRow];  // this wavefront's rows
+    uint16_t* row = &lists[(lane < kP ? lane : 0) * kRow];
+    if (threadIdx.x == 0) ev_lock = 0;
+    __syncthreads();  // the only workgroup barrier: from here on the wavefronts run independently
 
     // ---- per-lane slot state
     int stage = (lane < kP) ? S_FETCH : S_IDLE;  // lanes >= kP only help in phase B
@@ -280,7 +292,7 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
     float scale = 1.0f, refbest = 0.0f;
     OptFields F;
     Bobyqa3 B;
-    B.slot = lane < kP ? lane : 0;
+    B.slot = wave * kP + (lane < kP ? lane : 0);
     // request posted to phase B (with the patch axes of calculatePatchAxis for the request's reference image)
     float ax[3] = {0, 0, 0}, ay[3] = {0, 0, 0}, az[3] = {0, 0, 1};
     int op = OP_NONE, req_ref = 0, req_robust = 0;
@@ -294,7 +306,7 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
 
 #ifdef HPMVS_PROFILE_PHASES
     long long tA = 0, tB = 0, nrounds = 0, nreq = 0, t0 = clock64();
-    s_prof[lane] = 0ull;
+    if (wave == 0) s_prof[lane] = 0ull;
     __syncthreads();
 #endif
     for (;;) {
@@ -416,14 +428,18 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
             const DevView& RV = sc.views[row[op == OP_OBJ ? 0 : req_ref]];
             calc_patch_axes(RV.xaxis, RV.yaxis, n, scale, ax, ay, az);
         }
-        // ================= phase B: the wave serves the posted requests one patch at a time
-        __syncthreads();  // single-wave workgroup: orders the lanes' LDS list updates before cross-lane reads
+        // ================= phase B: the wave serves all posted requests in one packed pass
+        wave_lds_sync();  // orders the lanes' LDS list updates before cross-lane reads (wavefront scope)
         unsigned long long pending = __ballot(op != OP_NONE);
 #ifdef HPMVS_PROFILE_PHASES
         { const long long t1 = clock64(); tA += t1 - t0; t0 = t1; nrounds++; nreq += __popcll(pending); }
 #endif
         if (pending == 0ull) break;  // every lane idle and nothing posted: queue drained
         {
+            // the staging buffers are shared with the other wavefront(s) of the workgroup
+            if (lane == 0)
+                while (atomicCAS(&ev_lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(16);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             PackedReq q;
             q.obj_mode = (op == OP_OBJ) ? 1 : 0;
             q.ref = req_ref; q.robust = req_robust; q.nimg = nimg; q.thr = req_thr;
@@ -432,6 +448,8 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
             PackedRes r;
             r.obj = 2.0; r.keep = 0ull; r.incc_sum = 0.0f; r.ngrabs = 0;
             wave_eval_packed<kRow>(sc, o, lists, pending, q, r, evlds);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicExch(&ev_lock, 0);
             if (op != OP_NONE) {
                 res_f = r.obj;
                 res_mask = r.keep;
@@ -440,20 +458,22 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
                 op = OP_NONE;
             }
         }
-        __syncthreads();
+        wave_lds_sync();
 #ifdef HPMVS_PROFILE_PHASES
         { const long long t1 = clock64(); tB += t1 - t0; t0 = t1; }
 #endif
     }
 #ifdef HPMVS_PROFILE_PHASES
+    unsigned long long* dbg = (unsigned long long*)(queue + 4);
     if (lane == 0) {
-        unsigned long long* dbg = (unsigned long long*)(queue + 4);
         atomicAdd(&dbg[0], (unsigned long long)tA);
         atomicAdd(&dbg[1], (unsigned long long)tB);
         atomicAdd(&dbg[2], (unsigned long long)nrounds);
         atomicAdd(&dbg[3], (unsigned long long)nreq);
-        for (int k = 0; k < 64; k++) atomicAdd(&dbg[4 + k], s_prof[k]);
     }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 64; k++) atomicAdd(&dbg[4 + k], s_prof[k]);
 #endif
 }
 
@@ -462,14 +482,16 @@ void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b,
     if (b.n <= 0) return;
     // persistent single-wave workgroups, kP patches in flight per wave; LDS (~25.5 KB per wave: optimiser
     // state + image lists) admits 6 waves per CU
-    int waves = (b.n + kP - 1) / kP;
-    // waves per CU: LDS (optimiser state + lists) and the 32-waves-per-CU limit
-    const int lds_per_wave = (int)(sizeof(double) * BQ_ND * kP + sizeof(int) * BQ_NI * kP + sizeof(uint16_t) * kP * kRow + sizeof(EvalLds));
-    int per_cu = (160 * 1024) / lds_per_wave;
-    if (per_cu > 4 * HPMVS_WAVES_PER_EU) per_cu = 4 * HPMVS_WAVES_PER_EU;
+    int wgs = (b.n + kP * kW - 1) / (kP * kW);
+    // workgroups per CU: LDS (optimiser state + image lists per wavefront, one staging buffer per workgroup)
+    // and the waves-per-SIMD limit
+    const int lds_per_wg = kW * (int)(sizeof(double) * BQ_ND * kP + sizeof(int) * BQ_NI * kP + sizeof(uint16_t) * kP * kRow) +
+                           (int)sizeof(EvalLds) + 16;
+    int per_cu = (160 * 1024) / lds_per_wg;
+    if (per_cu > 4 * HPMVS_WAVES_PER_EU / kW) per_cu = 4 * HPMVS_WAVES_PER_EU / kW;
     const int cap = n_cus * per_cu;
-    if (waves > cap) waves = cap;
-    hipLaunchKernelGGL(optimize_kernel, dim3(waves), dim3(64), 0, st, sc, o, b, queue_counter);
+    if (wgs > cap) wgs = cap;
+    hipLaunchKernelGGL(optimize_kernel, dim3(wgs), dim3(64 * kW), 0, st, sc, o, b, queue_counter);
 }
 
 }  // namespace hpmvs

@@ -33,7 +33,7 @@
 #include "prof.h"
 #if defined(HPMVS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
 #define PH_T(v) const long long v = clock64()
-#define PH_ADD(v0, v1, i) do { if (__lane_id() == 0) { s_prof[2 * (i)] += (unsigned long long)((v1) - (v0)); s_prof[2 * (i) + 1] += 1ull; } } while (0)
+#define PH_ADD(v0, v1, i) do { if (__lane_id() == 0) { atomicAdd(&s_prof[2 * (i)], (unsigned long long)((v1) - (v0))); atomicAdd(&s_prof[2 * (i) + 1], 1ull); } } while (0)
 #else
 #define PH_T(v) do { } while (0)
 #define PH_ADD(v0, v1, i) do { } while (0)
