@@ -2,19 +2,19 @@
 //
 // Mapping (MI355X-first, not a translation of the reference's one-thread-per-patch OpenMP loop):
 //
-//   * A persistent grid of single-wave workgroups (8 per CU, bounded by LDS) pulls patches from a
-//     global work queue.
+//   * A persistent grid of two-wavefront workgroups (4 per CU, bounded by LDS) pulls patches from a
+//     global work queue.  The wavefronts of a workgroup are independent except that they share the
+//     texel staging buffers of phase B under an LDS lock.
 //   * Lanes 0..kP-1 of a wave each own one patch ("slot") and run that patch's control logic as
 //     plain SIMT code: the optimize() pipeline of the reference
 //     (src/hpmvs/PatchOptimizer.cpp:48-103: addImages / filterImagesNCC / sortImages /
 //     assureImageAngles / optimizePatch / ... / setRefImage) and the BOBYQA state machine
 //     (bobyqa3.hpp).  This is "phase A"; it ends when the lane needs photometric data.
-//   * Photometric work is done by the WHOLE WAVE for one patch at a time ("phase B"): the wave
-//     loops over the lanes that posted a request, broadcasts the request (centre, normal, scale,
-//     patch axes, image list) with v_readlane, and evaluates it with wave_eval_exact
-//     (photometric.hpp): lane v prepares image v, lanes 0..48 fetch the 7x7 window texels, and the
-//     reference's sequential float32 sums are formed lane-per-image from LDS-staged values.  The
-//     scalar result goes back to the requesting lane.
+//   * Photometric work is done by the WHOLE WAVE for all posted requests at once ("phase B",
+//     wave_eval_packed in photometric.hpp): the (request, image) pairs become jobs, one lane each
+//     prepares its image, the usable jobs are packed into chunks of 8 staging slots, lanes 0..48
+//     fetch the 7x7 window texels, and the reference's sequential float32 sums are formed
+//     lane-per-image from LDS-staged values.  The results go back to the requesting lanes.
 //
 //   Patches finish at different times (40-1000 evaluations); a finished lane immediately pulls the
 //   next patch from the queue, so slots stay busy until the queue drains.
@@ -480,8 +480,7 @@ __global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optim
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* queue_counter, int n_cus,
                      hipStream_t st) {
     if (b.n <= 0) return;
-    // persistent single-wave workgroups, kP patches in flight per wave; LDS (~25.5 KB per wave: optimiser
-    // state + image lists) admits 6 waves per CU
+    // persistent workgroups of kW wavefronts, kP patches in flight per wavefront
     int wgs = (b.n + kP * kW - 1) / (kP * kW);
     // workgroups per CU: LDS (optimiser state + image lists per wavefront, one staging buffer per workgroup)
     // and the waves-per-SIMD limit
