@@ -6,10 +6,11 @@ Stated tolerance.  Every float32 operation of the objective and every float64 op
 is the one the CPU executes, so the whole refinement is expected to be BIT-IDENTICAL: same
 success/failure and failing stage, same evaluation count, same centre / normal / image list /
 colour.  The only arithmetic that is not reproduced operation-for-operation is the C library's
-double acos()/cos()/log2() (used once per patch for the BOBYQA start point and the level tests;
-asinf IS reproduced, see photometric.hpp): a last-bit difference there perturbs the float64 start
-point by ~1e-16 and BOBYQA can amplify that (it moves 7 % of patches out of their basin for a 1e-9
-relative perturbation of f, tests/sensitivity_probe.py).  The tests therefore require
+double cos()/log2() (used once per patch for cosb and the level tests); asinf IS reproduced and the
+float64 acos of the start point is rounded to nearest on the device, which is what glibc returns for
+all but ~0.06 % of arguments (photometric.hpp, cr_acos.hpp).  A last-bit difference there perturbs the
+float64 start point by ~1e-16 and BOBYQA can amplify that (it moves 7 % of patches out of their basin
+for a 1e-9 relative perturbation of f, tests/sensitivity_probe.py).  The tests therefore require
   * decisions + failing stage identical            : 100 %
   * bit-identical refined patch (all float fields) : >= 99 %  (measured 100 %)
   * mean |d ncc| over all jointly successful patches <= 1e-5  (SURVEY 8d proposed 5e-3)
@@ -207,3 +208,33 @@ def test_many_views_multi_chunk_is_bit_identical():
         assert np.array_equal(np.array(Q[k].normal[:], dtype=np.float32), b.normal[k])
         assert list(Q[k].images[:Q[k].n_images]) == list(b.images[k, :b.n_images[k]]) and Q[k].nevals == b.nevals[k]
     g.close()
+
+
+@pytest.mark.parametrize("opts", [
+    dict(MIN_IMAGES_PER_PATCH=2, NCC_ALPHA_1=0.5, NCC_ALPHA_2=0.6),
+    dict(MAX_ANGLE=float(np.float32(45.0 * np.pi / 180.0)), MIN_ANGLE=float(np.float32(5.0 * np.pi / 180.0)), NCC_ALPHA_1=0.3, NCC_ALPHA_2=0.4),
+])
+def test_non_default_options_are_honoured_identically(opts, tiny_seeds, oracle_scene, gpu_scene):
+    """HpmvsOptions fields the path reads (reference include/hpmvs/HpmvsOptions.h:29-58) reach the kernel and
+    the oracle alike: decisions, stages and refined patches stay identical, and differ from the defaults."""
+    from hpmvs_amd import api
+    from oracle import oracle as orc
+    og, oc = api.default_options(), orc.default_options()
+    for k, v in opts.items():
+        setattr(og, k, v)
+        setattr(oc, k, v)
+    b = api.Batch.from_seeds(tiny_seeds)
+    api.optimize_batch(gpu_scene, b, og)
+    P = orc.patches_from_seeds(tiny_seeds)
+    orc.optimize_batch(oracle_scene, P, options=oc, n_threads=8)
+    stage_cpu = np.array([p.stage for p in P])
+    assert np.array_equal(stage_cpu, b.stage)
+    ok = np.nonzero(b.ok)[0]
+    assert len(ok) >= 20
+    for k in ok:
+        assert np.array_equal(np.array(P[k].center[:], dtype=np.float32), b.center[k])
+        assert np.array_equal(np.array(P[k].normal[:], dtype=np.float32), b.normal[k])
+        assert list(P[k].images[:P[k].n_images]) == list(b.images[k, :b.n_images[k]])
+    d = api.Batch.from_seeds(tiny_seeds)
+    api.optimize_batch(gpu_scene, d)
+    assert not np.array_equal(d.stage, b.stage) or not np.array_equal(d.center, b.center)
