@@ -118,11 +118,15 @@ enum {  // float64 slots: arrays first (names as in Powell's paper / bobyqb_), t
     O_fbeg = 174,
     O_stepa = 175,
     O_stepb = 176,
-    O_ptsaux = 177,
-    O_ptsid = 183,
-    O_fbase_r = 190,
-    O_vquad_r = 191,
-    BQ_ND = 192
+    BQ_ND = 177,
+    // rescue_ state (bobyqa.c:143-742) overlays vectors that are dead between label 190 and the next
+    // trust-region / geometry step: xnew, xalt, d are recomputed by trsbox / altmov before they are read
+    // again, wsuma only lives from label 230 to the evaluation that follows it.  (15 doubles per patch
+    // = one more patch per wavefront in LDS.)
+    O_ptsaux = O_xnew,   // 6 = xnew[3] + xalt[3]
+    O_ptsid = O_wsuma,   // 7
+    O_fbase_r = O_d,
+    O_vquad_r = O_d + 1
 };
 enum {  // int32 slots
     I_rc = 0,

@@ -19,7 +19,7 @@
 //   Patches finish at different times (40-1000 evaluations); a finished lane immediately pulls the
 //   next patch from the queue, so slots stay busy until the queue drains.
 //
-//   The per-patch optimiser state (192 float64 + 13 int32) and image lists (uint16 ids, padded
+//   The per-patch optimiser state (177 float64 + 13 int32) and image lists (uint16 ids, padded
 //   rows) live in LDS as [index][slot], so the kP lanes touch consecutive words and none of it goes
 //   through scratch / HBM.  (A first version kept the state in per-lane scratch for 64 patches per
 //   wave: PMC showed 2.1 G scratch/flat instructions and 157 GB of HBM traffic per 1e5-patch launch
