@@ -2,9 +2,9 @@
 //
 // Mapping (MI355X-first, not a translation of the reference's one-thread-per-patch OpenMP loop):
 //
-//   * A persistent grid of two-wavefront workgroups (4 per CU, bounded by LDS) pulls patches from a
-//     global work queue.  The wavefronts of a workgroup are independent except that they share the
-//     texel staging buffers of phase B under an LDS lock.
+//   * A persistent grid of single-wavefront workgroups (8 per CU, bounded by LDS) pulls patches from a
+//     global work queue.  (HPMVS_WG_WAVES > 1 builds multi-wavefront workgroups whose wavefronts share
+//     the texel staging buffers of phase B under an LDS lock.)
 //   * Lanes 0..kP-1 of a wave each own one patch ("slot") and run that patch's control logic as
 //     plain SIMT code: the optimize() pipeline of the reference
 //     (src/hpmvs/PatchOptimizer.cpp:48-103: addImages / filterImagesNCC / sortImages /
@@ -30,12 +30,14 @@
 #include "prof.h"
 #define BQ_STATE_LDS 1
 #ifndef BQ_P
-#define BQ_P 10
+#define BQ_P 9
 #endif
-// wavefronts per workgroup: they share ONE set of texel staging buffers (EvalLds) under a lock, which is what
-// lets 10 instead of 8 patches per wavefront fit the 160 KB of LDS at 8 wavefronts per CU
+// Wavefronts per workgroup.  With more than one they share ONE set of texel staging buffers (EvalLds) under
+// an LDS lock, which trades lock waits for LDS: 2 x 10 slots was the best configuration while the optimiser
+// state was 1588 B per patch; with the 1468 B state 9 slots and a private buffer fit 8 single-wave workgroups
+// per CU (158.9 of 160 KB) and run 1-2 % faster, so that is the default.
 #ifndef HPMVS_WG_WAVES
-#define HPMVS_WG_WAVES 2
+#define HPMVS_WG_WAVES 1
 #endif
 #define BQ_SLOTS (BQ_P * HPMVS_WG_WAVES)
 #include "bobyqa3.hpp"
@@ -437,9 +439,11 @@ __global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optim
         if (pending == 0ull) break;  // every lane idle and nothing posted: queue drained
         {
             // the staging buffers are shared with the other wavefront(s) of the workgroup
-            if (lane == 0)
-                while (atomicCAS(&ev_lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(16);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (kW > 1) {
+                if (lane == 0)
+                    while (atomicCAS(&ev_lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(16);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
             PackedReq q;
             q.obj_mode = (op == OP_OBJ) ? 1 : 0;
             q.ref = req_ref; q.robust = req_robust; q.nimg = nimg; q.thr = req_thr;
@@ -448,8 +452,10 @@ __global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optim
             PackedRes r;
             r.obj = 2.0; r.keep = 0ull; r.incc_sum = 0.0f; r.ngrabs = 0;
             wave_eval_packed<kRow>(sc, o, lists, pending, q, r, evlds);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) atomicExch(&ev_lock, 0);
+            if (kW > 1) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) atomicExch(&ev_lock, 0);
+            }
             if (op != OP_NONE) {
                 res_f = r.obj;
                 res_mask = r.keep;
