@@ -1325,17 +1325,20 @@ BQ_HD int run(BqRef B, int label) {
     for (;;) {
         const bool live = (label != LRET_CONT && label != LRET_DONE);
         if (!__any(live)) break;
+        // Priority = a topological order of the label graph (20 -> 60; 650 -> 680 | 60 | 90; 680 -> 60 | 360;
+        // 60 -> 650 | 90; 90 -> 210 | 230; 210 -> 230; 230 -> 360): a label runs only when no lane can still
+        // arrive at it from an earlier one, so each block executes about once per round for all lanes.
         int pick = LRET_DONE;
         if (__any(live && label == L20)) pick = L20;
-        else if (__any(live && label == L90)) pick = L90;
         else if (__any(live && label == L650)) pick = L650;
         else if (__any(live && label == L680)) pick = L680;
         else if (__any(live && label == L720)) pick = L720;
         else if (__any(live && label == L190)) pick = L190;
-        else if (__any(live && label == L360)) pick = L360;
         else if (__any(live && label == L60)) pick = L60;
+        else if (__any(live && label == L90)) pick = L90;
         else if (__any(live && label == L210)) pick = L210;
         else if (__any(live && label == L230)) pick = L230;
+        else if (__any(live && label == L360)) pick = L360;
         if (live && label == pick) {
             BQ_PROF_BEGIN(tl_);
             const int was = label;
