@@ -1609,7 +1609,7 @@ BQ_HD_NOINLINE int bq_step_(BqRef B, double f) {
             }
         }
     } else if (BQN(phase) == bq::PH_MAIN) {
-        label = bq::after_eval(B, f);
+        { BQ_PROF_BEGIN(tae_); label = bq::after_eval(B, f); BQ_PROF_END(tae_, 23); }
     } else if (BQN(phase) == bq::PH_RESCUE) {
         label = bq::rescue_consume(B, f);
     }

@@ -74,3 +74,50 @@ def test_expand_rejects_bad_arguments(tiny_scene, tiny_seeds, gpu_scene):
                       np.zeros(0, np.int32), np.zeros((0, par.max_images), np.int32))
     out = api.expand_batch(gpu_scene, 0, empty, np.zeros((0, 3), np.float32), np.zeros(0, np.float32))
     assert out.n == 0
+
+
+def test_expand_with_device_pointers_on_a_stream(tiny_scene, tiny_seeds, gpu_scene):
+    """on_device = 1: every array is a device pointer and the call only enqueues on the given hipStream_t
+    (torch is just the allocator / stream here).  Same results as the host-pointer form."""
+    import ctypes as C
+    import torch
+    from hpmvs_amd import api
+    par = refined_parents(tiny_scene, tiny_seeds, gpu_scene)
+    n, N = par.n, 6
+    width = (par.scale * np.float32(2.0 / 0.9)).astype(np.float32)
+    cc = np.ascontiguousarray(par.center[:, :3])
+    want = api.expand_batch(gpu_scene, api.EXPAND_EXTEND, par, cc, width)
+    dev = torch.device("cuda", 0)
+
+    def dbatch(m, src=None):
+        t = dict(center=torch.zeros((m, 4), dtype=torch.float32, device=dev), normal=torch.zeros((m, 4), dtype=torch.float32, device=dev),
+                 scale=torch.zeros(m, dtype=torch.float32, device=dev), n_images=torch.zeros(m, dtype=torch.int32, device=dev),
+                 images=torch.full((m, par.max_images), -1, dtype=torch.int32, device=dev),
+                 ok=torch.zeros(m, dtype=torch.uint8, device=dev), stage=torch.zeros(m, dtype=torch.int32, device=dev))
+        if src is not None:
+            for k in ("center", "normal", "scale", "n_images", "images"):
+                t[k].copy_(torch.from_numpy(getattr(src, k)))
+        b = api.PatchBatch()
+        b.n, b.max_images = m, par.max_images
+        for k, v in t.items():
+            setattr(b, k, v.data_ptr())
+        return t, b
+
+    pt, pb = dbatch(n, par)
+    ot, ob = dbatch(n * N)
+    dcc, dcw = torch.from_numpy(cc).to(dev), torch.from_numpy(width).to(dev)
+    stream = torch.cuda.Stream(device=dev)
+    stream.wait_stream(torch.cuda.current_stream(dev))  # the uploads above ran on the current stream
+    o = api.default_options()
+    with torch.cuda.stream(stream):
+        rc = api.lib().hpmvs_expand_batch(gpu_scene.h, C.byref(o), api.EXPAND_EXTEND, C.byref(pb), dcc.data_ptr(), dcw.data_ptr(),
+                                          None, C.byref(ob), 1, C.c_void_p(stream.cuda_stream))
+    assert rc == 0, api.lib().hpmvs_last_error()
+    stream.synchronize()
+    assert np.array_equal(ot["ok"].cpu().numpy(), want.ok)
+    assert np.array_equal(ot["stage"].cpu().numpy(), want.stage)
+    assert np.array_equal(ot["center"].cpu().numpy(), want.center)
+    assert np.array_equal(ot["normal"].cpu().numpy(), want.normal)
+    assert np.array_equal(ot["scale"].cpu().numpy(), want.scale)
+    acc = want.ok.astype(bool)
+    assert np.array_equal(ot["n_images"].cpu().numpy()[acc], want.n_images[acc])
