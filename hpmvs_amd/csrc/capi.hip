@@ -16,11 +16,12 @@
 
 using namespace hpmvs;
 
-// Each optimize launch gets its own work-queue counter block, handed out round-robin, so that launches
-// issued concurrently from several host threads / streams (the reference runs one PatchOptimizer per
-// OpenMP thread against one shared Scene: src/hpmvs/Scene.cpp:94-96,166-167) never share a counter.
-static constexpr int kQueueSlots = 64;
-static constexpr size_t kQueueSlotBytes = 1024;
+// Each optimize launch gets its own workspace (work-queue counter block + the per-slot image-list rows),
+// handed out round-robin, so that launches issued concurrently from several host threads / streams (the
+// reference runs one PatchOptimizer per OpenMP thread against one shared Scene: src/hpmvs/Scene.cpp:94-96,
+// 166-167) never share one.  16 launches in flight per scene; each of them fills the GPU.
+static constexpr int kQueueSlots = 16;
+static constexpr size_t kQueueSlotBytes = 1024;  // the counter block at the head of a workspace (zeroed per launch)
 
 static thread_local std::string g_err;
 
@@ -48,7 +49,8 @@ struct hpmvs_scene {
     DevView* dviews = nullptr;
     int32_t* dcovis_off = nullptr;
     int32_t* dcovis = nullptr;
-    int32_t* dqueue = nullptr;          // kQueueSlots work-queue counter blocks (1 KB each), one per in-flight launch
+    int32_t* dqueue = nullptr;          // kQueueSlots launch workspaces of ws_bytes each
+    size_t ws_bytes = 0;
     mutable unsigned next_slot = 0;
     mutable int32_t* last_queue = nullptr;
     size_t bytes = 0;
@@ -229,8 +231,9 @@ int hpmvs_scene_commit(hpmvs_scene* s) {
     HIPCHK(hipMemcpy(s->dcovis_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&s->dcovis, sizeof(int32_t) * flat.size()));
     HIPCHK(hipMemcpy(s->dcovis, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)&s->dqueue, kQueueSlots * kQueueSlotBytes));
-    HIPCHK(hipMemset(s->dqueue, 0, kQueueSlots * kQueueSlotBytes));
+    s->ws_bytes = (optimize_workspace_bytes(s->n_cus) + 255) & ~(size_t)255;
+    HIPCHK(hipMalloc((void**)&s->dqueue, kQueueSlots * s->ws_bytes));
+    HIPCHK(hipMemset(s->dqueue, 0, kQueueSlots * s->ws_bytes));
     s->bytes += sizeof(DevView) * (size_t)s->n_views + sizeof(int32_t) * (off.size() + flat.size());
     s->committed = true;
     return HPMVS_OK;
@@ -415,7 +418,7 @@ int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_pat
         int32_t* q;
         {
             std::lock_guard<std::mutex> lk(s->mu);  // counter slot + the scene's single event pair
-            q = (int32_t*)((char*)s->dqueue + (size_t)(s->next_slot++ % kQueueSlots) * kQueueSlotBytes);
+            q = (int32_t*)((char*)s->dqueue + (size_t)(s->next_slot++ % kQueueSlots) * s->ws_bytes);
             s->last_queue = q;
             HIPCHK(hipMemsetAsync(q, 0, kQueueSlotBytes, st));
             HIPCHK(hipEventRecord(s->ev0, st));
@@ -477,7 +480,7 @@ int hpmvs_init_patches_batch(const hpmvs_scene* s, const hpmvs_options* o, int s
     {
         {
             std::lock_guard<std::mutex> lk(s->mu);
-            int32_t* q = (int32_t*)((char*)s->dqueue + (size_t)(s->next_slot++ % kQueueSlots) * kQueueSlotBytes);
+            int32_t* q = (int32_t*)((char*)s->dqueue + (size_t)(s->next_slot++ % kQueueSlots) * s->ws_bytes);
             s->last_queue = q;
             launch_seed_init(dev_scene(s), d, start_level, n_points, dxyz, doff, dimg, sg.d, st);
             HIPCHK(hipGetLastError());
@@ -542,7 +545,7 @@ int hpmvs_expand_batch(const hpmvs_scene* s, const hpmvs_options* o, int mode, c
     const DevOptions d = make_dev_options(o);
     {
         std::lock_guard<std::mutex> lk(s->mu);
-        int32_t* q = (int32_t*)((char*)s->dqueue + (size_t)(s->next_slot++ % kQueueSlots) * kQueueSlotBytes);
+        int32_t* q = (int32_t*)((char*)s->dqueue + (size_t)(s->next_slot++ % kQueueSlots) * s->ws_bytes);
         s->last_queue = q;
         launch_expand_init(dev_scene(s), mode, parents->n, sp.d, dcc, dcw, dskip, sg.d, st);
         HIPCHK(hipGetLastError());

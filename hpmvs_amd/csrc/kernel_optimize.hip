@@ -30,12 +30,12 @@
 #include "prof.h"
 #define BQ_STATE_LDS 1
 #ifndef BQ_P
-#define BQ_P 9
+#define BQ_P 10
 #endif
 // Wavefronts per workgroup.  With more than one they share ONE set of texel staging buffers (EvalLds) under
-// an LDS lock, which trades lock waits for LDS: 2 x 10 slots was the best configuration while the optimiser
-// state was 1588 B per patch; with the 1468 B state 9 slots and a private buffer fit 8 single-wave workgroups
-// per CU (158.9 of 160 KB) and run 1-2 % faster, so that is the default.
+// an LDS lock, which trades lock waits (~7 % of a round) for LDS; the default is single-wavefront workgroups
+// with a private buffer: 10 x 1468 B of optimiser state + 5.4 KB of staging = 20.1 KB, 8 per CU.  (The image
+// lists, touched a dozen times per patch, live in a global-memory workspace, not in LDS.)
 #ifndef HPMVS_WG_WAVES
 #define HPMVS_WG_WAVES 1
 #endif
@@ -50,7 +50,8 @@ namespace {
 
 constexpr int kP = BQ_P;  // patches ("slots") per wavefront: lanes 0..kP-1 own one each
 constexpr int kW = HPMVS_WG_WAVES;
-constexpr int kRow = 66;  // uint16 per LDS row: 64 ids + 2 pad -> row stride 33 dwords, conflict-free per lane
+constexpr int kRow = 64;  // uint16 ids per image-list row (global workspace, one row per slot)
+constexpr size_t kCounterBytes = 1024;  // head of the launch workspace: work-queue counter (+ profiling counters)
 
 enum Op { OP_NONE = 0, OP_OBJ = 1, OP_INCC = 2, OP_REFSUM = 3 };
 enum Stage {
@@ -276,12 +277,12 @@ __device__ __forceinline__ F3 patch_colour_v(DevScene sc, const uint16_t* row, i
 #define HPMVS_WAVES_PER_EU 2
 #endif
 __global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
-    __shared__ uint16_t lists_all[kW * kP * kRow];
     __shared__ EvalLds evlds;  // shared by the workgroup's wavefronts, guarded by ev_lock
     __shared__ int ev_lock;
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
-    uint16_t* lists = &lists_all[wave * kP * kRow];  // this wavefront's rows
+    // this wavefront's image-list rows in the launch workspace (behind the counter block)
+    uint16_t* lists = (uint16_t*)((char*)queue + kCounterBytes) + (size_t)(blockIdx.x * kW + wave) * kP * kRow;
     uint16_t* row = &lists[(lane < kP ? lane : 0) * kRow];
     if (threadIdx.x == 0) ev_lock = 0;
     __syncthreads();  // the only workgroup barrier: from here on the wavefronts run independently
@@ -483,20 +484,27 @@ __global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optim
 #endif
 }
 
-void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* queue_counter, int n_cus,
+static int max_workgroups(int n_cus) {
+    // workgroups per CU: LDS (optimiser state per wavefront, one staging buffer per workgroup) and the
+    // waves-per-SIMD limit
+    const int lds_per_wg = kW * (int)(sizeof(double) * BQ_ND * kP + sizeof(int) * BQ_NI * kP) + (int)sizeof(EvalLds) + 16;
+    int per_cu = (160 * 1024) / lds_per_wg;
+    if (per_cu > 4 * HPMVS_WAVES_PER_EU / kW) per_cu = 4 * HPMVS_WAVES_PER_EU / kW;
+    return n_cus * per_cu;
+}
+
+size_t optimize_workspace_bytes(int n_cus) {
+    return kCounterBytes + (size_t)max_workgroups(n_cus) * kW * kP * kRow * sizeof(uint16_t);
+}
+
+void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus,
                      hipStream_t st) {
     if (b.n <= 0) return;
     // persistent workgroups of kW wavefronts, kP patches in flight per wavefront
     int wgs = (b.n + kP * kW - 1) / (kP * kW);
-    // workgroups per CU: LDS (optimiser state + image lists per wavefront, one staging buffer per workgroup)
-    // and the waves-per-SIMD limit
-    const int lds_per_wg = kW * (int)(sizeof(double) * BQ_ND * kP + sizeof(int) * BQ_NI * kP + sizeof(uint16_t) * kP * kRow) +
-                           (int)sizeof(EvalLds) + 16;
-    int per_cu = (160 * 1024) / lds_per_wg;
-    if (per_cu > 4 * HPMVS_WAVES_PER_EU / kW) per_cu = 4 * HPMVS_WAVES_PER_EU / kW;
-    const int cap = n_cus * per_cu;
+    const int cap = max_workgroups(n_cus);
     if (wgs > cap) wgs = cap;
-    hipLaunchKernelGGL(optimize_kernel, dim3(wgs), dim3(64 * kW), 0, st, sc, o, b, queue_counter);
+    hipLaunchKernelGGL(optimize_kernel, dim3(wgs), dim3(64 * kW), 0, st, sc, o, b, workspace);
 }
 
 }  // namespace hpmvs

@@ -21,8 +21,10 @@ void launch_expand_init(const DevScene& sc, int mode, int n, const DevBatch& par
                         const float* cell_width, const uint8_t* skip, const DevBatch& out, hipStream_t st);
 void launch_expand_gate(int mode, int n, const DevBatch& parents, const float* cell_center, const float* cell_width,
                         const DevBatch& out, hipStream_t st);
-// workspace: one int32 work-queue counter (zeroed by the launcher on `st`)
-void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* queue_counter,
+// workspace: optimize_workspace_bytes(n_cus) bytes per in-flight launch; its first 1 KB (work-queue counter)
+// must be zero when the kernel starts
+size_t optimize_workspace_bytes(int n_cus);
+void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace,
                      int n_cus, hipStream_t st);
 
 }  // namespace hpmvs
