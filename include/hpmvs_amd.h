@@ -24,6 +24,10 @@
  *   hpmvs_inccs_batch        <- PatchOptimizer::setINCCs, PatchOptimizer.cpp:448-474.
  *   hpmvs_build_pyramid      <- Image::load's pyramid, src/hpmvs/Image.cpp:55-63
  *                               (CImg get_resize_halfXY, thirdLibs/cimg/CImg.h:21189-21203).
+ *   hpmvs_init_patches_batch <- the seed loop of Scene::initPatches, src/hpmvs/Scene.cpp:112-178.
+ *   hpmvs_expand_batch       <- the candidate loops of CellProcessor::extend / ::branch,
+ *                               src/hpmvs/CellProcessor.cpp:84-142 and :210-262.
+ *   hpmvs_camera_from_nvm    <- Camera::init, src/hpmvs/Camera.cpp:34-81.
  */
 #ifndef HPMVS_AMD_H
 #define HPMVS_AMD_H
