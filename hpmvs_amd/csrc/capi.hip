@@ -55,9 +55,28 @@ struct hpmvs_scene {
     mutable int32_t* last_queue = nullptr;
     size_t bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t slot_done[kQueueSlots] = {};   // recorded behind the last launch that used workspace k
+    mutable bool slot_used[kQueueSlots] = {};
     mutable std::mutex mu;
     mutable bool timed = false;
 };
+
+// Workspace hand-out (call with s->mu held).  Before a workspace is reused the launch that used it last must
+// have finished: more than kQueueSlots launches in flight against one scene (e.g. 256 OpenMP threads each
+// calling optimize()) simply queue up here instead of sharing a counter / image-list rows.
+static int acquire_workspace(const hpmvs_scene* s, int32_t** q, int* slot) {
+    const int k = (int)(s->next_slot++ % kQueueSlots);
+    if (s->slot_used[k]) HIPCHK(hipEventSynchronize(s->slot_done[k]));
+    *q = (int32_t*)((char*)s->dqueue + (size_t)k * s->ws_bytes);
+    *slot = k;
+    s->last_queue = *q;
+    return HPMVS_OK;
+}
+static int release_workspace(const hpmvs_scene* s, int slot, hipStream_t st) {
+    HIPCHK(hipEventRecord(s->slot_done[slot], st));
+    s->slot_used[slot] = true;
+    return HPMVS_OK;
+}
 
 extern "C" {
 
@@ -231,6 +250,7 @@ int hpmvs_scene_commit(hpmvs_scene* s) {
     HIPCHK(hipMemcpy(s->dcovis_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&s->dcovis, sizeof(int32_t) * flat.size()));
     HIPCHK(hipMemcpy(s->dcovis, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice));
+    for (int k = 0; k < kQueueSlots; k++) HIPCHK(hipEventCreateWithFlags(&s->slot_done[k], hipEventDisableTiming));
     s->ws_bytes = (optimize_workspace_bytes(s->n_cus) + 255) & ~(size_t)255;
     HIPCHK(hipMalloc((void**)&s->dqueue, kQueueSlots * s->ws_bytes));
     HIPCHK(hipMemset(s->dqueue, 0, kQueueSlots * s->ws_bytes));
@@ -247,6 +267,7 @@ int hpmvs_scene_destroy(hpmvs_scene* s) {
     if (s->dcovis_off) hipFree(s->dcovis_off);
     if (s->dcovis) hipFree(s->dcovis);
     if (s->dqueue) hipFree(s->dqueue);
+    for (int k = 0; k < kQueueSlots; k++) if (s->slot_done[k]) hipEventDestroy(s->slot_done[k]);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
     delete s;
@@ -418,14 +439,15 @@ int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_pat
         int32_t* q;
         {
             std::lock_guard<std::mutex> lk(s->mu);  // counter slot + the scene's single event pair
-            q = (int32_t*)((char*)s->dqueue + (size_t)(s->next_slot++ % kQueueSlots) * s->ws_bytes);
-            s->last_queue = q;
+            int slot;
+            if ((rc = acquire_workspace(s, &q, &slot))) return rc;
             HIPCHK(hipMemsetAsync(q, 0, kQueueSlotBytes, st));
             HIPCHK(hipEventRecord(s->ev0, st));
             launch_optimize(dev_scene(s), d, sg.d, q, s->n_cus, st);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(s->ev1, st));
             s->timed = true;
+            if ((rc = release_workspace(s, slot, st))) return rc;
         }
         if (!on_device) HIPCHK(hipStreamSynchronize(st));
     }
@@ -480,8 +502,9 @@ int hpmvs_init_patches_batch(const hpmvs_scene* s, const hpmvs_options* o, int s
     {
         {
             std::lock_guard<std::mutex> lk(s->mu);
-            int32_t* q = (int32_t*)((char*)s->dqueue + (size_t)(s->next_slot++ % kQueueSlots) * s->ws_bytes);
-            s->last_queue = q;
+            int32_t* q;
+            int slot;
+            if ((rc = acquire_workspace(s, &q, &slot))) return rc;
             launch_seed_init(dev_scene(s), d, start_level, n_points, dxyz, doff, dimg, sg.d, st);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemsetAsync(q, 0, kQueueSlotBytes, st));
@@ -492,6 +515,7 @@ int hpmvs_init_patches_batch(const hpmvs_scene* s, const hpmvs_options* o, int s
             s->timed = true;
             launch_drift_gate(n_points, dxyz, sg.d, st);
             HIPCHK(hipGetLastError());
+            if ((rc = release_workspace(s, slot, st))) return rc;
         }
         if (!on_device) HIPCHK(hipStreamSynchronize(st));
     }
@@ -545,8 +569,9 @@ int hpmvs_expand_batch(const hpmvs_scene* s, const hpmvs_options* o, int mode, c
     const DevOptions d = make_dev_options(o);
     {
         std::lock_guard<std::mutex> lk(s->mu);
-        int32_t* q = (int32_t*)((char*)s->dqueue + (size_t)(s->next_slot++ % kQueueSlots) * s->ws_bytes);
-        s->last_queue = q;
+        int32_t* q;
+        int slot;
+        if ((rc = acquire_workspace(s, &q, &slot))) return rc;
         launch_expand_init(dev_scene(s), mode, parents->n, sp.d, dcc, dcw, dskip, sg.d, st);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemsetAsync(q, 0, kQueueSlotBytes, st));
@@ -557,6 +582,7 @@ int hpmvs_expand_batch(const hpmvs_scene* s, const hpmvs_options* o, int mode, c
         s->timed = true;
         launch_expand_gate(mode, parents->n, sp.d, dcc, dcw, sg.d, st);
         HIPCHK(hipGetLastError());
+        if ((rc = release_workspace(s, slot, st))) return rc;
     }
     if (!on_device) {
         HIPCHK(hipStreamSynchronize(st));

@@ -75,18 +75,18 @@ int main(int argc, char** argv) {
                copy.center_[2], copy.normal_[0], copy.normal_[1], copy.normal_[2], copy.images_.size());
     }
     // (1b) the reference's data-parallel form (src/hpmvs/Scene.cpp:94-96,114,166-167): one optimizer per OpenMP
-    //      thread, all calling optimize() concurrently against the one shared scene
-    {
-        const int nthreads = 4;
+    //      thread, all calling optimize() concurrently against the one shared scene -- with 4 threads, and with
+    //      40 (more concurrent launches than the scene has launch workspaces: they must queue, not collide)
+    for (int nthreads : {4, 40}) {
         std::vector<mo3d::PatchOptimizer> pool;
         for (int i = 0; i < nthreads; i++) pool.emplace_back(options, &scene);
         std::vector<mo3d::Patch3d> copies;
         for (int i = 0; i < np; i++) copies.emplace_back(*patches[i]);
         std::vector<int> okv(np, 0);
-#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 4)
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
         for (int i = 0; i < np; i++) okv[i] = pool[omp_get_thread_num()].optimize(copies[i]) ? 1 : 0;
         for (int i = 0; i < np; i++)
-            printf("omp %d %d %.9g %.9g %.9g %.9g %.9g %.9g %zu\n", i, okv[i], copies[i].center_[0], copies[i].center_[1],
+            printf("omp%d %d %d %.9g %.9g %.9g %.9g %.9g %.9g %zu\n", nthreads, i, okv[i], copies[i].center_[0], copies[i].center_[1],
                    copies[i].center_[2], copies[i].normal_[0], copies[i].normal_[1], copies[i].normal_[2],
                    copies[i].images_.size());
     }

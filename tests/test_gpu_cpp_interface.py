@@ -54,16 +54,17 @@ def test_cpp_patchoptimizer_equals_c_abi(tiny_scene, tiny_seeds, gpu_scene, tmp_
         if ok:
             vals = np.array([float(t) for t in r[3:9]], dtype=np.float32)
             assert np.array_equal(vals, np.concatenate([batch.center[k, :3], batch.normal[k, :3]]).astype(np.float32))
-    # four OpenMP threads, one PatchOptimizer each, concurrent optimize() calls == the batch results
-    omp = [l.split() for l in out if l.startswith("omp")]
-    assert len(omp) == n
-    for r in omp:
-        k, ok = int(r[1]), int(r[2])
-        assert ok == batch.ok[k]
-        if ok:
-            vals = np.array([float(t) for t in r[3:9]], dtype=np.float32)
-            assert np.array_equal(vals, np.concatenate([batch.center[k, :3], batch.normal[k, :3]]).astype(np.float32))
-            assert int(r[9]) == batch.n_images[k]
+    # 4 and 40 OpenMP threads, one PatchOptimizer each, concurrent optimize() calls == the batch results
+    for tag in ("omp4", "omp40"):
+        omp = [l.split() for l in out if l.split()[0] == tag]
+        assert len(omp) == n
+        for r in omp:
+            k, ok = int(r[1]), int(r[2])
+            assert ok == batch.ok[k], (tag, k)
+            if ok:
+                vals = np.array([float(t) for t in r[3:9]], dtype=np.float32)
+                assert np.array_equal(vals, np.concatenate([batch.center[k, :3], batch.normal[k, :3]]).astype(np.float32)), (tag, k)
+                assert int(r[9]) == batch.n_images[k]
     assert int(out[-1].split()[1]) == int(batch.ok.sum())
     # PatchOptimizer::expandBatch (CellProcessor::extend candidates for every refined patch) == hpmvs_expand_batch
     keep = np.nonzero(batch.ok)[0]
