@@ -489,7 +489,16 @@ __device__ __forceinline__ float shfl_f(float v, int src_lane) {
 }
 __device__ __forceinline__ int shfl_i(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 
-// lists: LDS rows of ROW uint16 image ids, row p belongs to lane p.  Must be called by all 64 lanes.
+// end of a setINCCs request: sequential float sum of the per-image values (lane k holds inccs[k]) and the
+// filterImagesNCC mask; out of line so that the unrolled delivery loop carries one copy
+__device__ __noinline__ void incc_finalize(float mine, int np, float thr, unsigned long long& keep, float& sum) {
+    float s = 0.0f;
+    for (int k = 0; k < np; k++) s += bcast_f(mine, k);
+    sum = s;
+    keep = __ballot(mine < 1.0f - thr);
+}
+
+// lists: rows of ROW uint16 image ids, row p belongs to lane p.  Must be called by all 64 lanes.
 template <int ROW>
 __device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOptions& o, const uint16_t* lists,
                                                  unsigned long long pending, const PackedReq& q, PackedRes& out,
@@ -580,11 +589,9 @@ __device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOp
             if (cur_obj) {
                 if (lane == cur) { d_val = val; d_nok = nok; out.ngrabs += ngr; }
             } else {
-                const int np = bcast_i(q.nimg, cur);
-                float s = 0.0f;
-                for (int k = 0; k < np; k++) s += bcast_f(mine, k);
-                const float thr = bcast_f(q.thr, cur);
-                const unsigned long long keep = __ballot(mine < 1.0f - thr);
+                unsigned long long keep;
+                float s;
+                incc_finalize(mine, bcast_i(q.nimg, cur), bcast_f(q.thr, cur), keep, s);
                 if (lane == cur) { out.keep = keep; out.incc_sum = s; out.ngrabs += ngr; }
             }
         };
@@ -594,13 +601,11 @@ __device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOp
             PH_T(t3);
             // job lane of every slot (wave-uniform), also kept per lane for the dynamic delivery loop
             int jl[S];
-            int jlv = 0;
             unsigned int refslots = 0u;
 #pragma unroll
             for (int s = 0; s < S; s++) {
                 const unsigned long long m = __ballot(pos == cb + s);
                 jl[s] = m ? __ffsll((long long)m) - 1 : 0;
-                if (lane == s) jlv = jl[s];
                 if (s < ns && ((refjobs >> jl[s]) & 1ull)) refslots |= 1u << s;
             }
             // ---- 1. fetch + stage
@@ -679,8 +684,10 @@ __device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOp
             PH_T(t7);
             PH_ADD(t6, t7, 21);
             // ---- deliver in sequence order
-            for (int s = 0; s < ns; s++) {
-                const int v = bcast_i(jlv, s);
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                if (s >= ns) break;
+                const int v = jl[s];
                 if ((refslots >> s) & 1u) {
                     if (cur >= 0) finalize();
                     cur = bcast_i(myp, v);
