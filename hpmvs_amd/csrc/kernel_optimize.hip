@@ -288,7 +288,11 @@ __global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optim
     __syncthreads();  // the only workgroup barrier: from here on the wavefronts run independently
 
     // ---- per-lane slot state
-    int stage = (lane < kP) ? S_FETCH : S_IDLE;  // lanes >= kP only help in phase B
+    // Small batches are spread over as many wavefronts as possible (a wavefront with fewer busy slots has
+    // shorter rounds: one lone patch advances ~2.4x faster than one of ten), so only `quota` lanes pull work.
+    const int n_waves = (int)gridDim.x * kW;
+    const int quota = (b.n + n_waves - 1) / n_waves < kP ? (b.n + n_waves - 1) / n_waves : kP;
+    int stage = (lane < quota) ? S_FETCH : S_IDLE;  // the other lanes only help in phase B
     int idx = -1, nimg = 0, ii = 0, refindex = -1, ngrabs = 0, fail_stage = 0, nl_result = 0;
     float c0[3] = {0, 0, 0}, n0[3] = {0, 0, 0};  // optimize() input (kept for "patch untouched")
     float c[3] = {0, 0, 0}, n[3] = {0, 0, 1};    // pCenter_, pNormal_
@@ -501,7 +505,7 @@ void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b,
                      hipStream_t st) {
     if (b.n <= 0) return;
     // persistent workgroups of kW wavefronts, kP patches in flight per wavefront
-    int wgs = (b.n + kP * kW - 1) / (kP * kW);
+    int wgs = (b.n + kW - 1) / kW;  // up to one wavefront per patch (see `quota` in the kernel)
     const int cap = max_workgroups(n_cus);
     if (wgs > cap) wgs = cap;
     hipLaunchKernelGGL(optimize_kernel, dim3(wgs), dim3(64 * kW), 0, st, sc, o, b, workspace);
