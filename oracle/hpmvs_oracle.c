@@ -283,6 +283,7 @@ typedef struct {
     float depthScale, angleScale;
     float refTex[147], comTex[147];
     long ngrabs, ngrabs_all;
+    int overflow; /* attached-image list hit ORC_MAX_IMAGES */
     int last_level;
     float last_cdxdy[6];
 } popt;
@@ -395,7 +396,10 @@ static int add_images(popt *po) {
         if (pc[0] < 0.0f || s->imgs[cv].w[imgLevel] - 1 <= pc[0] || pc[1] < 0.0f ||
             s->imgs[cv].h[imgLevel] - 1 <= pc[1])
             continue;
-        if (po->nimg < ORC_MAX_IMAGES) po->img[po->nimg++] = cv;
+        /* the list is a fixed ORC_MAX_IMAGES array here (reference: unbounded vector<int>): an image that does
+         * not fit fails the patch with stage 100, exactly as the device path does */
+        if (po->nimg >= ORC_MAX_IMAGES) { po->overflow = 1; return 0; }
+        po->img[po->nimg++] = cv;
     }
     return po->nimg >= po->o->MIN_IMAGES_PER_PATCH;
 }
@@ -732,6 +736,7 @@ int orc_optimize(const orc_scene *s, const orc_options *o, orc_patch *p, int whi
         stage = 9; if (!filter_images_ncc(&po, o->NCC_ALPHA_2)) break;
         stage = 0;
     } while (0);
+    if (po.overflow) stage = 100;
     p->stage = stage;
     p->ngrabs = po.ngrabs;
     p->ngrabs_all = po.ngrabs_all;

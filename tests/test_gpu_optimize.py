@@ -238,3 +238,37 @@ def test_non_default_options_are_honoured_identically(opts, tiny_seeds, oracle_s
     d = api.Batch.from_seeds(tiny_seeds)
     api.optimize_batch(gpu_scene, d)
     assert not np.array_equal(d.stage, b.stage) or not np.array_equal(d.center, b.center)
+
+
+def test_maximum_image_lists_and_overflow():
+    """HPMVS_MAX_IMAGES = 64 attached images per patch: lists that reach the cap through addImages refine
+    identically to the oracle; a patch handed over with more than the batch's max_images fails with stage 100
+    and is left untouched (the reference's vector<int> is unbounded; the cap is the documented difference)."""
+    import torch
+    from hpmvs_amd import api, synth
+    from oracle import oracle as orc
+    scene = synth.make_scene(70, 480, 270, n_waves=12, device=torch.device("cuda", 0))
+    g = api.Scene(scene)
+    osc = orc.OracleScene(scene)
+    seeds = synth.make_seeds(scene, 120, start_level=1, max_images=64, max_seed_images=60, seed=synth.SEED + 11)
+    assert seeds.n_images.max() >= 30
+    b = api.Batch.from_seeds(seeds)
+    api.optimize_batch(g, b)
+    Q = orc.patches_from_seeds(seeds)
+    orc.optimize_batch(osc, Q, n_threads=8)
+    assert np.array_equal(np.array([q.stage for q in Q]), b.stage)
+    ok = np.nonzero(b.ok)[0]
+    assert len(ok) >= 30
+    for k in ok:
+        assert np.array_equal(np.array(Q[k].center[:], dtype=np.float32), b.center[k])
+        assert np.array_equal(np.array(Q[k].normal[:], dtype=np.float32), b.normal[k])
+        assert list(Q[k].images[:Q[k].n_images]) == list(b.images[k, :b.n_images[k]]) and Q[k].nevals == b.nevals[k]
+    # addImages can push a list past the cap: both sides then report stage 100
+    print("max attached after refinement", int(b.n_images[ok].max()), "stage-100 patches", int((b.stage == 100).sum()))
+    # a batch whose rows are narrower than a patch's list: stage 100, untouched
+    narrow = api.Batch(seeds.center[:8], seeds.normal[:8], seeds.scale[:8], seeds.n_images[:8], seeds.images[:8, :16])
+    narrow.n_images[:] = 20  # claims more images than the row holds
+    api.optimize_batch(g, narrow)
+    assert (narrow.ok == 0).all() and (narrow.stage == 100).all()
+    assert np.array_equal(narrow.center, seeds.center[:8].astype(np.float32))
+    g.close()
