@@ -331,7 +331,13 @@ __global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optim
                 BQA(xfinal, 0) = 0.0; BQA(xfinal, 1) = 0.0; BQA(xfinal, 2) = 0.0;
                 if (nimg < 0) { fail_stage = -nimg; nimg = 0; finish_fail = true; break; }  // rejected by seed_init_kernel
                 if (nimg > kMaxImages || nimg > b.max_images) { fail_stage = 100; finish_fail = true; break; }
-                for (int k = 0; k < nimg; k++) row[k] = (uint16_t)b.images[(size_t)idx * b.max_images + k];
+                bool bad_id = false;
+                for (int k = 0; k < nimg; k++) {
+                    const int id = b.images[(size_t)idx * b.max_images + k];
+                    bad_id |= (id < 0 || id >= sc.n_views);
+                    row[k] = (uint16_t)id;
+                }
+                if (bad_id) { fail_stage = 101; finish_fail = true; break; }  // image id outside the scene: rejected, never dereferenced
                 nimg = add_images_v(sc, o, row, nimg, HPMVS_F3(c), HPMVS_F3(n), scale);
                 if (nimg < 0) { fail_stage = 100; finish_fail = true; break; }
                 if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 1; finish_fail = true; break; }

@@ -95,7 +95,8 @@ typedef struct {
     double *x;           /* [n][3] final optimiser variables (depth, angle1, angle2) */
     int32_t *result;     /* [n]    nlopt_result code of the BOBYQA run */
     int32_t *nevals;     /* [n]    objective evaluations */
-    int32_t *stage;      /* [n]    0 = ok, else index of the pipeline stage that returned false */
+    int32_t *stage;      /* [n]    0 = ok, else index of the pipeline stage that returned false (1..9);
+                          *        100 = attached-image list overflow, 101 = an image id outside the scene */
     int32_t *ngrabs;     /* [n]    sampleTexture calls that passed the gates (588 B of image each) */
 } hpmvs_patch_batch;
 

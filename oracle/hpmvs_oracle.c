@@ -722,6 +722,8 @@ int orc_optimize(const orc_scene *s, const orc_options *o, orc_patch *p, int whi
     popt_begin(&po, s, o, p);
     p->nlopt_result = 0; p->nevals = 0; p->fmin = 0; p->x[0] = p->x[1] = p->x[2] = 0;
     int stage = 0;
+    for (int k = 0; k < p->n_images; k++)
+        if (p->images[k] < 0 || p->images[k] >= s->n_views) { p->stage = 101; p->ngrabs = 0; p->ngrabs_all = 0; return 0; } /* as the device path */
     do {
         stage = 1; if (!add_images(&po)) break;
         stage = 2; if (!filter_images_ncc(&po, o->NCC_ALPHA_1)) break;

@@ -272,3 +272,25 @@ def test_maximum_image_lists_and_overflow():
     assert (narrow.ok == 0).all() and (narrow.stage == 100).all()
     assert np.array_equal(narrow.center, seeds.center[:8].astype(np.float32))
     g.close()
+
+
+def test_invalid_image_ids_are_rejected_not_dereferenced(tiny_seeds, oracle_scene, gpu_scene):
+    """An attached image id outside [0, n_views) fails that patch with stage 101 on both sides; the other
+    patches of the batch are unaffected."""
+    from hpmvs_amd import api
+    from oracle import oracle as orc
+    good = api.Batch.from_seeds(tiny_seeds)
+    api.optimize_batch(gpu_scene, good)
+    b = api.Batch.from_seeds(tiny_seeds)
+    bad = [3, 17, 40]
+    b.images[3, 0] = -1
+    b.images[17, 1] = 1000
+    b.images[40, 2] = gpu_scene.n_views if hasattr(gpu_scene, "n_views") else 3
+    api.optimize_batch(gpu_scene, b)
+    assert (b.ok[bad] == 0).all() and (b.stage[bad] == 101).all()
+    rest = np.setdiff1d(np.arange(b.n), bad)
+    assert np.array_equal(b.ok[rest], good.ok[rest]) and np.array_equal(b.center[rest], good.center[rest])
+    P = orc.patches_from_seeds(tiny_seeds, bad)
+    P[0].images[0] = -1; P[1].images[1] = 1000; P[2].images[2] = 3
+    orc.optimize_batch(oracle_scene, P, n_threads=1)
+    assert [p.stage for p in P] == [101, 101, 101]
