@@ -59,3 +59,52 @@ def test_objective_parity(tiny_seeds, oracle_scene, gpu_scene):
         f_cpu = np.array([orc.objective_at(oracle_scene, P[k], x[k]) for k in range(len(idx))])
         assert np.array_equal(f_gpu, f_cpu), np.abs(f_gpu - f_cpu).max()
         assert (f_cpu < 2.0).sum() > 10
+
+
+@pytest.mark.parametrize("kind", ["noise", "flat_blocks", "saturated"])
+def test_photometric_parity_on_hostile_images(kind, tiny_scene, tiny_seeds):
+    """Images the smooth synthetic texture never produces: uint8 noise (large variances), 16x16 constant blocks
+    (windows with zero variance -> the `ave2 == 0 -> 1` branch of Patch2d::normalize, Patch2d.hpp:71-72) and
+    0/255 saturation.  setINCCs, objective_fn and the full refinement stay bit-identical to the oracle; the
+    packed evaluator (optimize) and the one-request evaluator (objective/inccs kernels) both see them."""
+    import copy
+    from hpmvs_amd import api
+    from oracle import oracle as orc
+    rng = np.random.default_rng({"noise": 1, "flat_blocks": 2, "saturated": 3}[kind])
+    scene = copy.copy(tiny_scene)
+    scene.views = []
+    for v in tiny_scene.views:
+        h, w = v.height, v.width
+        if kind == "noise":
+            img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        elif kind == "flat_blocks":
+            small = rng.integers(0, 256, size=(h // 16 + 1, w // 16 + 1, 3), dtype=np.uint8)
+            img = np.repeat(np.repeat(small, 16, axis=0), 16, axis=1)[:h, :w]
+        else:
+            img = (rng.integers(0, 2, size=(h // 4 + 1, w // 4 + 1, 3), dtype=np.uint8) * 255)
+            img = np.repeat(np.repeat(img, 4, axis=0), 4, axis=1)[:h, :w]
+        nv = copy.copy(v)
+        nv.rgb = np.ascontiguousarray(img)
+        scene.views.append(nv)
+    g = api.Scene(scene)
+    osc = orc.OracleScene(scene)
+    idx = np.nonzero(tiny_seeds.n_images >= 3)[0][:120]
+    batch = api.Batch.from_seeds(tiny_seeds, idx)
+    P = orc.patches_from_seeds(tiny_seeds, idx)
+    for ref_idx, robust in [(0, 0), (1, 1)]:
+        got = api.inccs_batch(g, batch, ref_idx, robust)
+        for k in range(len(idx)):
+            assert np.array_equal(got[k, :P[k].n_images], orc.inccs(osc, P[k], ref_idx, robust)), (kind, k)
+    x0 = np.array([orc.initial_parameters(osc, P[k]) for k in range(len(idx))])
+    f_gpu, _ = api.objective_batch(g, batch, x0)
+    f_cpu = np.array([orc.objective_at(osc, P[k], x0[k]) for k in range(len(idx))])
+    assert np.array_equal(f_gpu, f_cpu)
+    b = api.Batch.from_seeds(tiny_seeds, idx)
+    api.optimize_batch(g, b)
+    Q = orc.patches_from_seeds(tiny_seeds, idx)
+    orc.optimize_batch(osc, Q, n_threads=8)
+    assert np.array_equal(np.array([q.stage for q in Q]), b.stage)
+    for k in np.nonzero(b.ok)[0]:
+        assert np.array_equal(np.array(Q[k].center[:], dtype=np.float32), b.center[k])
+        assert Q[k].nevals == b.nevals[k]
+    g.close()
