@@ -3,8 +3,7 @@
 // Mapping (MI355X-first, not a translation of the reference's one-thread-per-patch OpenMP loop):
 //
 //   * A persistent grid of single-wavefront workgroups (8 per CU, bounded by LDS) pulls patches from a
-//     global work queue.  (HPMVS_WG_WAVES > 1 builds multi-wavefront workgroups whose wavefronts share
-//     the texel staging buffers of phase B under an LDS lock.)
+//     global work queue.
 //   * Lanes 0..kP-1 of a wave each own one patch ("slot") and run that patch's control logic as
 //     plain SIMT code: the optimize() pipeline of the reference
 //     (src/hpmvs/PatchOptimizer.cpp:48-103: addImages / filterImagesNCC / sortImages /
@@ -32,14 +31,11 @@
 #ifndef BQ_P
 #define BQ_P 10
 #endif
-// Wavefronts per workgroup.  With more than one they share ONE set of texel staging buffers (EvalLds) under
-// an LDS lock, which trades lock waits (~7 % of a round) for LDS; the default is single-wavefront workgroups
-// with a private buffer: 10 x 1468 B of optimiser state + 5.4 KB of staging = 20.1 KB, 8 per CU.  (The image
-// lists, touched a dozen times per patch, live in a global-memory workspace, not in LDS.)
-#ifndef HPMVS_WG_WAVES
-#define HPMVS_WG_WAVES 1
-#endif
-#define BQ_SLOTS (BQ_P * HPMVS_WG_WAVES)
+// Single-wavefront workgroups: 10 x 1468 B of optimiser state + 5.4 KB of texel staging = 20.1 KB of LDS, 8 per
+// CU.  (The image lists, touched a dozen times per patch, live in a global-memory workspace, not in LDS.
+// Multi-wavefront workgroups -- sharing the staging buffers under a lock, or scheduling the BOBYQA blocks of all
+// their slots cooperatively -- were measured 5-25 % slower, DESIGN.md section 6, and are gone.)
+#define BQ_SLOTS BQ_P
 #include "bobyqa3.hpp"
 #include "launch.h"
 #include "photometric.hpp"
@@ -49,7 +45,6 @@ namespace hpmvs {
 namespace {
 
 constexpr int kP = BQ_P;  // patches ("slots") per wavefront: lanes 0..kP-1 own one each
-constexpr int kW = HPMVS_WG_WAVES;
 constexpr int kRow = 64;  // uint16 ids per image-list row (global workspace, one row per slot)
 constexpr size_t kCounterBytes = 1024;  // head of the launch workspace: work-queue counter (+ profiling counters)
 
@@ -276,21 +271,17 @@ __device__ __forceinline__ F3 patch_colour_v(DevScene sc, const uint16_t* row, i
 #ifndef HPMVS_WAVES_PER_EU
 #define HPMVS_WAVES_PER_EU 2
 #endif
-__global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
-    __shared__ EvalLds evlds;  // shared by the workgroup's wavefronts, guarded by ev_lock
-    __shared__ int ev_lock;
+__global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
+    __shared__ EvalLds evlds;  // texel staging of phase B
     const int lane = lane_id();
-    const int wave = (int)(threadIdx.x >> 6);
     // this wavefront's image-list rows in the launch workspace (behind the counter block)
-    uint16_t* lists = (uint16_t*)((char*)queue + kCounterBytes) + (size_t)(blockIdx.x * kW + wave) * kP * kRow;
+    uint16_t* lists = (uint16_t*)((char*)queue + kCounterBytes) + (size_t)blockIdx.x * kP * kRow;
     uint16_t* row = &lists[(lane < kP ? lane : 0) * kRow];
-    if (threadIdx.x == 0) ev_lock = 0;
-    __syncthreads();  // the only workgroup barrier: from here on the wavefronts run independently
 
     // ---- per-lane slot state
     // Small batches are spread over as many wavefronts as possible (a wavefront with fewer busy slots has
     // shorter rounds: one lone patch advances ~2.4x faster than one of ten), so only `quota` lanes pull work.
-    const int n_waves = (int)gridDim.x * kW;
+    const int n_waves = (int)gridDim.x;
     const int quota = (b.n + n_waves - 1) / n_waves < kP ? (b.n + n_waves - 1) / n_waves : kP;
     int stage = (lane < quota) ? S_FETCH : S_IDLE;  // the other lanes only help in phase B
     int idx = -1, nimg = 0, ii = 0, refindex = -1, ngrabs = 0, fail_stage = 0, nl_result = 0;
@@ -299,7 +290,7 @@ __global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optim
     float scale = 1.0f, refbest = 0.0f;
     OptFields F;
     Bobyqa3 B;
-    B.slot = wave * kP + (lane < kP ? lane : 0);
+    B.slot = lane < kP ? lane : 0;
     // request posted to phase B (with the patch axes of calculatePatchAxis for the request's reference image)
     float ax[3] = {0, 0, 0}, ay[3] = {0, 0, 0}, az[3] = {0, 0, 1};
     int op = OP_NONE, req_ref = 0, req_robust = 0;
@@ -313,7 +304,7 @@ __global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optim
 
 #ifdef HPMVS_PROFILE_PHASES
     long long tA = 0, tB = 0, nrounds = 0, nreq = 0, t0 = clock64();
-    if (wave == 0) s_prof[lane] = 0ull;
+    s_prof[lane] = 0ull;
     __syncthreads();
 #endif
     for (;;) {
@@ -442,19 +433,13 @@ __global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optim
             calc_patch_axes(RV.xaxis, RV.yaxis, n, scale, ax, ay, az);
         }
         // ================= phase B: the wave serves all posted requests in one packed pass
-        wave_lds_sync();  // orders the lanes' LDS list updates before cross-lane reads (wavefront scope)
+        wave_lds_sync();  // orders the lanes' image-list updates (global workspace) before the cross-lane reads of phase B
         unsigned long long pending = __ballot(op != OP_NONE);
 #ifdef HPMVS_PROFILE_PHASES
         { const long long t1 = clock64(); tA += t1 - t0; t0 = t1; nrounds++; nreq += __popcll(pending); }
 #endif
         if (pending == 0ull) break;  // every lane idle and nothing posted: queue drained
         {
-            // the staging buffers are shared with the other wavefront(s) of the workgroup
-            if (kW > 1) {
-                if (lane == 0)
-                    while (atomicCAS(&ev_lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(16);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
             PackedReq q;
             q.obj_mode = (op == OP_OBJ) ? 1 : 0;
             q.ref = req_ref; q.robust = req_robust; q.nimg = nimg; q.thr = req_thr;
@@ -463,10 +448,6 @@ __global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optim
             PackedRes r;
             r.obj = 2.0; r.keep = 0ull; r.incc_sum = 0.0f; r.ngrabs = 0;
             wave_eval_packed<kRow>(sc, o, lists, pending, q, r, evlds);
-            if (kW > 1) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) atomicExch(&ev_lock, 0);
-            }
             if (op != OP_NONE) {
                 res_f = r.obj;
                 res_mask = r.keep;
@@ -497,24 +478,24 @@ __global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optim
 static int max_workgroups(int n_cus) {
     // workgroups per CU: LDS (optimiser state per wavefront, one staging buffer per workgroup) and the
     // waves-per-SIMD limit
-    const int lds_per_wg = kW * (int)(sizeof(double) * BQ_ND * kP + sizeof(int) * BQ_NI * kP) + (int)sizeof(EvalLds) + 16;
+    const int lds_per_wg = (int)(sizeof(double) * BQ_ND * kP + sizeof(int) * BQ_NI * kP) + (int)sizeof(EvalLds) + 16;
     int per_cu = (160 * 1024) / lds_per_wg;
-    if (per_cu > 4 * HPMVS_WAVES_PER_EU / kW) per_cu = 4 * HPMVS_WAVES_PER_EU / kW;
+    if (per_cu > 4 * HPMVS_WAVES_PER_EU) per_cu = 4 * HPMVS_WAVES_PER_EU;
     return n_cus * per_cu;
 }
 
 size_t optimize_workspace_bytes(int n_cus) {
-    return kCounterBytes + (size_t)max_workgroups(n_cus) * kW * kP * kRow * sizeof(uint16_t);
+    return kCounterBytes + (size_t)max_workgroups(n_cus) * kP * kRow * sizeof(uint16_t);
 }
 
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus,
                      hipStream_t st) {
     if (b.n <= 0) return;
-    // persistent workgroups of kW wavefronts, kP patches in flight per wavefront
-    int wgs = (b.n + kW - 1) / kW;  // up to one wavefront per patch (see `quota` in the kernel)
+    // persistent single-wavefront workgroups, kP patches in flight each
+    int wgs = b.n;  // up to one wavefront per patch (see `quota` in the kernel)
     const int cap = max_workgroups(n_cus);
     if (wgs > cap) wgs = cap;
-    hipLaunchKernelGGL(optimize_kernel, dim3(wgs), dim3(64 * kW), 0, st, sc, o, b, workspace);
+    hipLaunchKernelGGL(optimize_kernel, dim3(wgs), dim3(64), 0, st, sc, o, b, workspace);
 }
 
 }  // namespace hpmvs
