@@ -7,10 +7,14 @@
 One "step" = one expansion round: every rank runs the full optimize() (image selection, BOBYQA
 refinement of depth + normal against NCC over the attached views, reference-image selection) on
 its shard of synthetic seed patches, all inputs already resident in HBM, and -- for N > 1 -- one
-RCCL all-gather of the fixed-size refined-patch records (north_star's exchange step).  Scaling is
-weak: every rank refines `--patches` seeds of the same replicated scene.
+RCCL all-gather of the fixed-size refined-patch records (north_star's exchange step).
 
-Workload (BASELINE.json configs[1]): 12 synthetic 1920x1080 views, 1e5 seed patches per GPU.
+Default workload = the configuration BASELINE.json's metric is quoted on (configs[2], "c2"): 50
+synthetic 3840x2160 views, 1e6 seed patches per GPU.  `--scaling weak` (default): every rank refines
+its own 1e6 seeds of the replicated scene.  `--scaling strong` (configs[3]/[4], "c3"/"c4"): ONE
+batch, identical on every rank, is cut with `shard_range` (reference Scene.cpp:94-96,114: the
+OpenMP loop over one seed vector) and the refined records are all-gathered, so every rank ends the
+step holding the full refined set.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     : algorithmic image bytes of the refinement kernel (588 B per sampleTexture that
@@ -41,11 +45,17 @@ from hpmvs_amd import api, synth  # noqa: E402
 from hpmvs_amd import distributed as dd  # noqa: E402
 
 WORKLOADS = {
-    # name: (views, width, height, seeds per GPU, start_level)
-    "c0_tiny": (3, 640, 480, 200, 2),
-    "c1_12v_1080p_1e5": (12, 1920, 1080, 100_000, 4),
-    "c2_50v_4k_1e6": (50, 3840, 2160, 1_000_000, 4),
+    # name: (views, width, height, seeds [per GPU when weak, in total when strong], start_level, default scaling)
+    "c0_tiny": (3, 640, 480, 200, 2, "weak"),
+    "c1_12v_1080p_1e5": (12, 1920, 1080, 100_000, 4, "weak"),
+    "c2_50v_4k_1e6": (50, 3840, 2160, 1_000_000, 4, "weak"),               # BASELINE configs[2]: the headline
+    "c3_50v_4k_1e6_sharded": (50, 3840, 2160, 1_000_000, 4, "strong"),     # configs[3]: c2's batch cut across the ranks
+    "c4_200v_4k_1e7": (200, 3840, 2160, 10_000_000, 4, "strong"),          # configs[4]: 6.6 GB of pyramids per GPU
+    # stress: START_LEVEL 1 puts the 7x7 windows in pyramid levels 0-1 (1.55 GB for 50 views, far beyond
+    # the 256 MB MALL), the case in which image bytes really come from HBM
+    "s1_50v_4k_1e6_level1": (50, 3840, 2160, 1_000_000, 1, "weak"),
 }
+DEFAULT_WORKLOAD = "c2_50v_4k_1e6"
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 RECORD_BYTES = dd.RECORD_BYTES  # all-gathered refined-patch record
 
@@ -80,10 +90,11 @@ def c_batch(t, n, max_images):
     return b
 
 
-def pack_records(t):
-    """Fixed 128-byte refined-patch record per patch (what one expansion round exchanges)."""
+def pack_records(t, check=False):
+    """Fixed-size refined-patch record per patch (what one expansion round exchanges).  The id / count
+    ranges are validated in the warm-up steps (check=True costs a device sync), not in the timed ones."""
     return dd.pack_records(t["center"], t["normal"], t["color"], t["scale"], t["fmin"], t["ok"], t["n_images"],
-                           t["images"])
+                           t["images"], check=check)
 
 
 def main():
@@ -91,9 +102,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c1_12v_1080p_1e5", choices=list(WORKLOADS))
-    ap.add_argument("--patches", type=int, default=0, help="override seeds per GPU")
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=list(WORKLOADS))
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak: seeds per GPU fixed; strong: one batch cut across the ranks (default: the workload's)")
+    ap.add_argument("--patches", type=int, default=0, help="override the workload's seed count")
     ap.add_argument("--cpu-sample", type=int, default=32768, help="patches of the CPU-baseline / parity sample")
+    ap.add_argument("--cpu-sample-1core", type=int, default=768, help="patches of the 1-core CPU run")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -110,10 +124,24 @@ def main():
     if use_dist:
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
-    views, W, H, n_seeds, start_level = WORKLOADS[args.workload]
+    views, W, H, n_total, start_level, scaling = WORKLOADS[args.workload]
+    if args.scaling:
+        scaling = args.scaling
     if args.patches > 0:
-        n_seeds = args.patches
+        n_total = args.patches
     max_images = 32
+    if scaling == "strong":
+        # one batch, the same on every rank; rank r refines [lo, hi) of it
+        lo, hi = dd.shard_range(n_total, rank, world)
+        counts = [dd.shard_range(n_total, r, world)[1] - dd.shard_range(n_total, r, world)[0] for r in range(world)]
+        seed_value = synth.SEED
+        n_job = n_total
+    else:
+        lo, hi = 0, n_total
+        counts = [n_total] * world
+        seed_value = synth.SEED + 977 * rank
+        n_job = world * n_total
+    n_seeds = hi - lo  # patches this rank refines per step
 
     # ---- scene: rendered on the GPU, replicated on every rank, resident in HBM
     t0 = time.time()
@@ -121,13 +149,16 @@ def main():
     gpu_scene = api.Scene(scene, device=local_rank)
     torch.cuda.synchronize()
     t_scene = time.time() - t0
-    seeds = synth.make_seeds(scene, n_seeds, start_level=start_level, max_images=max_images, seed=synth.SEED + 977 * rank)
+    seeds = synth.make_seeds(scene, n_total, start_level=start_level, max_images=max_images, seed=seed_value)
+    if scaling == "strong" and world > 1:
+        seeds = synth.Seeds(center=seeds.center[lo:hi], normal=seeds.normal[lo:hi], scale=seeds.scale[lo:hi],
+                            n_images=seeds.n_images[lo:hi], images=seeds.images[lo:hi], truth=seeds.truth[lo:hi])
     pristine = device_batch(seeds, dev, max_images)
     work = {k: v.clone() for k, v in pristine.items()}
     opts = api.default_options()
     L = api.lib()
     stream = torch.cuda.current_stream().cuda_stream
-    gathered = torch.empty((world * n_seeds, RECORD_BYTES), dtype=torch.uint8, device=dev) if use_dist else None
+    gathered = None
 
     events = []
 
@@ -145,7 +176,8 @@ def main():
         if timed:
             events.append((e0, e1))
         if use_dist:
-            dist.all_gather_into_tensor(gathered, pack_records(work))  # == dd.all_gather_records (equal shards)
+            nonlocal gathered
+            gathered = dd.all_gather_records(pack_records(work, check=not timed), counts)  # ONE collective per round
 
     def fence():
         torch.cuda.synchronize()
@@ -169,6 +201,37 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
+    # ---- SURVEY 8d's wall definition ("seeds on host -> refined records on host"): the same step with the
+    # seed arrays coming from pinned host memory and the refined fields copied back, timed separately (PCIe
+    # inclusive; reported beside `value`, never as `value`)
+    h2h = None
+    if not use_dist:
+        in_keys = ("center", "normal", "scale", "n_images", "images")
+        out_keys = ("center", "normal", "n_images", "images", "ok", "color", "fmin")
+        host_in = {k: pristine[k].cpu().pin_memory() for k in in_keys}
+        host_out = {k: torch.empty_like(work[k], device="cpu").pin_memory() for k in out_keys}
+        def h2h_step():
+            for k in in_keys:
+                work[k].copy_(host_in[k], non_blocking=True)
+            b = c_batch(work, n_seeds, max_images)
+            rc = L.hpmvs_optimize_batch(gpu_scene.h, C.byref(opts), C.byref(b), 1, C.c_void_p(stream))
+            if rc != 0:
+                raise RuntimeError(L.hpmvs_last_error().decode())
+            for k in out_keys:
+                host_out[k].copy_(work[k], non_blocking=True)
+        h2h_step()
+        torch.cuda.synchronize()
+        reps = max(1, min(3, args.steps))
+        th = time.perf_counter()
+        for _ in range(reps):
+            h2h_step()
+        torch.cuda.synchronize()
+        th = (time.perf_counter() - th) / reps
+        h2h = {"value": n_seeds / th, "unit": "patches/s", "ms_per_step": 1e3 * th, "steps": reps,
+               "bytes_in": int(sum(host_in[k].numel() * host_in[k].element_size() for k in in_keys)),
+               "bytes_out": int(sum(host_out[k].numel() * host_out[k].element_size() for k in out_keys)),
+               "what": "pinned host seeds -> H2D -> optimize_kernel -> D2H of the refined Patch3d fields, one stream"}
+
     ok = work["ok"].cpu().numpy().astype(bool)
     ngrabs = work["ngrabs"].cpu().numpy().astype(np.int64)
     nevals = work["nevals"].cpu().numpy()
@@ -180,21 +243,23 @@ def main():
 
     out = {
         "metric": "refined_patches_per_sec",
-        "value": world * n_seeds * args.steps / elapsed,
+        "value": n_job * args.steps / elapsed,
         "unit": "patches/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32 textures / f64 optimiser",
         "data": "synthetic",
         "config": {"workload": args.workload, "views": views, "image": f"{W}x{H}", "pyramid_levels": 6,
-                   "seeds_per_gpu": n_seeds, "start_level": start_level, "max_images": max_images,
+                   "seeds_per_gpu": n_seeds, "seeds_per_step_all_gpus": n_job, "start_level": start_level,
+                   "max_images": max_images,
                    "parallelism": f"patch-shard x{world} + all-gather of {RECORD_BYTES} B records"},
-        "successes_per_sec": world * float(ok.sum()) * args.steps / elapsed,
+        "host_to_host": h2h,
+        "successes_per_sec_rank0_extrapolated": n_job * float(ok.mean()) * args.steps / elapsed,
         "success_fraction": float(ok.mean()),
         "mean_evals_per_refined_patch": float(nevals[nevals > 0].mean()) if (nevals > 0).any() else 0.0,
         "mean_grabs_per_patch": float(ngrabs.mean()),
@@ -213,6 +278,10 @@ def main():
             if rec and rec.get("seeds_per_gpu") == n_seeds:
                 out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = rec.get("source")
+                # instruction-issue view of the same kernel (it is issue bound, not HBM bound: DESIGN.md section 6)
+                for k in ("valu_lane_utilization", "valu_insts_per_patch", "kernel_commit"):
+                    if k in rec:
+                        out["roofline"][k] = rec[k]
         except Exception:
             pass
 
@@ -228,6 +297,20 @@ def main():
         tc = time.perf_counter()
         orc.optimize_batch(osc, P, which=which, n_threads=cores)
         tc = time.perf_counter() - tc
+        # the same loop on ONE core, smaller sample
+        m1 = min(args.cpu_sample_1core, m)
+        P1 = orc.patches_from_seeds(seeds, np.arange(m1))
+        t1 = time.perf_counter()
+        orc.optimize_batch(osc, P1, which=which, n_threads=1)
+        t1 = time.perf_counter() - t1
+        cpu_model, sockets = "unknown", 0
+        try:
+            info = open("/proc/cpuinfo").read()
+            names = [l.split(":", 1)[1].strip() for l in info.splitlines() if l.startswith("model name")]
+            cpu_model = names[0] if names else "unknown"
+            sockets = len({l.split(":", 1)[1].strip() for l in info.splitlines() if l.startswith("physical id")})
+        except Exception:
+            pass
         okc = np.array([p.stage == 0 for p in P])
         okg = ok[:m]
         both = np.nonzero(okc & okg)[0]
@@ -257,6 +340,9 @@ def main():
                       f"Scene::initPatches; photometric path = oracle/ C restatement, optimiser = "
                       f"{'genuine NLopt 2.4.2 BOBYQA (oracle/_ref)' if which == orc.OPT_REF else 'oracle BOBYQA port'}",
             "seconds": tc, "successes": int(okc.sum()),
+            "optimizer_is_reference_nlopt": bool(which == orc.OPT_REF),
+            "cpu_model": cpu_model, "sockets": sockets, "hardware_threads": cores,
+            "one_core": {"value": m1 / t1, "unit": "patches/s", "cores": 1, "sample": f"first {m1} seeds", "seconds": t1},
         }
         out["parity"] = {
             "sample": m, "decision_agreement": float((okc == okg).mean()),

@@ -4,9 +4,19 @@ The refinement path has no data dependence between patches (reference
 src/hpmvs/PatchOptimizer.cpp:78-103 reads only its own Patch3d and the immutable scene; the
 reference itself runs it as an OpenMP loop over seeds, src/hpmvs/Scene.cpp:114).  One process per
 GPU refines a contiguous block of the batch against its own replica of the scene; the only
-exchange is ONE all-gather per expansion round of fixed 128-byte records, so that every rank holds
+exchange is ONE all-gather per expansion round of fixed-size records, so that every rank holds
 the full refined set before the host scheduler inserts it (RCCL over xGMI on the GPU box, gloo in
 the CPU tests).  No all-reduce, no ring dependency.
+
+Record (192 bytes, the layout of `hpmvs_record` in include/hpmvs_amd.h -- the C ABI packs the same
+bytes on the device with `hpmvs_pack_records`):
+
+    0   center[4] f32      16  normal[4] f32     32  color[3] f32     44  scale f32
+    48  fmin f64           56  ok u8             57  pad u8           58  n_images u16
+    60  pad[4]             64  images[64] u16 (unused slots 0xFFFF)
+
+All 64 image ids of the ABI (`HPMVS_MAX_IMAGES`) travel; an id that does not fit 16 bits or a list
+longer than 64 raises instead of truncating.
 """
 from __future__ import annotations
 
@@ -14,8 +24,9 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-RECORD_BYTES = 128
-MAX_RECORD_IMAGES = 32  # ids stored as uint16
+RECORD_BYTES = 192
+MAX_RECORD_IMAGES = 64  # == HPMVS_MAX_IMAGES; ids stored as uint16
+NO_IMAGE = 0xFFFF
 
 
 def shard_range(n: int, rank: int, world: int):
@@ -25,9 +36,23 @@ def shard_range(n: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def pack_records(center, normal, color, scale, fmin, ok, n_images, images) -> torch.Tensor:
-    """SoA outputs -> [n, 128] uint8 records (same layout on every rank, any device)."""
+def pack_records(center, normal, color, scale, fmin, ok, n_images, images, check: bool = True) -> torch.Tensor:
+    """SoA outputs -> [n, 192] uint8 records (same layout on every rank, any device).
+
+    `check` validates the ranges on the device (one small reduction + sync); the timed path of
+    bench.py validates once outside the timed region and passes check=False."""
     n = scale.shape[0]
+    cols = images.shape[1]
+    if cols > MAX_RECORD_IMAGES:
+        raise ValueError(f"images has {cols} columns; the record carries {MAX_RECORD_IMAGES}")
+    if check and n > 0:
+        nmax = int(n_images.max())
+        if nmax > cols or nmax > MAX_RECORD_IMAGES:
+            raise ValueError(f"a patch has {nmax} images but only {min(cols, MAX_RECORD_IMAGES)} ids can travel")
+        valid = torch.arange(cols, device=images.device)[None, :] < n_images.to(images.device)[:, None].clamp(min=0)
+        live = images[valid]
+        if live.numel() and (int(live.max()) >= NO_IMAGE or int(live.min()) < 0):
+            raise ValueError("image id outside [0, 65534] cannot be stored in the uint16 record")
     rec = torch.zeros((n, RECORD_BYTES), dtype=torch.uint8, device=scale.device)
     rec[:, 0:16] = center.contiguous().view(torch.uint8).view(n, 16)
     rec[:, 16:32] = normal.contiguous().view(torch.uint8).view(n, 16)
@@ -35,9 +60,13 @@ def pack_records(center, normal, color, scale, fmin, ok, n_images, images) -> to
     rec[:, 44:48] = scale.contiguous().view(torch.uint8).view(n, 4)
     rec[:, 48:56] = fmin.contiguous().view(torch.uint8).view(n, 8)
     rec[:, 56] = ok.to(torch.uint8)
-    rec[:, 57] = n_images.to(torch.uint8)
-    img16 = images[:, :MAX_RECORD_IMAGES].to(torch.int16).contiguous()
-    rec[:, 64:64 + 2 * img16.shape[1]] = img16.view(torch.uint8).view(n, -1)
+    rec[:, 58:60] = n_images.to(torch.int16).contiguous().view(torch.uint8).view(n, 2)
+    ids = torch.full((n, MAX_RECORD_IMAGES), -1, dtype=torch.int16, device=scale.device)  # 0xFFFF
+    nim = n_images.to(images.device)[:, None].clamp(min=0)
+    col = torch.arange(cols, device=images.device)[None, :]
+    # ids >= 32768 wrap to the same 16 bits an unsigned store would write
+    ids[:, :cols] = torch.where(col < nim, images, torch.full_like(images, -1)).to(torch.int16)
+    rec[:, 64:192] = ids.view(torch.uint8).view(n, 128)
     return rec
 
 
@@ -45,10 +74,14 @@ def unpack_records(rec: torch.Tensor) -> dict:
     rec = rec.cpu().contiguous()
     n = rec.shape[0]
     f32 = lambda a, b, c: rec[:, a:b].contiguous().view(torch.float32).view(n, c).numpy()
+    ids = rec[:, 64:192].contiguous().view(torch.int16).view(n, MAX_RECORD_IMAGES).numpy().astype(np.uint16)
+    images = ids.astype(np.int32)
+    images[ids == NO_IMAGE] = -1
     return dict(center=f32(0, 16, 4), normal=f32(16, 32, 4), color=f32(32, 44, 3), scale=f32(44, 48, 1)[:, 0],
                 fmin=rec[:, 48:56].contiguous().view(torch.float64).view(n).numpy(),
-                ok=rec[:, 56].numpy().astype(bool), n_images=rec[:, 57].numpy().astype(np.int32),
-                images=rec[:, 64:128].contiguous().view(torch.int16).view(n, MAX_RECORD_IMAGES).numpy())
+                ok=rec[:, 56].numpy().astype(bool),
+                n_images=rec[:, 58:60].contiguous().view(torch.int16).view(n).numpy().astype(np.uint16).astype(np.int32),
+                images=images)
 
 
 def all_gather_records(local: torch.Tensor, counts=None) -> torch.Tensor:

@@ -102,13 +102,23 @@ def optimizer_available(which: int) -> bool:
     return lib().orc_optimizer_available(which) == 0
 
 
-def best_optimizer() -> int:
-    """Genuine NLopt BOBYQA when oracle/_ref travelled, else the own port."""
+def best_optimizer(allow_port: bool = False) -> int:
+    """The optimiser every parity check runs: the reference's GENUINE NLopt BOBYQA (oracle/_ref).
+
+    There is no silent downgrade: oracle/bobyqa_port.cpp is a host build of the PRODUCT's own
+    bobyqa3.hpp, so comparing the HIP path against it proves nothing about the reference.  If
+    oracle/_ref did not travel this raises; the port is only used where a caller asks for it by
+    name (`which=OPT_PORT`, or allow_port=True / HPMVS_ORACLE_ALLOW_PORT=1 for timing-only use)."""
     if optimizer_available(OPT_REF):
         return OPT_REF
-    if optimizer_available(OPT_PORT):
+    if (allow_port or os.environ.get("HPMVS_ORACLE_ALLOW_PORT") == "1") and optimizer_available(OPT_PORT):
+        import sys
+        print("oracle: oracle/_ref/libref_bobyqa.so is missing -- using the BOBYQA PORT (a host build of the "
+              "product's own state machine): results are NOT a parity check", file=sys.stderr)
         return OPT_PORT
-    raise RuntimeError("oracle: neither oracle/_ref/libref_bobyqa.so nor the BOBYQA port is available")
+    raise RuntimeError("oracle: oracle/_ref/libref_bobyqa.so (genuine NLopt BOBYQA, built by oracle/Makefile from "
+                       "/root/reference in the build container) is missing; refusing to fall back to the port of the "
+                       "product's own optimiser.  Compare against tests/golden instead.")
 
 
 class OracleScene:

@@ -15,7 +15,8 @@ i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_FLAT SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM" \
-           "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+           "GRBM_GUI_ACTIVE GRBM_COUNT" \
+           "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU SQ_INSTS_VALU SQ_INSTS_SALU"; do
   i=$((i+1))
   rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $RAW/pmc$i -o p -- python bench.py --steps 1 --warmup 0 --no-cpu ${BENCH_EXTRA:-} > $OUT/bench_pmc$i.log 2>&1
   python profiles/summarize.py $RAW/pmc$i $OUT/${TAG}_pmc$i

@@ -1,5 +1,5 @@
 """world_size-2 gloo test of the multi-GPU path's host logic: contiguous patch-index sharding, the
-128-byte record pack/unpack, and ONE all-gather per round (hpmvs_amd/distributed.py).  The per-shard
+192-byte record pack/unpack, and ONE all-gather per round (hpmvs_amd/distributed.py).  The per-shard
 compute is done by the CPU oracle here (the GPU kernel is covered by the -m gpu tests)."""
 import os
 import sys
@@ -77,3 +77,41 @@ def test_two_rank_round_equals_single_rank_round():
     assert np.array_equal(two, one)
     u = dd.unpack_records(torch.from_numpy(two))
     assert u["ok"].sum() >= 10 and np.all(u["center"][:, 3][u["ok"]] == 1.0)
+
+
+def test_records_carry_all_64_ids_and_16_bit_view_numbers():
+    """no silent truncation to 32 ids / int16.  A 64-image patch and ids up to 65534 survive the
+    round trip; unused slots come back as -1, never as view 0."""
+    from hpmvs_amd import distributed as dd
+    n = 5
+    rng = np.random.default_rng(3)
+    nim = np.array([64, 33, 3, 0, 40], np.int32)
+    imgs = np.full((n, 64), -1, np.int32)
+    for k in range(n):
+        imgs[k, :nim[k]] = rng.integers(0, 65535, nim[k])
+    imgs[0, 0] = 65534
+    imgs[1, 5] = 40000
+    t = torch.from_numpy
+    rec = dd.pack_records(t(rng.random((n, 4), np.float32)), t(rng.random((n, 4), np.float32)),
+                          t(rng.random((n, 3), np.float32)), t(rng.random(n, np.float32)),
+                          t(rng.random(n)), t(np.ones(n, np.uint8)), t(nim), t(imgs))
+    assert rec.shape == (n, dd.RECORD_BYTES) and dd.RECORD_BYTES == 192
+    u = dd.unpack_records(rec)
+    assert np.array_equal(u["n_images"], nim)
+    assert np.array_equal(u["images"], imgs)
+
+
+def test_records_refuse_what_they_cannot_carry():
+    from hpmvs_amd import distributed as dd
+    import pytest
+    t = torch.from_numpy
+    base = lambda n: (t(np.zeros((n, 4), np.float32)), t(np.zeros((n, 4), np.float32)), t(np.zeros((n, 3), np.float32)),
+                      t(np.zeros(n, np.float32)), t(np.zeros(n)), t(np.ones(n, np.uint8)))
+    with pytest.raises(ValueError):  # more images than id columns handed over
+        dd.pack_records(*base(1), t(np.array([40], np.int32)), t(np.zeros((1, 32), np.int32)))
+    with pytest.raises(ValueError):  # an id that does not fit 16 bits
+        dd.pack_records(*base(1), t(np.array([2], np.int32)), t(np.array([[1, 70000] + [0] * 30], np.int32)))
+    with pytest.raises(ValueError):  # 0xFFFF is the "no image" marker
+        dd.pack_records(*base(1), t(np.array([1], np.int32)), t(np.array([[65535] + [0] * 31], np.int32)))
+    with pytest.raises(ValueError):  # wider than the ABI's 64
+        dd.pack_records(*base(1), t(np.array([1], np.int32)), t(np.zeros((1, 65), np.int32)))
