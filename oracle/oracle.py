@@ -250,3 +250,36 @@ def half_resize(img: np.ndarray) -> np.ndarray:
     out = np.zeros((h // 2, w // 2, 3), dtype=np.uint8)
     lib().orc_half_resize(img.ctypes.data, w, h, out.ctypes.data)
     return out
+
+
+# ---- the reference's GENUINE CImg pyramid (oracle/_ref/libref_cimg.so, built by oracle/Makefile from
+# /root/reference/thirdLibs/cimg/CImg.h; travels to the GPU box as a prebuilt checker like libref_bobyqa.so)
+_cimg = None
+
+
+def cimg_available() -> bool:
+    return os.path.exists(os.path.join(HERE, "_ref", "libref_cimg.so"))
+
+
+def cimg_pyramid(img: np.ndarray, n_levels: int):
+    """Image::load's pyramid (reference src/hpmvs/Image.cpp:55-63) by the genuine CImg: list of
+    interleaved uint8 [h, w, 3] arrays, level 0 first."""
+    global _cimg
+    if _cimg is None:
+        _cimg = C.CDLL(os.path.join(HERE, "_ref", "libref_cimg.so"))
+        _cimg.ref_cimg_pyramid.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    h, w, _ = img.shape
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    outs, ws, hs = [], (C.c_int * n_levels)(), (C.c_int * n_levels)()
+    ww, hh = w, h
+    for _ in range(n_levels):
+        outs.append(np.zeros((hh, ww, 3), dtype=np.uint8))
+        ww, hh = ww // 2, hh // 2
+    ptrs = (C.c_void_p * n_levels)(*[o.ctypes.data for o in outs])
+    rc = _cimg.ref_cimg_pyramid(img.ctypes.data, w, h, n_levels, ptrs, ws, hs)
+    if rc != 0:
+        raise RuntimeError("ref_cimg_pyramid failed")
+    for l in range(n_levels):
+        assert (ws[l], hs[l]) == (outs[l].shape[1], outs[l].shape[0]), "CImg level size differs from floor(w/2) x floor(h/2)"
+    return outs

@@ -7,6 +7,8 @@ known-answer cases, NLopt's own Box-Betts test function (thirdLibs/nlopt-2.4.2/t
 """
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -38,6 +40,44 @@ def test_half_resize_matches_independent_numpy_restatement():
                 acc = term if k == 0 else (acc + term).astype(np.float32)
                 k += 1
         assert np.array_equal(got, acc.astype(np.uint8)), (h, w)
+
+
+def _golden_cimg():
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g4_cimg_pyramid.npz"))
+    names = sorted({k.split("_")[0] for k in z.files})
+    return z, names
+
+
+def test_half_resize_matches_the_genuine_cimg_goldens():
+    """tests/golden/g4_cimg_pyramid.npz was produced by the reference's vendored CImg (get_resize_halfXY +
+    permute_axes("cxyz"), Image.cpp:55-63, make_golden_cimg.py): every level of every fixture, byte for byte."""
+    from oracle import oracle as orc
+    z, names = _golden_cimg()
+    for name in names:
+        cur, l = z[f"{name}_in"], 1
+        while f"{name}_l{l}" in z.files:
+            cur = orc.half_resize(cur)
+            assert np.array_equal(cur, z[f"{name}_l{l}"]), (name, l)
+            l += 1
+
+
+def test_half_resize_matches_the_genuine_cimg_library():
+    """Where oracle/_ref/libref_cimg.so is present (build container, GPU box): random images of many sizes,
+    whole pyramids, against the genuine library itself."""
+    from oracle import oracle as orc
+    if not orc.cimg_available():
+        pytest.skip("oracle/_ref/libref_cimg.so not present on this box (goldens cover it)")
+    rng = np.random.default_rng(11)
+    for (h, w) in [(2, 2), (3, 3), (5, 4), (9, 7), (64, 33), (101, 255), (480, 640), (1080, 1920)]:
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        n_levels = 1
+        while min(h, w) >> n_levels >= 1 and n_levels < 6:
+            n_levels += 1
+        ref = orc.cimg_pyramid(img, n_levels)
+        cur = img
+        for l in range(1, n_levels):
+            cur = orc.half_resize(cur)
+            assert np.array_equal(cur, ref[l]), (h, w, l)
 
 
 def test_constant_texture_hits_the_zero_variance_branch(tiny_scene):

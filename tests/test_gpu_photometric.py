@@ -108,3 +108,28 @@ def test_photometric_parity_on_hostile_images(kind, tiny_scene, tiny_seeds):
         assert np.array_equal(np.array(Q[k].center[:], dtype=np.float32), b.center[k])
         assert Q[k].nevals == b.nevals[k]
     g.close()
+
+
+def test_pyramid_matches_the_genuine_cimg():
+    """half_resize_kernel against the reference's vendored CImg: the committed goldens
+    (tests/golden/g4_cimg_pyramid.npz, produced by CImg itself) and, when oracle/_ref/libref_cimg.so
+    travelled, the library on fresh random images -- whole pyramids, byte for byte."""
+    import os
+    from hpmvs_amd import api
+    from oracle import oracle as orc
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g4_cimg_pyramid.npz"))
+    for name in sorted({k.split("_")[0] for k in z.files}):
+        cur, l = z[f"{name}_in"], 1
+        while f"{name}_l{l}" in z.files:
+            cur = api.build_pyramid(cur)
+            assert np.array_equal(cur, z[f"{name}_l{l}"]), (name, l)
+            l += 1
+    assert orc.cimg_available(), "oracle/_ref/libref_cimg.so did not travel"
+    rng = np.random.default_rng(5)
+    for (h, w) in [(9, 7), (64, 33), (480, 640), (1080, 1920), (2160, 3840)]:
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        ref = orc.cimg_pyramid(img, 6 if min(h, w) >= 64 else 3)
+        cur = img
+        for l in range(1, len(ref)):
+            cur = api.build_pyramid(cur)
+            assert np.array_equal(cur, ref[l]), (h, w, l)
