@@ -106,8 +106,9 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="weak: seeds per GPU fixed; strong: one batch cut across the ranks (default: the workload's)")
     ap.add_argument("--patches", type=int, default=0, help="override the workload's seed count")
-    ap.add_argument("--cpu-sample", type=int, default=32768, help="patches of the CPU-baseline / parity sample")
-    ap.add_argument("--cpu-sample-1core", type=int, default=768, help="patches of the 1-core CPU run")
+    ap.add_argument("--cpu-sample", type=int, default=32768, help="patches of the parity sample")
+    ap.add_argument("--cpu-timing-sample", type=int, default=262144, help="patches of the all-core CPU-baseline run")
+    ap.add_argument("--cpu-sample-1core", type=int, default=16384, help="patches of the 1-core CPU run")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -294,9 +295,15 @@ def main():
         P = orc.patches_from_seeds(seeds, idx)
         cores = os.cpu_count() or 1
         which = orc.best_optimizer()
+        orc.optimize_batch(osc, P, which=which, n_threads=cores)   # parity sample
+        # timing: a bigger bounded sample so that thread start-up does not dominate (a few seconds of all-core work)
+        mt = min(args.cpu_timing_sample, n_seeds)
+        Pt = orc.patches_from_seeds(seeds, np.arange(mt))
         tc = time.perf_counter()
-        orc.optimize_batch(osc, P, which=which, n_threads=cores)
+        orc.optimize_batch(osc, Pt, which=which, n_threads=cores)
         tc = time.perf_counter() - tc
+        okt = int(sum(1 for p in Pt if p.stage == 0))
+        del Pt
         # the same loop on ONE core, smaller sample
         m1 = min(args.cpu_sample_1core, m)
         P1 = orc.patches_from_seeds(seeds, np.arange(m1))
@@ -334,12 +341,12 @@ def main():
             cs = float(np.clip(np.dot(np.array(p.normal[:3]), nor_g[k, :3]), -1, 1))
             basin.append(dd < 0.25 and np.degrees(np.arccos(cs)) < 2.0)
         out["cpu_baseline"] = {
-            "value": m / tc, "unit": "patches/s", "cores": cores,
+            "value": mt / tc, "unit": "patches/s", "cores": cores,
             "kind": "port",
-            "sample": f"first {m} seeds of the same workload, OpenMP schedule(dynamic,64) over patches like "
+            "sample": f"first {mt} seeds of the same workload, OpenMP schedule(dynamic,64) over patches like "
                       f"Scene::initPatches; photometric path = oracle/ C restatement, optimiser = "
                       f"{'genuine NLopt 2.4.2 BOBYQA (oracle/_ref)' if which == orc.OPT_REF else 'oracle BOBYQA port'}",
-            "seconds": tc, "successes": int(okc.sum()),
+            "seconds": tc, "successes": okt,
             "optimizer_is_reference_nlopt": bool(which == orc.OPT_REF),
             "cpu_model": cpu_model, "sockets": sockets, "hardware_threads": cores,
             "one_core": {"value": m1 / t1, "unit": "patches/s", "cores": 1, "sample": f"first {m1} seeds", "seconds": t1},

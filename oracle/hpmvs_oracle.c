@@ -25,8 +25,22 @@
 /* tiny float vector helpers (Eigen fixed-size ops restated as scalar loops)  */
 
 static inline float dot3(const float *a, const float *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+/* Order of Eigen's 4-float reductions (Vector4f::dot / norm / normalized, the rows of P * X).  Which one an
+ * hpmvs binary has depends on the SIMD ISA Eigen was compiled for, and Eigen itself is absent from this image:
+ *   0  left to right            ((x0+x1)+x2)+x3   no vectorisation              <- what the HIP path restates
+ *   1  SSE2 packet reduction    (x0+x2)+(x1+x3)   predux: movehl + add, shuffle + add
+ *   2  SSE3 horizontal add      (x0+x1)+(x2+x3)   haddps twice
+ * tests/test_cpu_oracle.py::test_eigen_reduction_order_sensitivity runs the oracle under all three and reports
+ * how far the refined patches move (the "stated float tolerance" against a real build). */
+static int g_dot4_order = 0;
+void orc_set_dot4_order(int order) { g_dot4_order = order; }
+static inline float sum4(float p0, float p1, float p2, float p3) {
+    if (g_dot4_order == 1) return (p0 + p2) + (p1 + p3);
+    if (g_dot4_order == 2) return (p0 + p1) + (p2 + p3);
+    return ((p0 + p1) + p2) + p3;
+}
 static inline float dot4(const float *a, const float *b) {
-    return ((a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]) + a[3] * b[3];
+    return sum4(a[0] * b[0], a[1] * b[1], a[2] * b[2], a[3] * b[3]);
 }
 static inline void cross3(const float *a, const float *b, float *r) {
     const float r0 = a[1] * b[2] - a[2] * b[1];
@@ -190,7 +204,7 @@ static void cam_project(const orc_camera *cam, const float *X, int level, float 
     const float *P = cam->P[level];
     float r[3];
     for (int k = 0; k < 3; k++)
-        r[k] = ((P[k * 4 + 0] * X[0] + P[k * 4 + 1] * X[1]) + P[k * 4 + 2] * X[2]) + P[k * 4 + 3] * X[3];
+        r[k] = sum4(P[k * 4 + 0] * X[0], P[k * 4 + 1] * X[1], P[k * 4 + 2] * X[2], P[k * 4 + 3] * X[3]);
     if (r[2] <= 0.0f) {
         out[0] = -65535.0f; out[1] = -65535.0f; out[2] = -1.0f;
     } else {

@@ -151,7 +151,11 @@ typedef double (*orc_obj_fn)(unsigned n, const double *x, double *grad, void *da
 int orc_bobyqa_minimize(int which, int n, orc_obj_fn f, void *data, double *x, const double *lb,
                         const double *ub, double xtol_rel, int maxeval, double *minf, int *nevals);
 
+/* test-only switch: evaluation order of Eigen's 4-float reductions (0 left-to-right = default, 1 SSE2, 2 SSE3) */
+void orc_set_dot4_order(int order);
+
 #ifdef __cplusplus
 }
 #endif
+
 #endif

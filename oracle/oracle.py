@@ -98,6 +98,11 @@ def default_options() -> Options:
     return o
 
 
+def set_dot4_order(order: int):
+    """Evaluation order of Eigen's 4-float reductions in the oracle (0 left-to-right, 1 SSE2, 2 SSE3 haddps)."""
+    lib().orc_set_dot4_order(int(order))
+
+
 def optimizer_available(which: int) -> bool:
     return lib().orc_optimizer_available(which) == 0
 

@@ -320,3 +320,39 @@ def test_cr_acos_matches_host_libm():
     bad = ~same
     assert np.all((out[bad] == np.nextafter(g[bad], 4.0)) | (out[bad] == np.nextafter(g[bad], -4.0)))
     assert out[0] == 0.0 and out[1] == np.pi and out[2] == np.pi / 2
+
+
+def test_eigen_reduction_order_sensitivity(tiny_scene, tiny_seeds):
+    """What "parity" can mean against a real hpmvs binary.  The reference forms its 4-float reductions with Eigen,
+    whose evaluation order depends on the SIMD ISA it was compiled for (left-to-right, SSE2 packets, SSE3 haddps);
+    the oracle and the HIP path restate left-to-right.  Re-running the oracle with the other two orders shows
+    the size of the effect (BOBYQA amplifies last-bit differences of the objective, tests/sensitivity_probe.py):
+    decisions agree, NCC scores agree to ~1e-3, but patches are NOT bit-identical and ~10 % leave the basin
+    (profiles/r02/eigen_order_sensitivity.json has the 4000-seed figures).  Hence the stated tolerance:
+    bit-identical to the ORACLE; distributional (decisions, mean |d ncc| <= 5e-3) to an arbitrary x86 build."""
+    from oracle import oracle as orc
+    if not _has_ref():
+        pytest.skip("needs oracle/_ref (genuine NLopt)")
+    osc = orc.OracleScene(tiny_scene)
+
+    def run(order):
+        orc.set_dot4_order(order)
+        try:
+            P = orc.patches_from_seeds(tiny_seeds)
+            orc.optimize_batch(osc, P, which=orc.OPT_REF, n_threads=2)
+        finally:
+            orc.set_dot4_order(0)
+        return P
+
+    base = run(0)
+    again = run(0)
+    assert all(list(a.center) == list(b.center) and a.stage == b.stage for a, b in zip(base, again))
+    unrob = lambda f: f / (1.0 - 3.0 * f)
+    for order in (1, 2):
+        P = run(order)
+        ok0 = np.array([p.stage == 0 for p in base]); ok1 = np.array([p.stage == 0 for p in P])
+        both = np.nonzero(ok0 & ok1)[0]
+        dncc = np.array([abs(unrob(base[k].fmin) - unrob(P[k].fmin)) for k in both])
+        print(dict(order=order, decisions=float((ok0 == ok1).mean()), mean_dncc=float(dncc.mean()), n=len(both)))
+        assert (ok0 == ok1).mean() >= 0.97
+        assert dncc.mean() <= 5e-3  # SURVEY 8d's proposed tolerance holds across Eigen builds
