@@ -36,7 +36,7 @@
 #define BQ_HD __host__ __device__ inline
 // the big routines are real calls on the GPU: their register demand stays out of the caller's
 // wave-cooperative sampling loop (occupancy), and the code is shared by the call sites
-#define BQ_HD_NOINLINE __host__ __device__ __attribute__((noinline))
+#define BQ_HD_NOINLINE static __host__ __device__ __attribute__((noinline))  // static: two kernels (TUs) include this header
 #else
 #define BQ_HD inline
 #define BQ_HD_NOINLINE inline
@@ -153,8 +153,13 @@ enum {  // int32 slots
 #ifndef BQ_SLOTS
 #define BQ_SLOTS BQ_P
 #endif
+#if defined(BQ_STATE_LDS_EXTERN)
+// the including kernel owns the LDS buffer (shared with its other phases) and defines bq_lds_d / bq_lds_i
+// as pointer expressions into it before including this header
+#else
 __shared__ double bq_lds_d[BQ_ND * BQ_SLOTS];
 __shared__ int bq_lds_i[BQ_NI * BQ_SLOTS];
+#endif
 struct Bobyqa3 { int slot; };
 #define BQ_D(i) bq_lds_d[(i) * BQ_SLOTS + B.slot]
 #define BQ_I(i) bq_lds_i[(i) * BQ_SLOTS + B.slot]
@@ -1353,6 +1358,38 @@ BQ_HD int run(BqRef B, int label) {
 }
 
 
+// The same scheduler restricted to a SET of labels (bit (1 << label) of `allowed`): runs until no lane waits on
+// an allowed label.  The stream kernel (kernel_stream.hip) executes the expensive blocks (L60 trsbox, L90 shift,
+// L210 altmov, L230, L190 rescue) only for wavefronts whose lanes ALL wait on that block (patches queue up per
+// block in global memory); the cheap transition labels run inline wherever a patch happens to be.
+BQ_HD int run_set(BqRef B, int label, unsigned allowed) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (;;) {
+        const bool live = (label != LRET_CONT && label != LRET_DONE) && ((allowed >> label) & 1u);
+        if (!__any(live)) break;
+        int pick = LRET_DONE;
+        if (__any(live && label == L20)) pick = L20;
+        else if (__any(live && label == L650)) pick = L650;
+        else if (__any(live && label == L680)) pick = L680;
+        else if (__any(live && label == L720)) pick = L720;
+        else if (__any(live && label == L190)) pick = L190;
+        else if (__any(live && label == L60)) pick = L60;
+        else if (__any(live && label == L90)) pick = L90;
+        else if (__any(live && label == L210)) pick = L210;
+        else if (__any(live && label == L230)) pick = L230;
+        else if (__any(live && label == L360)) pick = L360;
+        if (live && label == pick) label = step_label(B, label);
+    }
+#else
+    while (label != LRET_CONT && label != LRET_DONE && ((allowed >> label) & 1u)) label = step_label(B, label);
+#endif
+    return label;
+}
+
+// L90 (bobyqa.c:2246-2322) does nothing unless the step is small relative to |xopt|: the cheap outcome
+BQ_HD bool l90_is_noop(BqRef B) { return !(BQS(dsq) <= BQS(xoptsq) * .001); }
+BQ_HD int l90_next(BqRef B) { return (BQN(ntrits) == 0) ? L210 : L230; }
+
 // Code after an evaluation at xbase + xnew in the main loop (bobyqa.c:2583-2970)
 // returns the label to continue at (or LRET_DONE)
 BQ_HD_NOINLINE int after_eval(BqRef B, double f) {
@@ -1577,7 +1614,10 @@ BQ_HD int bq_step(BqRef B, double f) {
     BQ_PROF_END(t_, 3);
     return r;
 }
-BQ_HD_NOINLINE int bq_step_(BqRef B, double f) {
+// everything bq_step does before the label loop: consumes f, returns the label to continue at
+BQ_HD_NOINLINE int bq_step_entry(BqRef B, double f);
+BQ_HD_NOINLINE int bq_step_(BqRef B, double f) { return bq::run(B, bq_step_entry(B, f)); }
+BQ_HD_NOINLINE int bq_step_entry(BqRef B, double f) {
     int label = bq::LRET_DONE;
     if (BQN(phase) == bq::PH_PRELIM) {
         bq::prelim_consume(B, f);
@@ -1613,7 +1653,7 @@ BQ_HD_NOINLINE int bq_step_(BqRef B, double f) {
     } else if (BQN(phase) == bq::PH_RESCUE) {
         label = bq::rescue_consume(B, f);
     }
-    return bq::run(B, label);
+    return label;
 }
 
 }  // namespace hpmvs

@@ -27,4 +27,18 @@ size_t optimize_workspace_bytes(int n_cus);
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace,
                      int n_cus, hipStream_t st);
 
+// Throughput form (kernel_stream.hip): patches stream through per-block queues; `n_recs` in-flight patch records
+// per shard (stream_records_for(n)).
+// The first stream_workspace_zero_bytes(n_recs) bytes of the workspace must be zero when the kernel starts; after
+// the launch the int at byte offset stream_abort_offset() is non-zero iff the kernel gave up (internal error).
+int stream_records_for(int n);
+size_t stream_workspace_bytes(int n_cus, int n_recs);
+size_t stream_workspace_zero_bytes(int n_recs);
+size_t stream_abort_offset();
+size_t stream_stats_offset();  // SK_STATS builds: 64 u64 counters
+size_t stream_shard_stride();  // the control blocks of the shards are this many bytes apart
+int stream_shards();
+void launch_stream(const DevScene& sc, const DevOptions& o, const DevBatch& b, void* workspace, int n_cus, int n_recs,
+                   hipStream_t st);
+
 }  // namespace hpmvs

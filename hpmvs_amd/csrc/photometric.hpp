@@ -498,11 +498,25 @@ __device__ __noinline__ void incc_finalize(float mine, int np, float thr, unsign
     keep = __ballot(mine < 1.0f - thr);
 }
 
-// lists: rows of ROW uint16 image ids, row p belongs to lane p.  Must be called by all 64 lanes.
-template <int ROW>
-__device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOptions& o, const uint16_t* lists,
+// image id `i` of the list at `row`.  COHERENT: the list was written by ANOTHER wavefront during this launch
+// (stream kernel: write-through sc1 stores), so the read bypasses this CU's L1 (sc1 load, 4-byte granule).
+template <bool COHERENT>
+__device__ __forceinline__ int list_id(const uint16_t* row, int i) {
+    if (COHERENT) {
+        const unsigned int w = __hip_atomic_load((const unsigned int*)(row + (i & ~1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (i & 1) ? (int)(w >> 16) : (int)(w & 0xffffu);
+    }
+    return (int)row[i];
+}
+
+// myrow: the calling lane's own image list (uint16 ids, 4-byte aligned; read only for lanes with a pending
+// request).  Must be called by all 64 lanes.
+template <bool COHERENT>
+__device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOptions& o, const uint16_t* myrow,
                                                  unsigned long long pending, const PackedReq& q, PackedRes& out,
                                                  EvalLds& L) {
+    const unsigned long long rowbits_ = (unsigned long long)myrow;
+    const int row_lo_ = (int)(rowbits_ & 0xffffffffull), row_hi_ = (int)(rowbits_ >> 32);
     constexpr int S = kChunk + 1;  // staging slots
     const int lane = lane_id();
     const bool active = lane < kTexPix;
@@ -545,7 +559,9 @@ __device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOp
         const float scale = shfl_f(q.scale, src);
         Prep P;
         P.ok = 0; P.tlx = P.tly = P.dxx = P.dxy = P.dyx = P.dyy = 0.0f; P.pix = nullptr; P.W = 0;
-        if (myp >= 0) P = prep_image(sc.views[(int)lists[myp * ROW + myi]], o, c, scale, pxa, pya, zax);
+        const unsigned long long rb_ = ((unsigned long long)(unsigned int)shfl_i(row_hi_, src) << 32) |
+                                       (unsigned long long)(unsigned int)shfl_i(row_lo_, src);
+        if (myp >= 0) P = prep_image(sc.views[list_id<COHERENT>((const uint16_t*)rb_, myi)], o, c, scale, pxa, pya, zax);
         const unsigned long long okmask = __ballot(P.ok != 0);
         PH_T(t2);
         PH_ADD(t1, t2, 13);
@@ -723,6 +739,185 @@ __device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOp
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// LANE-PER-GRAB exact-order evaluator: every (request, image) pair is one lane.
+//
+// The packed evaluator above spreads ONE grab over 49 lanes and has to hand the reference's sequential float32
+// sums to single lanes through LDS (5 barriers and ~2.1 k wave-cycles per grab).  Here a lane does a whole
+// sampleTexture by itself, exactly like the CPU thread of the reference does: the 49 bilinear taps in the
+// reference's incremental stepping order (PatchOptimizer.cpp:511-526), the 147 raw values in registers,
+// Patch2d::normalize's three sequential passes (Patch2d.hpp:46-84) and the 147-term dot product
+// (Patch2d.hpp:37-44) with the request's reference texture, whose normalised values are read from the lane that
+// grabbed the reference image with ds_bpermute (no LDS allocation, no barriers).  Up to 64 grabs advance per
+// pass, the sums need no staging, and every float operation is the reference's in the reference's order.
+// Requests are packed into passes like in wave_eval_packed (whole requests, <= 64 jobs per pass).
+__device__ __forceinline__ void grab_window(const Prep& P, float (&t)[3 * kTexPix]) {
+    float lx = P.tlx, ly = P.tly;  // row start: l += dy per row, c += dx per column
+#pragma unroll
+    for (int yy = 0; yy < kTex; yy++) {
+        float cx = lx, cy = ly;
+#pragma unroll
+        for (int xx = 0; xx < kTex; xx++) {
+            const int ix = (int)cx, iy = (int)cy;
+            const uint8_t* p0 = P.pix + 3 * (iy * P.W + ix);
+            Taps tp;
+            tp.a = load8(p0);
+            tp.b = load8(p0 + 3 * P.W);
+            const float dx1 = cx - (float)ix, dx0 = 1.0f - dx1;
+            const float dy1 = cy - (float)iy, dy0 = 1.0f - dy1;
+            tp.f00 = dx0 * dy0; tp.f01 = dx0 * dy1; tp.f10 = dx1 * dy0; tp.f11 = dx1 * dy1;
+            const int k = 3 * (yy * kTex + xx);
+            texel(tp, t[k], t[k + 1], t[k + 2]);
+            cx += P.dxx; cy += P.dxy;
+        }
+        lx += P.dyx; ly += P.dyy;
+        // one row of taps (14 loads) in flight at a time: without this fence the scheduler hoists all 98 loads
+        // of the window and spills the texture to scratch
+        asm volatile("" ::: "memory");
+    }
+}
+
+// Patch2d::normalize (Patch2d.hpp:46-84) on a register-resident texture
+__device__ __forceinline__ void normalize_window(float (&t)[3 * kTexPix]) {
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kTexPix; i++) { s0 += t[3 * i]; s1 += t[3 * i + 1]; s2 += t[3 * i + 2]; }
+    const float a0 = div_by(s0, 1.0 / 49.0), a1 = div_by(s1, 1.0 / 49.0), a2 = div_by(s2, 1.0 / 49.0);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kTexPix; i++) {
+        const float f0 = a0 - t[3 * i], f1 = a1 - t[3 * i + 1], f2 = a2 - t[3 * i + 2];
+        q += f0 * f0 + f1 * f1 + f2 * f2;
+    }
+    float v2 = sqrtf(div_by(q, 1.0 / 147.0));
+    if (v2 == 0.0f) v2 = 1.0f;
+    const double iv = recip64(v2);
+#pragma unroll
+    for (int i = 0; i < kTexPix; i++) {
+        t[3 * i] = div_by(t[3 * i] - a0, iv);
+        t[3 * i + 1] = div_by(t[3 * i + 1] - a1, iv);
+        t[3 * i + 2] = div_by(t[3 * i + 2] - a2, iv);
+    }
+}
+
+// myrow: the calling lane's own image list (uint16 ids; only read for lanes with a pending request).
+// Must be called by all 64 lanes (wave-uniform control flow around every cross-lane operation).
+#ifndef HPMVS_EVAL_JOBS_INLINE
+#define HPMVS_EVAL_JOBS_ATTR __noinline__
+#else
+#define HPMVS_EVAL_JOBS_ATTR __forceinline__
+#endif
+// (out of line by default: its ~200 VGPRs -- the 147 texture values -- then do not compete with the caller's
+//  long-lived per-patch registers inside the tap loop; the arguments travel by value, in registers)
+template <bool COHERENT>
+__device__ HPMVS_EVAL_JOBS_ATTR PackedRes wave_eval_jobs(DevScene sc, DevOptions o, const uint16_t* myrow,
+                                                       unsigned long long pending, PackedReq q, PackedRes out) {
+    const int lane = lane_id();
+    const int q_refsel = q.obj_mode ? 0 : q.ref;
+    const unsigned long long rowbits = (unsigned long long)myrow;
+    const int row_lo = (int)(rowbits & 0xffffffffull), row_hi = (int)(rowbits >> 32);
+
+    unsigned long long rem = pending;
+    while (rem) {
+        // ---- a pass: whole requests whose jobs fit the 64 lanes (at least one request)
+        unsigned long long batch = 0ull;
+        int J = 0;
+        for (unsigned long long t = rem; t; t &= t - 1ull) {
+            const int p = __ffsll((long long)t) - 1;
+            const int np = bcast_i(q.nimg, p);
+            if (batch && J + np > 64) break;
+            batch |= 1ull << p;
+            J += np;
+        }
+        rem &= ~batch;
+        PH_T(t1);
+        // ---- job of this lane (request myp, image index myi); each requesting lane learns where its jobs sit
+        int myp = -1, myi = 0, refl = 0, myoff = 0, maxnp = 0;
+        {
+            int off = 0;
+            for (unsigned long long t = batch; t; t &= t - 1ull) {
+                const int p = __ffsll((long long)t) - 1;
+                const int np = bcast_i(q.nimg, p);
+                const int refp = bcast_i(q_refsel, p);
+                if (lane >= off && lane < off + np) { myp = p; myi = lane - off; refl = off + refp; }
+                if (lane == p) myoff = off;
+                maxnp = np > maxnp ? np : maxnp;
+                off += np;
+            }
+        }
+        const int src = myp >= 0 ? myp : 0;
+        float c[3], zax[3], pxa[3], pya[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            c[k] = shfl_f(q.c[k], src); zax[k] = shfl_f(q.zax[k], src);
+            pxa[k] = shfl_f(q.px[k], src); pya[k] = shfl_f(q.py[k], src);
+        }
+        const float scale = shfl_f(q.scale, src);
+        const unsigned long long rb = ((unsigned long long)(unsigned int)shfl_i(row_hi, src) << 32) |
+                                      (unsigned long long)(unsigned int)shfl_i(row_lo, src);
+        Prep P;
+        P.ok = 0; P.tlx = P.tly = P.dxx = P.dxy = P.dyx = P.dyy = 0.0f; P.pix = nullptr; P.W = 0;
+        if (myp >= 0) P = prep_image(sc.views[list_id<COHERENT>((const uint16_t*)rb, myi)], o, c, scale, pxa, pya, zax);
+        const unsigned long long okmask = __ballot(P.ok != 0);
+        PH_T(t2);
+        PH_ADD(t1, t2, 13);
+
+        // ---- the grab: sampleTexture + normalize, one lane per (request, image) whose reference image is usable
+        const bool refok = (okmask >> refl) & 1ull;
+        const bool work = myp >= 0 && P.ok && refok;
+        float t[3 * kTexPix];
+#pragma unroll
+        for (int k = 0; k < 3 * kTexPix; k++) t[k] = 0.0f;
+        if (work) {
+            grab_window(P, t);
+            normalize_window(t);
+        }
+        PH_T(t3);
+        PH_ADD(t2, t3, 14);
+        // ---- Patch2d::dot with the reference texture (held by lane refl)
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3 * kTexPix; k++) acc += shfl_f(t[k], refl) * t[k];
+        const float raw = 1.0f - div_by(acc, 1.0 / 147.0);
+        const float rob = robustincc(raw);
+        PH_T(t4);
+        PH_ADD(t3, t4, 21);
+
+        // ---- delivery: every requesting lane walks its own jobs in image order
+        const bool mine = (batch >> lane) & 1ull;
+        const int np = mine ? q.nimg : 0;
+        const bool myrefok = mine && np > 0 && ((okmask >> (myoff + q_refsel)) & 1ull);
+        double val = 0.0;
+        float isum = 0.0f;
+        unsigned long long keep = 0ull;
+        int nok = 0, ngr = myrefok ? 1 : 0;
+        for (int i = 0; i < maxnp; i++) {
+            const int jl = (myoff + i) & 63;
+            const float e_raw = shfl_f(raw, jl), e_rob = shfl_f(rob, jl);
+            if (i < np) {
+                const bool jok = myrefok && ((okmask >> jl) & 1ull);
+                if (q.obj_mode) {
+                    if (jok && i != q_refsel) { val += (double)e_rob; nok++; ngr++; }
+                } else {
+                    float e = 2.0f;
+                    if (myrefok && i == q_refsel) e = 0.0f;
+                    else if (jok) { e = q.robust ? e_rob : e_raw; ngr++; }
+                    isum += e;
+                    if (e < 1.0f - q.thr) keep |= 1ull << i;
+                }
+            }
+        }
+        if (mine) {
+            out.ngrabs += ngr;
+            if (q.obj_mode) out.obj = (!myrefok || nok < o.MIN_IMAGES_PER_PATCH - 1) ? 2.0 : val / (double)nok;
+            else { out.keep = myrefok ? keep : 0ull; out.incc_sum = isum; }
+        }
+        PH_T(t5);
+        PH_ADD(t4, t5, 22);
+    }
+    return out;
 }
 
 // ------------------------------------------------------------------------------------------
