@@ -29,6 +29,32 @@
 //                        1.1 M benchmark patches, pinned on synthetic ill-conditioned objectives)
 //
 // Indexing: the accessor macros are 1-based like the mathematics; storage is dense 0-based.
+//
+// ---------------------------------------------------------------------------------------------------------------
+// LICENCE NOTICE.  The numerical content of this file is M. J. D. Powell's BOBYQA algorithm as distributed with
+// NLopt 2.4.2 (bobyqa/bobyqa.c, "converted via v2c, cleaned up, and incorporated into NLopt by S. G. Johnson").
+// The routines below restate that code statement by statement (same quantities, same operation order -- that is
+// the point: bit-identical trajectories), re-structured as a resumable fixed-size state machine.  This file is
+// therefore a derived work of MIT-licensed software and carries its notice (NLopt 2.4.2 bobyqa/COPYRIGHT):
+//
+//   Copyright (c) 2009 M. J. D. Powell (mjdp@cam.ac.uk)
+//   Modifications Copyright (c) 2010 Massachusetts Institute of Technology
+//
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+//   documentation files (the "Software"), to deal in the Software without restriction, including without
+//   limitation the rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the
+//   Software, and to permit persons to whom the Software is furnished to do so, subject to the following
+//   conditions:
+//
+//   The above copyright notice and this permission notice shall be included in all copies or substantial portions
+//   of the Software.
+//
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED
+//   TO THE WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT. IN NO EVENT SHALL
+//   THE AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF
+//   CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER
+//   DEALINGS IN THE SOFTWARE.
+// ---------------------------------------------------------------------------------------------------------------
 #pragma once
 
 #if defined(__HIPCC__)

@@ -188,6 +188,7 @@ int hpmvs_scene_create(int n_views, int device, hpmvs_scene** out) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     hpmvs_scene* s = new hpmvs_scene();
+    struct Guard { hpmvs_scene* p; ~Guard() { if (p) { if (p->ev0) hipEventDestroy(p->ev0); if (p->ev1) hipEventDestroy(p->ev1); delete p; } } } guard{s};
     s->device = device;
     s->n_views = n_views;
     s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -197,6 +198,7 @@ int hpmvs_scene_create(int n_views, int device, hpmvs_scene** out) {
     s->covis.resize(n_views);
     HIPCHK(hipEventCreate(&s->ev0));
     HIPCHK(hipEventCreate(&s->ev1));
+    guard.p = nullptr;
     *out = s;
     return HPMVS_OK;
 }
@@ -209,6 +211,16 @@ int hpmvs_scene_set_view(hpmvs_scene* s, int view, int width, int height, const 
     if (cam->n_levels < 1 || cam->n_levels > HPMVS_MAX_LEVELS) return fail(HPMVS_ERR_ARG, "scene_set_view: bad n_levels");
     HIPCHK(hipSetDevice(s->device));
     DevView& V = s->hviews[view];
+    if (s->view_set[view]) {  // set again: release the previous pyramid of this view
+        for (int l = 0; l < V.n_levels; l++) {
+            void* old = (void*)V.pix[l];
+            for (size_t k = 0; k < s->allocs.size(); k++)
+                if (s->allocs[k] == old) { s->allocs.erase(s->allocs.begin() + k); break; }
+            if (old) { hipFree(old); s->bytes -= (size_t)V.w[l] * V.h[l] * 3 + 16; }
+            V.pix[l] = nullptr;
+        }
+        s->view_set[view] = 0;
+    }
     // Image::init/load: max(1, MAXLEVEL) + 1 pyramid levels (reference Image.cpp:33-57); the camera has
     // MAXLEVEL + 1 projection levels (Camera.cpp:36).  Both are MAXLEVEL + 1 for MAXLEVEL >= 1.
     const int levels = cam->n_levels < 2 ? 2 : cam->n_levels;
@@ -326,13 +338,13 @@ int hpmvs_build_pyramid(int device, const uint8_t* src, int w, int h, uint8_t* d
         return HPMVS_OK;
     }
     uint8_t *ds = nullptr, *dd = nullptr;
+    struct Free { uint8_t*& a; uint8_t*& b; ~Free() { if (a) hipFree(a); if (b) hipFree(b); } } free_on_exit{ds, dd};
     HIPCHK(hipMalloc((void**)&ds, nb));
     HIPCHK(hipMalloc((void**)&dd, nb2 + 16));
     HIPCHK(hipMemcpy(ds, src, nb, hipMemcpyHostToDevice));
     launch_half_resize(ds, w, h, dd, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(dst, dd, nb2, hipMemcpyDeviceToHost));
-    hipFree(ds); hipFree(dd);
     return HPMVS_OK;
 }
 
@@ -375,6 +387,10 @@ int check_batch_shape(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_
     if (!s->committed) return fail(HPMVS_ERR_STATE, "scene not committed");
     if (b->n < 0 || b->max_images < 1 || b->max_images > HPMVS_MAX_IMAGES) return fail(HPMVS_ERR_ARG, "bad n/max_images");
     if (o->MAXLEVEL < 1 || o->MAXLEVEL >= HPMVS_MAX_LEVELS) return fail(HPMVS_ERR_ARG, "MAXLEVEL out of range");
+    // a negative level would index the per-level tables with a negative subscript (addImages); an image-count floor
+    // below 1 would let an empty list reach setINCCs (the reference's addImages fails on an empty list regardless)
+    if (o->MINLEVEL < 0 || o->MINLEVEL > o->MAXLEVEL) return fail(HPMVS_ERR_ARG, "MINLEVEL out of range");
+    if (o->MIN_IMAGES_PER_PATCH < 1) return fail(HPMVS_ERR_ARG, "MIN_IMAGES_PER_PATCH must be >= 1");
     return HPMVS_OK;
 }
 
@@ -485,12 +501,14 @@ static int enqueue_refinement(const hpmvs_scene* s, const DevOptions& d, const D
         int32_t* q;
         int slot;
         if ((rc = acquire_workspace(s, &q, &slot))) return rc;
+        // whatever happens below, the slot's event is recorded behind the work that was enqueued, so that the next
+        // user of this workspace waits for it
+        struct Release { const hpmvs_scene* s; int slot; hipStream_t st; ~Release() { hipEventRecord(s->slot_done[slot], st); s->slot_used[slot] = true; } } rel{s, slot, st};
         HIPCHK(hipMemsetAsync(q, 0, kQueueSlotBytes, st));
         HIPCHK(hipEventRecord(s->ev0, st));
         launch_optimize(dev_scene(s), d, batch, q, s->n_cus, st);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(s->ev1, st));
-        if ((rc = release_workspace(s, slot, st))) return rc;
         s->last_kernel = 0;
     }
     s->timed = true;
@@ -563,9 +581,13 @@ int hpmvs_init_patches_batch(const hpmvs_scene* s, const hpmvs_options* o, int s
     int rc = check_batch_shape(s, o, b);
     if (rc) return rc;
     if (b->n != n_points) return fail(HPMVS_ERR_ARG, "init_patches_batch: b->n must equal n_points");
-    if (n_points > 0 && (!xyz || !meas_off || !meas_img || !b->center || !b->normal || !b->scale || !b->n_images ||
+    if (n_points > 0 && (!xyz || !meas_off || !b->center || !b->normal || !b->scale || !b->n_images ||
                          !b->images || !b->ok))
         return fail(HPMVS_ERR_ARG, "init_patches_batch: missing array");
+    // meas_img may be NULL when no point has a measurement (every seed then fails with stage 10, like the
+    // reference's empty image list); with host arrays that is checkable here
+    if (n_points > 0 && !meas_img && (on_device || meas_off[n_points] != 0))
+        return fail(HPMVS_ERR_ARG, "init_patches_batch: meas_img missing");
     if (start_level < 0 || start_level > o->MAXLEVEL) return fail(HPMVS_ERR_ARG, "init_patches_batch: bad start_level");
     if (n_points == 0) return HPMVS_OK;
     HIPCHK(hipSetDevice(s->device));

@@ -63,7 +63,16 @@ __global__ void __launch_bounds__(256) objective_kernel(DevScene sc, DevOptions 
         const int32_t* list = b.images + (size_t)p * b.max_images;
         double f = 2.0;
         int ngr = 0;
-        if (nimg > 0 && nimg <= kMaxImages) {
+        // image ids come straight from the caller: a list that is longer than its row, or an id outside the scene,
+        // is answered with the plateau value 2.0 (what objective_fn returns when the reference grab fails), never
+        // dereferenced
+        bool ids_ok = nimg > 0 && nimg <= kMaxImages && nimg <= b.max_images;
+        if (ids_ok) {
+            const int l = lane_id();
+            const int id = (l < nimg) ? list[l] : 0;
+            ids_ok = !__any(id < 0 || id >= sc.n_views);
+        }
+        if (ids_ok) {
             const float c0[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
             OptFields F;
             set_optimization_fields(sc.views[list[0]], c0, F);
@@ -105,7 +114,12 @@ __global__ void __launch_bounds__(256) inccs_kernel(DevScene sc, DevOptions o, D
         const int32_t* list = b.images + (size_t)p * b.max_images;
         const int lane = lane_id();
         float mine = 2.0f;
-        if (nimg > 0 && nimg <= kMaxImages && ref_idx < nimg) {
+        bool ids_ok = nimg > 0 && nimg <= kMaxImages && nimg <= b.max_images && ref_idx >= 0 && ref_idx < nimg;
+        if (ids_ok) {  // same validation as objective_kernel: bad lists give inccs = 2.0 for every image
+            const int id = (lane < nimg) ? list[lane] : 0;
+            ids_ok = !__any(id < 0 || id >= sc.n_views);
+        }
+        if (ids_ok) {
             const float c[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
             const float n[3] = {b.normal[4 * p], b.normal[4 * p + 1], b.normal[4 * p + 2]};
             float px[3], py[3], pz[3];

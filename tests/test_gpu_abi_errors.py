@@ -59,3 +59,50 @@ def test_expand_shape_errors(tiny_seeds, gpu_scene):
     cc = np.zeros((4, 3), np.float32); cw = np.ones(4, np.float32)
     assert L.hpmvs_expand_batch(gpu_scene.h, C.byref(o), 0, C.byref(pb), cc.ctypes.data, cw.ctypes.data, None, C.byref(ob), 0, None) == -2
     assert b"fan-out" in L.hpmvs_last_error()
+
+
+def test_bad_image_lists_reach_the_standalone_kernels_as_values_not_faults(tiny_seeds, gpu_scene):
+    """hpmvs_objective_batch / hpmvs_inccs_batch take image ids straight from the caller.  An id outside
+    the scene, a -1 padded entry inside the counted part, or a count beyond the row is answered with the plateau
+    value 2.0 (objective_fn / setINCCs when the reference grab fails) -- no out-of-bounds read, no GPU fault."""
+    from hpmvs_amd import api
+    idx = np.nonzero(tiny_seeds.n_images >= 3)[0][:6]
+    good = api.Batch.from_seeds(tiny_seeds, idx)
+    x = np.zeros((good.n, 3))
+    f_good, _ = api.objective_batch(gpu_scene, good, x)
+    bad = api.Batch.from_seeds(tiny_seeds, idx)
+    bad.images[0, 1] = 9999          # outside the scene
+    bad.images[1, 0] = -1            # padding marker in the reference slot
+    bad.n_images[2] = bad.max_images + 5   # longer than the row
+    bad.n_images[3] = 0
+    f_bad, g_bad = api.objective_batch(gpu_scene, bad, x)
+    assert np.all(f_bad[:4] == 2.0) and np.all(g_bad[:4] == 0)
+    assert np.array_equal(f_bad[4:], f_good[4:])      # the untouched patches are unaffected
+    inc = api.inccs_batch(gpu_scene, bad, 0, 0)
+    for k in range(3):
+        nim = min(int(bad.n_images[k]), bad.max_images)
+        assert np.all(inc[k, :nim] == 2.0)
+    # and the gpu is still alive
+    f_again, _ = api.objective_batch(gpu_scene, good, x)
+    assert np.array_equal(f_again, f_good)
+
+
+def test_option_ranges_are_validated(tiny_seeds, gpu_scene):
+    from hpmvs_amd import api
+    L = api.lib()
+    b = api.Batch.from_seeds(tiny_seeds, np.arange(4))
+    cb = b.c_struct()
+    for field, value in (("MINLEVEL", -1), ("MINLEVEL", 6), ("MIN_IMAGES_PER_PATCH", 0), ("MAXLEVEL", 0)):
+        o = api.default_options()
+        setattr(o, field, value)
+        assert L.hpmvs_optimize_batch(gpu_scene.h, C.byref(o), C.byref(cb), 0, None) == -2, field
+        assert field.encode() in L.hpmvs_last_error()
+
+
+def test_init_patches_without_any_measurement(tiny_scene, gpu_scene):
+    """meas_off all zero and meas_img NULL: every seed fails with stage 10 (empty image list, Scene.cpp:152) instead
+    of the call being rejected."""
+    from hpmvs_amd import api
+    xyz = np.zeros((5, 3))
+    batch = api.init_patches_batch(gpu_scene, xyz, np.zeros(6, np.int32), np.zeros(0, np.int32), start_level=2)
+    assert (batch.ok == 0).all() and (batch.stage == 10).all()
