@@ -514,6 +514,44 @@ static int enqueue_refinement(const hpmvs_scene* s, const DevOptions& d, const D
     s->timed = true;
     return HPMVS_OK;
 }
+extern "C" int hpmvs_selftest_bobyqa(int device, int n, const int32_t* kind, const double* params, const double* x0,
+                                     const double* lb, const double* ub, int maxeval, double* xfinal, double* minf,
+                                     int32_t* result, int32_t* nevals, int32_t* rescue_calls, double* trace, int trace_cap) {
+    if (n < 0 || (n > 0 && (!kind || !params || !x0 || !lb || !ub || !xfinal || !minf || !result || !nevals || !rescue_calls)))
+        return fail(HPMVS_ERR_ARG, "selftest_bobyqa: missing array");
+    if (trace && trace_cap < 1) return fail(HPMVS_ERR_ARG, "selftest_bobyqa: trace_cap");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(HPMVS_ERR_NODEVICE, "no HIP device visible");
+    if (n == 0) return HPMVS_OK;
+    HIPCHK(hipSetDevice(device));
+    Staged sg;  // frees its device buffers on every exit path
+    int* dkind = nullptr; double *dpar = nullptr, *dx0 = nullptr, *dlb = nullptr, *dub = nullptr, *dxf = nullptr, *dmin = nullptr, *dtr = nullptr;
+    int *drc = nullptr, *dne = nullptr, *dres = nullptr;
+    int rc;
+    const size_t N = (size_t)n;
+    if ((rc = stage_in(sg, dkind, (const int*)kind, N, true))) return rc;
+    if ((rc = stage_in(sg, dpar, params, 8 * N, true))) return rc;
+    if ((rc = stage_in(sg, dx0, x0, 3 * N, true))) return rc;
+    if ((rc = stage_in(sg, dlb, lb, 3 * N, true))) return rc;
+    if ((rc = stage_in(sg, dub, ub, 3 * N, true))) return rc;
+    if ((rc = stage_in(sg, dxf, (const double*)xfinal, 3 * N, false))) return rc;
+    if ((rc = stage_in(sg, dmin, (const double*)minf, N, false))) return rc;
+    if ((rc = stage_in(sg, drc, (const int*)result, N, false))) return rc;
+    if ((rc = stage_in(sg, dne, (const int*)nevals, N, false))) return rc;
+    if ((rc = stage_in(sg, dres, (const int*)rescue_calls, N, false))) return rc;
+    if (trace && (rc = stage_in(sg, dtr, (const double*)trace, 4 * N * (size_t)trace_cap, false))) return rc;
+    launch_selftest(n, dkind, dpar, dx0, dlb, dub, maxeval, dxf, dmin, drc, dne, dres, dtr, trace_cap, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    if ((rc = stage_out(xfinal, dxf, 3 * N))) return rc;
+    if ((rc = stage_out(minf, dmin, N))) return rc;
+    if ((rc = stage_out((int*)result, drc, N))) return rc;
+    if ((rc = stage_out((int*)nevals, dne, N))) return rc;
+    if ((rc = stage_out((int*)rescue_calls, dres, N))) return rc;
+    if (trace && (rc = stage_out(trace, dtr, 4 * N * (size_t)trace_cap))) return rc;
+    return HPMVS_OK;
+}
+
 extern "C" int hpmvs_debug_stream_stats(const hpmvs_scene* s, unsigned long long* out64) {  // SK_STATS builds only
     if (!s || !s->stream_ws || !out64) return HPMVS_ERR_ARG;
     for (int k = 0; k < 64; k++) out64[k] = 0;

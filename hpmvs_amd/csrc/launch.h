@@ -27,6 +27,10 @@ size_t optimize_workspace_bytes(int n_cus);
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace,
                      int n_cus, hipStream_t st);
 
+// diagnostics: the BOBYQA state machine on analytic objectives (kernel_selftest.hip); device pointers
+void launch_selftest(int n, const int* kind, const double* params, const double* x0, const double* lb, const double* ub,
+                     int maxeval, double* xfinal, double* minf, int* rc, int* nevals, int* rescues, double* trace,
+                     int trace_cap, hipStream_t st);
 // Throughput form (kernel_stream.hip): patches stream through per-block queues; `n_recs` in-flight patch records
 // per shard (stream_records_for(n)).
 // The first stream_workspace_zero_bytes(n_recs) bytes of the workspace must be zero when the kernel starts; after

@@ -191,6 +191,18 @@ int hpmvs_inccs_batch(const hpmvs_scene *s, const hpmvs_options *o, const hpmvs_
 /* last optimize launch: kernel time measured with HIP events on the launch stream (ms) */
 int hpmvs_last_kernel_ms(const hpmvs_scene *s, float *ms);
 
+/* ---- diagnostics --------------------------------------------------------------------------------------------------
+ * The optimiser that optimize_kernel runs per lane (NLopt 2.4.2 LN_BOBYQA as PatchOptimizer.cpp:348-365 configures
+ * it: 3 variables, xtol_rel 1e-7, default initial step), driven ON THE GPU by the analytic objectives of
+ * hpmvs_amd/csrc/selftest_obj.h instead of the photometric one, 32 different problems per wavefront.  Exists so
+ * that the device build of the blocks the photometric objective never reaches (rescue_, bobyqa.c:143-742; active
+ * bounds; ROUNDOFF_LIMITED) can be compared evaluation by evaluation with the genuine library.  Host arrays:
+ * kind[n], params[n][8], x0/lb/ub[n][3] in; xfinal[n][3], minf[n], result[n] (nlopt_result), nevals[n],
+ * rescue_calls[n] out; trace[n][trace_cap][4] = (x0, x1, x2, f) of every evaluation (may be NULL). */
+int hpmvs_selftest_bobyqa(int device, int n, const int32_t *kind, const double *params, const double *x0,
+                          const double *lb, const double *ub, int maxeval, double *xfinal, double *minf,
+                          int32_t *result, int32_t *nevals, int32_t *rescue_calls, double *trace, int trace_cap);
+
 #ifdef __cplusplus
 }
 #endif

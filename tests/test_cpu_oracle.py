@@ -356,3 +356,23 @@ def test_eigen_reduction_order_sensitivity(tiny_scene, tiny_seeds):
         print(dict(order=order, decisions=float((ok0 == ok1).mean()), mean_dncc=float(dncc.mean()), n=len(both)))
         assert (ok0 == ok1).mean() >= 0.97
         assert dncc.mean() <= 5e-3  # SURVEY 8d's proposed tolerance holds across Eigen builds
+
+
+@pytest.mark.skipif(not _has_ref(), reason="oracle/_ref (genuine NLopt BOBYQA) not built on this box")
+def test_selftest_problem_set_host_state_machine_vs_genuine_bobyqa():
+    """The 64 analytic problems of the GPU self-test (tests/selftest_problems.py; 11 enter rescue_, results
+    -4 / 1 / 4 / 5): host build of bobyqa3.hpp vs the genuine library, evaluation by evaluation, and the
+    committed goldens are what the genuine library gives."""
+    import hashlib, json
+    import selftest_problems as sp
+    probs = sp.problems()
+    ref = sp.reference_run(probs)
+    mine, resc = sp.host_state_machine_run(probs)
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g5_bobyqa_selftest.json")))
+    for k, (r, m, g) in enumerate(zip(ref, mine, gold)):
+        assert r[:4] == m[:4], k
+        assert np.array_equal(r[4].view(np.int64), m[4].view(np.int64)), k
+        assert (r[0], r[1], r[2], r[3]) == (g["result"], g["x"], g["minf"], g["nevals"]), k
+        assert hashlib.sha256(r[4].tobytes()).hexdigest() == g["trace_sha256"], k
+        assert resc[k] == g["rescue_calls"]
+    assert sum(1 for c in resc if c) >= 10
