@@ -3,6 +3,7 @@
 // without a HIP device every compute entry point fails with HPMVS_ERR_NODEVICE.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -68,6 +69,14 @@ struct hpmvs_scene {
     mutable bool stream_used = false;
     mutable int* stream_abort = nullptr;
     mutable int last_kernel = 0;  // 0 = wavefront-bound kernel, 1 = stream kernel
+    // Small host-pointer batches (the unchanged callers' optimize() = batch of 1, and what a combiner makes of
+    // concurrent callers) are staged through persistent blocks: pinned host + device memory and a stream per
+    // entry, one H2D and one D2H copy per call, no hipMalloc / hipFree
+    struct StageEntry { hipStream_t st = nullptr; char* dev = nullptr; char* host = nullptr; std::mutex mu; };
+    static constexpr int kStageEntries = 8;
+    static constexpr int kStageCapPatches = 4096;
+    mutable StageEntry stage[kStageEntries];
+    mutable std::atomic<unsigned> stage_next{0};
 };
 
 // Which refinement kernel serves a batch: the wavefront-bound kernel (kernel_optimize.hip) unless HPMVS_KERNEL=stream
@@ -298,6 +307,11 @@ int hpmvs_scene_destroy(hpmvs_scene* s) {
     if (s->dcovis_off) hipFree(s->dcovis_off);
     if (s->dcovis) hipFree(s->dcovis);
     if (s->dqueue) hipFree(s->dqueue);
+    for (auto& e : s->stage) {
+        if (e.st) hipStreamDestroy(e.st);
+        if (e.dev) hipFree(e.dev);
+        if (e.host) hipHostFree(e.host);
+    }
     if (s->stream_ws) hipFree(s->stream_ws);
     if (s->stream_done) hipEventDestroy(s->stream_done);
     if (s->stream_abort) hipHostFree(s->stream_abort);
@@ -569,6 +583,76 @@ static int check_stream_abort(const hpmvs_scene* s) {
     return HPMVS_OK;
 }
 
+
+// ---- pooled staging of a small host batch -------------------------------------------------------------------------
+namespace {
+struct PoolLayout {
+    size_t off_center, off_normal, off_scale, off_nimg, off_images, in_bytes;
+    size_t off_ok, off_color, off_ncc, off_fmin, off_x, off_result, off_nevals, off_stage, off_ngrabs, total;
+};
+PoolLayout pool_layout(size_t n, size_t m) {
+    PoolLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
+    L.off_center = take(16 * n); L.off_normal = take(16 * n); L.off_scale = take(4 * n); L.off_nimg = take(4 * n);
+    L.off_images = take(4 * n * m);
+    L.in_bytes = o;
+    L.off_ok = take(n); L.off_color = take(12 * n); L.off_ncc = take(4 * n); L.off_fmin = take(8 * n); L.off_x = take(24 * n);
+    L.off_result = take(4 * n); L.off_nevals = take(4 * n); L.off_stage = take(4 * n); L.off_ngrabs = take(4 * n);
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+static int optimize_small_host_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_patch_batch* b) {
+    const size_t n = (size_t)b->n, m = (size_t)b->max_images;
+    const PoolLayout L = pool_layout(n, m);
+    hpmvs_scene::StageEntry& e = s->stage[s->stage_next.fetch_add(1) % hpmvs_scene::kStageEntries];
+    std::lock_guard<std::mutex> use(e.mu);
+    if (!e.st) {
+        const PoolLayout cap = pool_layout((size_t)hpmvs_scene::kStageCapPatches, (size_t)HPMVS_MAX_IMAGES);
+        HIPCHK(hipStreamCreateWithFlags(&e.st, hipStreamNonBlocking));
+        HIPCHK(hipMalloc((void**)&e.dev, cap.total));
+        HIPCHK(hipHostMalloc((void**)&e.host, cap.total));
+    }
+    char* h = e.host;
+    memcpy(h + L.off_center, b->center, 16 * n); memcpy(h + L.off_normal, b->normal, 16 * n);
+    memcpy(h + L.off_scale, b->scale, 4 * n); memcpy(h + L.off_nimg, b->n_images, 4 * n);
+    memcpy(h + L.off_images, b->images, 4 * n * m);
+    HIPCHK(hipMemcpyAsync(e.dev, h, L.in_bytes, hipMemcpyHostToDevice, e.st));
+    HIPCHK(hipMemsetAsync(e.dev + L.in_bytes, 0, L.total - L.in_bytes, e.st));
+    DevBatch D;
+    memset(&D, 0, sizeof(D));
+    D.n = b->n; D.max_images = b->max_images;
+    char* d = e.dev;
+    D.center = (float*)(d + L.off_center); D.normal = (float*)(d + L.off_normal); D.scale = (float*)(d + L.off_scale);
+    D.n_images = (int32_t*)(d + L.off_nimg); D.images = (int32_t*)(d + L.off_images);
+    D.ok = (uint8_t*)(d + L.off_ok); D.color = (float*)(d + L.off_color); D.ncc = (float*)(d + L.off_ncc);
+    D.fmin = (double*)(d + L.off_fmin); D.x = (double*)(d + L.off_x); D.result = (int32_t*)(d + L.off_result);
+    D.nevals = (int32_t*)(d + L.off_nevals); D.stage = (int32_t*)(d + L.off_stage); D.ngrabs = (int32_t*)(d + L.off_ngrabs);
+    const DevOptions dopt = make_dev_options(o);
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if ((rc = enqueue_refinement(s, dopt, D, e.st))) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(h, e.dev, L.total, hipMemcpyDeviceToHost, e.st));  // inputs come back refined in place
+    HIPCHK(hipStreamSynchronize(e.st));
+    if ((rc = check_stream_abort(s))) return rc;
+    memcpy(b->center, h + L.off_center, 16 * n); memcpy(b->normal, h + L.off_normal, 16 * n);
+    memcpy(b->n_images, h + L.off_nimg, 4 * n); memcpy(b->images, h + L.off_images, 4 * n * m);
+    memcpy(b->ok, h + L.off_ok, n);
+    if (b->color) memcpy(b->color, h + L.off_color, 12 * n);
+    if (b->ncc) memcpy(b->ncc, h + L.off_ncc, 4 * n);
+    if (b->fmin) memcpy(b->fmin, h + L.off_fmin, 8 * n);
+    if (b->x) memcpy(b->x, h + L.off_x, 24 * n);
+    if (b->result) memcpy(b->result, h + L.off_result, 4 * n);
+    if (b->nevals) memcpy(b->nevals, h + L.off_nevals, 4 * n);
+    if (b->stage) memcpy(b->stage, h + L.off_stage, 4 * n);
+    if (b->ngrabs) memcpy(b->ngrabs, h + L.off_ngrabs, 4 * n);
+    return HPMVS_OK;
+}
+
 extern "C" {
 
 int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_patch_batch* b, int on_device,
@@ -578,6 +662,7 @@ int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_pat
     if (!b->ok) return fail(HPMVS_ERR_ARG, "optimize_batch: ok[] is required");
     if (b->n == 0) return HPMVS_OK;
     HIPCHK(hipSetDevice(s->device));
+    if (!on_device && !stream && b->n <= hpmvs_scene::kStageCapPatches) return optimize_small_host_batch(s, o, b);
     hipStream_t st = (hipStream_t)stream;
     Staged sg;
     rc = stage_batch(sg, b, on_device != 0, true);

@@ -11,6 +11,10 @@
 #include <iomanip>
 #include <iostream>
 #include <strings.h>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 
 #include <hpmvs/Camera.h>
 #include <hpmvs/HpmvsOptions.h>
@@ -255,7 +259,37 @@ bool writeExtPly(const char* name, const std::vector<Ppatch3d>& patches, bool bi
 Scene::Scene() : dev_(nullptr), device_(0), maxLevel_(5) {
     if (const char* e = getenv("HPMVS_DEVICE")) device_ = atoi(e);
 }
-Scene::~Scene() { if (dev_) hpmvs_scene_destroy(dev_); }
+// ---------------------------------------------------------------- combiner of single-patch calls
+// The reference's callers hand over ONE patch per optimize() call from many host threads.  A lone patch is a
+// serial chain of ~90 (up to 1000) evaluation rounds of ~22 us on the GPU, so its latency cannot be hidden by
+// the device; what can be done is to run the patches of all threads that are waiting AT THE SAME TIME in one
+// launch instead of one launch (and one staging round trip) each.  Flat combining: a caller appends its patch
+// to the pending list; the first caller that finds no collector becomes the collector, waits a moment for the
+// other threads that were seen calling recently, takes the whole list, runs it as one optimizeBatch() and
+// wakes the owners.  While it runs, the next arrivals elect the next collector, so several combined launches
+// are in flight at once (each on its own staging entry / stream of the C ABI).  Results are those of
+// optimizeBatch(): patches are independent, so combining changes no bit of any result.
+namespace {
+struct Combiner {
+    struct Entry { Patch3d* patch; const HpmvsOptions* opt; bool done = false; uint8_t ok = 0; double f = 0.0; int evals = 0; };
+    std::mutex mu;
+    std::condition_variable cv_collect, cv_done;
+    std::vector<Entry*> pending;
+    bool collecting = false;
+    double recent = 1.0;  // decayed size of recent batches: how many callers to wait for
+};
+}  // namespace
+
+void* Scene::combiner() const {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!combiner_) combiner_ = new Combiner();
+    return combiner_;
+}
+
+Scene::~Scene() {
+    if (dev_) hpmvs_scene_destroy(dev_);
+    delete (Combiner*)combiner_;
+}
 
 bool Scene::addCameras(const NVM_Model& model, const HpmvsOptions& options) {
     maxLevel_ = options.MAXLEVEL;
@@ -375,10 +409,49 @@ PatchOptimizer::PatchOptimizer(const mo3d::HpmvsOptions& options, const mo3d::Sc
     : options_p(&options), scene_p(scene) {}
 
 bool PatchOptimizer::optimize(mo3d::Patch3d& patch) {
-    mo3d::Patch3d* p = &patch;
-    uint8_t ok = 0;
-    optimizeBatch(&p, 1, &ok);
-    return ok != 0;
+    Combiner& C = *(Combiner*)scene_p->combiner();
+    Combiner::Entry me;
+    me.patch = &patch; me.opt = options_p;
+    std::unique_lock<std::mutex> lk(C.mu);
+    C.pending.push_back(&me);
+    if (C.collecting) {
+        C.cv_collect.notify_one();
+        C.cv_done.wait(lk, [&] { return me.done; });
+    } else {
+        C.collecting = true;
+        // wait (briefly) for the threads that have been calling alongside lately
+        const size_t want = (size_t)(C.recent + 0.5);
+        if (want > 1)
+            C.cv_collect.wait_for(lk, std::chrono::microseconds(150), [&] { return C.pending.size() >= want; });
+        std::vector<Combiner::Entry*> take;
+        take.swap(C.pending);
+        C.collecting = false;
+        C.recent = std::max((double)take.size(), 0.75 * C.recent);
+        lk.unlock();
+        // one launch per distinct options object (normally one)
+        std::vector<char> handled(take.size(), 0);
+        for (size_t a = 0; a < take.size(); a++) {
+            if (handled[a]) continue;
+            std::vector<Patch3d*> group;
+            std::vector<size_t> who;
+            for (size_t k = a; k < take.size(); k++)
+                if (!handled[k] && take[k]->opt == take[a]->opt) { group.push_back(take[k]->patch); who.push_back(k); handled[k] = 1; }
+            std::vector<uint8_t> okv(group.size(), 0);
+            PatchOptimizer runner(*take[a]->opt, scene_p);
+            runner.optimizeBatch(group.data(), group.size(), okv.data());
+            for (size_t k = 0; k < who.size(); k++) {
+                take[who[k]]->ok = okv[k];
+                take[who[k]]->f = runner.lastF_.size() > k ? runner.lastF_[k] : 0.0;
+                take[who[k]]->evals = runner.lastEvals_.size() > k ? runner.lastEvals_[k] : 0;
+            }
+        }
+        lk.lock();
+        for (Combiner::Entry* e : take) e->done = true;
+        C.cv_done.notify_all();
+    }
+    lastF_.assign(1, me.f);
+    lastEvals_.assign(1, me.evals);
+    return me.ok != 0;
 }
 
 size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, uint8_t* ok) {

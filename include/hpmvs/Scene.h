@@ -38,8 +38,13 @@ public:
     hpmvs_scene* deviceScene() const;
     int device() const { return device_; }
     void setDevice(int d) { device_ = d; }
+    // Combines concurrent single-patch PatchOptimizer::optimize() calls of several host threads (the reference's
+    // callers: one optimizer per OpenMP thread, Scene.cpp:94-96,166-167, CellProcessor.cpp:129,256) into batched
+    // device launches; opaque, owned by the scene
+    void* combiner() const;
 private:
     mutable hpmvs_scene* dev_;
+    mutable void* combiner_ = nullptr;
     mutable std::mutex mu_;
     int device_;
     int maxLevel_;

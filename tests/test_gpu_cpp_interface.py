@@ -81,3 +81,44 @@ def test_cpp_patchoptimizer_equals_c_abi(tiny_scene, tiny_seeds, gpu_scene, tmp_
         if want.ok[t]:
             assert int(r[11]) == want.n_images[t]
     assert want.ok.sum() > 0
+
+
+def _dump_scene(path, scene, seeds, n):
+    with open(path, "wb") as f:
+        f.write(struct.pack("i", scene.n_views))
+        for v in scene.views:
+            f.write(struct.pack("iid4d3d", v.width, v.height, v.f, *v.q, *v.c))
+            f.write(np.ascontiguousarray(v.rgb, dtype=np.uint8).tobytes())
+        for lst in scene.covis:
+            f.write(struct.pack("i", len(lst)) + struct.pack(f"{len(lst)}i", *lst))
+        f.write(struct.pack("i", n))
+        for k in range(n):
+            m = int(seeds.n_images[k])
+            f.write(seeds.center[k].astype(np.float32).tobytes() + seeds.normal[k].astype(np.float32).tobytes())
+            f.write(struct.pack("fi", float(seeds.scale[k]), m) + struct.pack(f"{m}i", *seeds.images[k, :m]))
+
+
+def test_unchanged_callers_64_threads_in_a_loop(tiny_scene, tmp_path):
+    """the reference's calling pattern -- 64 host threads, one PatchOptimizer each, optimize(patch) in a
+    loop over 1e4 patches -- must give the bytes of one optimizeBatch() call; the host-side combiner turns the
+    concurrent single-patch calls into batched launches.  Throughput of both forms and the lone-call latency are
+    recorded in gpurun_out/callers.json (a thread has one patch in flight and a lone patch needs milliseconds on
+    the device, so T threads cannot exceed T / latency patches per second whatever the host layer does)."""
+    import json
+    from hpmvs_amd import synth
+    exe = os.path.join(ROOT, "tests", "native", "bench_callers")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe), "all"], check=True, capture_output=True)
+    n = 10000
+    seeds = synth.make_seeds(tiny_scene, n, start_level=2, seed=synth.SEED + 3)
+    dump = tmp_path / "scene10k.bin"
+    _dump_scene(dump, tiny_scene, seeds, n)
+    rows = []
+    for threads in (64, 8, 1):
+        r = subprocess.run([exe, str(dump), str(threads)], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        rows.append(json.loads(r.stdout.strip().splitlines()[-1]))
+        assert rows[-1]["mismatches"] == 0 and rows[-1]["refined"] > n // 2
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(rows, open("gpurun_out/callers.json", "w"), indent=1)
+    print(rows)
