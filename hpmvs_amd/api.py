@@ -50,7 +50,8 @@ EXPORTS = [
     "hpmvs_scene_create", "hpmvs_scene_set_view", "hpmvs_scene_set_covis", "hpmvs_scene_commit",
     "hpmvs_scene_destroy", "hpmvs_scene_get_level", "hpmvs_scene_bytes", "hpmvs_build_pyramid",
     "hpmvs_optimize_batch", "hpmvs_init_patches_batch", "hpmvs_objective_batch", "hpmvs_inccs_batch", "hpmvs_last_kernel_ms",
-    "hpmvs_expand_batch", "hpmvs_expand_directions",
+    "hpmvs_expand_batch", "hpmvs_expand_directions", "hpmvs_selftest_bobyqa",
+    "hpmvs_pack_records", "hpmvs_unpack_records", "hpmvs_allgather_records",
 ]
 
 _lib = None

@@ -3,6 +3,8 @@
 // without a HIP device every compute entry point fails with HPMVS_ERR_NODEVICE.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -528,6 +530,58 @@ static int enqueue_refinement(const hpmvs_scene* s, const DevOptions& d, const D
     s->timed = true;
     return HPMVS_OK;
 }
+// ---- multi-GPU exchange ------------------------------------------------------------------------------------------
+static_assert(sizeof(hpmvs_record) == 192, "hpmvs_record is 192 bytes");
+static DevBatch as_dev_batch(const hpmvs_patch_batch* b) {
+    DevBatch d;
+    memset(&d, 0, sizeof(d));
+    d.n = b->n; d.max_images = b->max_images;
+    d.center = b->center; d.normal = b->normal; d.scale = b->scale; d.n_images = b->n_images; d.images = b->images;
+    d.ok = b->ok; d.color = b->color; d.ncc = b->ncc; d.fmin = b->fmin; d.x = b->x; d.result = b->result;
+    d.nevals = b->nevals; d.stage = b->stage; d.ngrabs = b->ngrabs;
+    return d;
+}
+extern "C" int hpmvs_pack_records(const hpmvs_patch_batch* b, hpmvs_record* records, void* stream) {
+    if (!b || b->n < 0 || b->max_images < 1 || b->max_images > HPMVS_MAX_IMAGES) return fail(HPMVS_ERR_ARG, "pack_records: bad batch");
+    if (b->n > 0 && (!records || !b->center || !b->normal || !b->scale || !b->n_images || !b->images))
+        return fail(HPMVS_ERR_ARG, "pack_records: missing array");
+    launch_pack_records(as_dev_batch(b), records, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return HPMVS_OK;
+}
+extern "C" int hpmvs_unpack_records(const hpmvs_record* records, int n, hpmvs_patch_batch* b, void* stream) {
+    if (!b || n < 0 || b->n < n || b->max_images < 1 || b->max_images > HPMVS_MAX_IMAGES) return fail(HPMVS_ERR_ARG, "unpack_records: bad batch");
+    if (n > 0 && (!records || !b->center || !b->normal || !b->scale || !b->n_images || !b->images))
+        return fail(HPMVS_ERR_ARG, "unpack_records: missing array");
+    launch_unpack_records(records, n, as_dev_batch(b), (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return HPMVS_OK;
+}
+// ncclAllGather(sendbuff, recvbuff, sendcount, datatype, comm, stream); ncclUint8 = 1, ncclSuccess = 0 (rccl.h)
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+static nccl_allgather_fn find_allgather() {
+    static nccl_allgather_fn fn = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");  // the RCCL already in the process (the communicator's own)
+        if (!sym) {
+            void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) sym = dlsym(h, "ncclAllGather");
+        }
+        fn = (nccl_allgather_fn)sym;
+    });
+    return fn;
+}
+extern "C" int hpmvs_allgather_records(void* nccl_comm, const hpmvs_record* send, size_t count, hpmvs_record* recv, void* stream) {
+    if (!nccl_comm || (count > 0 && (!send || !recv))) return fail(HPMVS_ERR_ARG, "allgather_records: null argument");
+    nccl_allgather_fn fn = find_allgather();
+    if (!fn) return fail(HPMVS_ERR_STATE, "allgather_records: RCCL (ncclAllGather) not found in the process nor as librccl.so.1");
+    const int r = fn(send, recv, count * sizeof(hpmvs_record), /*ncclUint8*/ 1, nccl_comm, (hipStream_t)stream);
+    if (r != 0) return fail(HPMVS_ERR_HIP, "ncclAllGather failed with ncclResult_t " + std::to_string(r));
+    return HPMVS_OK;
+}
+
 extern "C" int hpmvs_selftest_bobyqa(int device, int n, const int32_t* kind, const double* params, const double* x0,
                                      const double* lb, const double* ub, int maxeval, double* xfinal, double* minf,
                                      int32_t* result, int32_t* nevals, int32_t* rescue_calls, double* trace, int trace_cap) {

@@ -328,4 +328,54 @@ void launch_expand_gate(int mode, int n, const DevBatch& parents, const float* c
                        cell_width, out);
 }
 
+// ------------------------------------------------------------------------------------------
+// Refined-patch records of the per-round all-gather (hpmvs_record, 192 bytes): one thread per patch, the 128 id
+// bytes as eight 16-byte stores.
+struct alignas(16) DevRecord {
+    float center[4]; float normal[4]; float color[3]; float scale; double fmin;
+    uint8_t ok, pad0; uint16_t n_images; uint8_t pad1[4];
+    uint16_t images[kMaxImages];
+};
+static_assert(sizeof(DevRecord) == 192, "record layout");
+
+__global__ void __launch_bounds__(256) pack_records_kernel(DevBatch b, DevRecord* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n) return;
+    DevRecord r;
+    for (int k = 0; k < 4; k++) { r.center[k] = b.center[4 * i + k]; r.normal[k] = b.normal[4 * i + k]; }
+    for (int k = 0; k < 3; k++) r.color[k] = b.color ? b.color[3 * i + k] : 0.0f;
+    r.scale = b.scale[i];
+    r.fmin = b.fmin ? b.fmin[i] : 0.0;
+    r.ok = b.ok ? b.ok[i] : 0; r.pad0 = 0;
+    const int nim = b.n_images[i];
+    r.n_images = (uint16_t)nim;
+    for (int k = 0; k < 4; k++) r.pad1[k] = 0;
+    for (int k = 0; k < kMaxImages; k++)
+        r.images[k] = (k < nim && k < b.max_images) ? (uint16_t)b.images[(size_t)i * b.max_images + k] : (uint16_t)0xFFFF;
+    out[i] = r;
+}
+
+__global__ void __launch_bounds__(256) unpack_records_kernel(const DevRecord* __restrict__ in, int n, DevBatch b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevRecord r = in[i];
+    for (int k = 0; k < 4; k++) { b.center[4 * i + k] = r.center[k]; b.normal[4 * i + k] = r.normal[k]; }
+    if (b.color) for (int k = 0; k < 3; k++) b.color[3 * i + k] = r.color[k];
+    b.scale[i] = r.scale;
+    if (b.fmin) b.fmin[i] = r.fmin;
+    if (b.ok) b.ok[i] = r.ok;
+    b.n_images[i] = (int32_t)(int16_t)r.n_images;
+    for (int k = 0; k < b.max_images; k++)
+        b.images[(size_t)i * b.max_images + k] = (k < kMaxImages && r.images[k] != 0xFFFF) ? (int32_t)r.images[k] : -1;
+}
+
+void launch_pack_records(const DevBatch& b, void* records, hipStream_t st) {
+    if (b.n <= 0) return;
+    hipLaunchKernelGGL(pack_records_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b, (DevRecord*)records);
+}
+void launch_unpack_records(const void* records, int n, const DevBatch& b, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(unpack_records_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const DevRecord*)records, n, b);
+}
+
 }  // namespace hpmvs

@@ -27,6 +27,9 @@ size_t optimize_workspace_bytes(int n_cus);
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace,
                      int n_cus, hipStream_t st);
 
+// refined-patch records of the multi-GPU exchange (include/hpmvs_amd.h: hpmvs_record, 192 bytes)
+void launch_pack_records(const DevBatch& b, void* records, hipStream_t st);
+void launch_unpack_records(const void* records, int n, const DevBatch& b, hipStream_t st);
 // diagnostics: the BOBYQA state machine on analytic objectives (kernel_selftest.hip); device pointers
 void launch_selftest(int n, const int* kind, const double* params, const double* x0, const double* lb, const double* ub,
                      int maxeval, double* xfinal, double* minf, int* rc, int* nevals, int* rescues, double* trace,

@@ -276,7 +276,9 @@ struct Combiner {
     std::condition_variable cv_collect, cv_done;
     std::vector<Entry*> pending;
     bool collecting = false;
-    double recent = 1.0;  // decayed size of recent batches: how many callers to wait for
+    int inside = 0;      // threads currently inside optimize()
+    int running = 0;     // of those, patches that are part of a batch on the device
+    double peak = 1.0;   // decayed maximum of `inside`: how many threads call concurrently
 };
 }  // namespace
 
@@ -414,19 +416,22 @@ bool PatchOptimizer::optimize(mo3d::Patch3d& patch) {
     me.patch = &patch; me.opt = options_p;
     std::unique_lock<std::mutex> lk(C.mu);
     C.pending.push_back(&me);
+    C.inside++;
+    C.peak = std::max((double)C.inside, 0.98 * C.peak);
     if (C.collecting) {
         C.cv_collect.notify_one();
         C.cv_done.wait(lk, [&] { return me.done; });
     } else {
         C.collecting = true;
-        // wait (briefly) for the threads that have been calling alongside lately
-        const size_t want = (size_t)(C.recent + 0.5);
+        // Wait (briefly: a lone patch needs milliseconds on the device) for the threads that call concurrently and
+        // are not already part of a running batch: they were released together and arrive within microseconds.
+        const int want = (int)(C.peak + 0.5) - C.running;
         if (want > 1)
-            C.cv_collect.wait_for(lk, std::chrono::microseconds(150), [&] { return C.pending.size() >= want; });
+            C.cv_collect.wait_for(lk, std::chrono::microseconds(250), [&] { return (int)C.pending.size() >= want; });
         std::vector<Combiner::Entry*> take;
         take.swap(C.pending);
         C.collecting = false;
-        C.recent = std::max((double)take.size(), 0.75 * C.recent);
+        C.running += (int)take.size();
         lk.unlock();
         // one launch per distinct options object (normally one)
         std::vector<char> handled(take.size(), 0);
@@ -446,9 +451,11 @@ bool PatchOptimizer::optimize(mo3d::Patch3d& patch) {
             }
         }
         lk.lock();
+        C.running -= (int)take.size();
         for (Combiner::Entry* e : take) e->done = true;
         C.cv_done.notify_all();
     }
+    C.inside--;
     lastF_.assign(1, me.f);
     lastEvals_.assign(1, me.evals);
     return me.ok != 0;

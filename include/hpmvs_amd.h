@@ -191,6 +191,35 @@ int hpmvs_inccs_batch(const hpmvs_scene *s, const hpmvs_options *o, const hpmvs_
 /* last optimize launch: kernel time measured with HIP events on the launch stream (ms) */
 int hpmvs_last_kernel_ms(const hpmvs_scene *s, float *ms);
 
+/* ---- multi-GPU: the per-round exchange of refined patches ---------------------------------------------------------
+ * Patches are independent (PatchOptimizer.cpp:78-103 reads only its patch and the immutable scene; the reference
+ * runs them as an OpenMP loop, Scene.cpp:94-96,114), so every rank (one process per GPU, scene replicated)
+ * refines a contiguous slice of the round's batch and the only exchange is ONE all-gather of fixed-size records,
+ * after which every rank holds the whole refined set for its host scheduler (main.cpp:145-181: one barrier per
+ * priority level).  These entry points make that reachable from a C/C++ host without Python:
+ *   hpmvs_pack_records       SoA batch (device arrays) -> n records (device), one kernel on `stream`
+ *   hpmvs_allgather_records  ncclAllGather of `count` records per rank over the caller's RCCL communicator
+ *                            (xGMI inside a node); RCCL is looked up at run time in the process (the library the
+ *                            communicator came from), else librccl.so.1 is opened -- no link-time dependency
+ *   hpmvs_unpack_records     records (device) -> SoA batch (device arrays); ok / color / fmin included
+ * Ragged rounds (n not divisible by the ranks): pad every rank to the largest slice, records beyond a rank's
+ * count are zero (ok = 0). */
+typedef struct hpmvs_record {
+    float center[4];
+    float normal[4];
+    float color[3];
+    float scale;
+    double fmin;
+    uint8_t ok;
+    uint8_t pad0;
+    uint16_t n_images;
+    uint8_t pad1[4];
+    uint16_t images[HPMVS_MAX_IMAGES]; /* unused slots 0xFFFF */
+} hpmvs_record;                        /* 192 bytes */
+int hpmvs_pack_records(const hpmvs_patch_batch *b, hpmvs_record *records, void *stream);
+int hpmvs_unpack_records(const hpmvs_record *records, int n, hpmvs_patch_batch *b, void *stream);
+int hpmvs_allgather_records(void *nccl_comm, const hpmvs_record *send, size_t count, hpmvs_record *recv, void *stream);
+
 /* ---- diagnostics --------------------------------------------------------------------------------------------------
  * The optimiser that optimize_kernel runs per lane (NLopt 2.4.2 LN_BOBYQA as PatchOptimizer.cpp:348-365 configures
  * it: 3 variables, xtol_rel 1e-7, default initial step), driven ON THE GPU by the analytic objectives of

@@ -122,3 +122,39 @@ def test_unchanged_callers_64_threads_in_a_loop(tiny_scene, tmp_path):
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(rows, open("gpurun_out/callers.json", "w"), indent=1)
     print(rows)
+
+
+def test_cpp_host_round_with_rccl_allgather(tiny_scene, tiny_seeds, gpu_scene, tmp_path):
+    """north_star's round from a C++ host without Python: optimize (device arrays) -> hpmvs_pack_records ->
+    hpmvs_allgather_records over an RCCL communicator (1 rank here) -> hpmvs_unpack_records.  The gathered records
+    are byte-identical to hpmvs_amd.distributed.pack_records of the C-ABI results, and unpacking restores them."""
+    import torch
+    from hpmvs_amd import api
+    from hpmvs_amd import distributed as dd
+    exe = os.path.join(ROOT, "tests", "native", "test_rccl_round")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe), "all"], check=True, capture_output=True)
+    n = 150
+    dump, outp = tmp_path / "scene.bin", tmp_path / "round.bin"
+    _dump_scene(dump, tiny_scene, tiny_seeds, n)
+    r = subprocess.run([exe, str(dump), str(outp)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(outp, "rb").read()
+    assert struct.unpack("i", raw[:4])[0] == n
+    rec = np.frombuffer(raw, dtype=np.uint8, count=n * dd.RECORD_BYTES, offset=4).reshape(n, dd.RECORD_BYTES)
+    batch = api.Batch.from_seeds(tiny_seeds, np.arange(n))
+    api.optimize_batch(gpu_scene, batch)
+    t = torch.from_numpy
+    want = dd.pack_records(t(batch.center), t(batch.normal), t(batch.color), t(batch.scale), t(batch.fmin), t(batch.ok),
+                           t(batch.n_images), t(batch.images)).numpy()
+    assert np.array_equal(rec, want)
+    off = 4 + n * dd.RECORD_BYTES
+    un = np.frombuffer(raw, dtype=np.int32, count=n, offset=off); off += 4 * n
+    ui = np.frombuffer(raw, dtype=np.int32, count=n * 32, offset=off).reshape(n, 32); off += 4 * n * 32
+    uok = np.frombuffer(raw, dtype=np.uint8, count=n, offset=off); off += n
+    uc = np.frombuffer(raw, dtype=np.float32, count=4 * n, offset=off).reshape(n, 4)
+    assert np.array_equal(un, batch.n_images) and np.array_equal(uok, batch.ok) and np.array_equal(uc, batch.center)
+    live = np.arange(32)[None, :] < batch.n_images[:, None]
+    assert np.array_equal(ui[live], batch.images[live]) and np.all(ui[~live] == -1)
+    u = dd.unpack_records(torch.from_numpy(rec.copy()))
+    assert np.array_equal(u["n_images"], batch.n_images) and np.array_equal(u["ok"], batch.ok.astype(bool))
