@@ -277,9 +277,12 @@ struct Combiner {
     std::vector<Entry*> pending;
     bool collecting = false;
     int inside = 0;      // threads currently inside optimize()
-    int running = 0;     // of those, patches that are part of a batch on the device
+    int launches = 0;    // combined batches currently on the device
     double peak = 1.0;   // decayed maximum of `inside`: how many threads call concurrently
 };
+// at most this many combined launches in flight: the device runs only a few kernels of different streams at once,
+// so further callers are better off joining the next batch than queueing a launch of their own
+constexpr int kMaxCombinedLaunches = 2;
 }  // namespace
 
 void* Scene::combiner() const {
@@ -423,15 +426,22 @@ bool PatchOptimizer::optimize(mo3d::Patch3d& patch) {
         C.cv_done.wait(lk, [&] { return me.done; });
     } else {
         C.collecting = true;
-        // Wait (briefly: a lone patch needs milliseconds on the device) for the threads that call concurrently and
-        // are not already part of a running batch: they were released together and arrive within microseconds.
-        const int want = (int)(C.peak + 0.5) - C.running;
-        if (want > 1)
-            C.cv_collect.wait_for(lk, std::chrono::microseconds(250), [&] { return (int)C.pending.size() >= want; });
+        // Collect: a lone caller launches at once.  With several threads calling, give the others a short window
+        // to join (a lone patch needs milliseconds on the device, the window is a fraction of that), and while
+        // kMaxCombinedLaunches batches are already on the device keep collecting until one of them returns.
+        if ((int)(C.peak + 0.5) > 1) {
+            const auto t_open = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+            for (;;) {
+                const bool everyone = (int)C.pending.size() >= (int)(C.peak + 0.5);
+                const bool window_over = std::chrono::steady_clock::now() >= t_open;
+                if (C.launches < kMaxCombinedLaunches && (everyone || window_over)) break;
+                C.cv_collect.wait_for(lk, std::chrono::microseconds(100));
+            }
+        }
         std::vector<Combiner::Entry*> take;
         take.swap(C.pending);
         C.collecting = false;
-        C.running += (int)take.size();
+        C.launches++;
         lk.unlock();
         // one launch per distinct options object (normally one)
         std::vector<char> handled(take.size(), 0);
@@ -451,9 +461,10 @@ bool PatchOptimizer::optimize(mo3d::Patch3d& patch) {
             }
         }
         lk.lock();
-        C.running -= (int)take.size();
+        C.launches--;
         for (Combiner::Entry* e : take) e->done = true;
         C.cv_done.notify_all();
+        C.cv_collect.notify_one();  // a collector may be waiting for a launch slot
     }
     C.inside--;
     lastF_.assign(1, me.f);
