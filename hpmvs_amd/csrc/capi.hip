@@ -622,11 +622,11 @@ extern "C" int hpmvs_selftest_bobyqa(int device, int n, const int32_t* kind, con
 
 extern "C" int hpmvs_debug_stream_stats(const hpmvs_scene* s, unsigned long long* out64) {  // SK_STATS builds only
     if (!s || !s->stream_ws || !out64) return HPMVS_ERR_ARG;
-    for (int k = 0; k < 64; k++) out64[k] = 0;
+    for (int k = 0; k < 80; k++) out64[k] = 0;   // caller's buffer holds 80 counters
     for (int sh = 0; sh < stream_shards(); sh++) {
-        unsigned long long t[64];
-        HIPCHK(hipMemcpy(t, (char*)s->stream_ws + sh * stream_shard_stride() + stream_stats_offset(), 64 * 8, hipMemcpyDeviceToHost));
-        for (int k = 0; k < 64; k++) out64[k] += t[k];
+        unsigned long long t[80];
+        HIPCHK(hipMemcpy(t, (char*)s->stream_ws + sh * stream_shard_stride() + stream_stats_offset(), 80 * 8, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 80; k++) out64[k] += t[k];
     }
     return HPMVS_OK;
 }

@@ -79,12 +79,36 @@ __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0
 #endif
 
 // ---- record layout (u64 words) ----------------------------------------------------------------------------
-constexpr int kRecD = 0;                       // 177 doubles: optimiser state, indices of bobyqa3.hpp
-constexpr int kRecI = 177;                     // 13 (+1) int32
-constexpr int kRecPS = 184;                    // PipeState, 24 words
-constexpr int kRecRow = 208;                   // 64 uint16 image ids
-constexpr int kRecWords = 224;                 // 1792 B
+// 2048 bytes = 8 pages of 32 words (256 B).  The optimiser state is stored in the order the blocks need it, so
+// that a visit pages in a PREFIX of the record and pages out a few whole pages:
+//   page 0-1  words   0..45  small vectors xeval..gnew (state 0..44) + pad
+//             words  46..69  scalars minf..stepb (state 154..176) + pad
+//   page 2    words  70..77  the 13 int32 + pad
+//             words  78..105 xpt, fval (state 45..72)
+//   page 3    words 106..119 pq, hq (state 73..85) + pad          <- L60 (trsbox) reads pages 0..3
+//   page 3-4  words 120..149 bmat (state 86..115)
+//   page 4-5  words 150..171 zmat (state 116..136) + pad          <- L90 / L210 / L230 read pages 0..5
+//   page 5    words 172..181 vlag (state 137..146); 182..189 wsuma (state 147..153) + pad; 190, 191 pad
+//   page 6    words 192..215 PipeState; 216..231 image list (64 uint16); 232..255 unused
+constexpr int kRecPS = 192;
+constexpr int kRecRow = 216;
+constexpr int kRecWords = 256;
 constexpr int kRowWords = 16;
+constexpr int kPageWords = 32;
+// record word of a float64 state index (bobyqa3.hpp O_*) / of int32 state index k (two per word)
+__host__ __device__ constexpr int rec_word_of_d(int i) {
+    return i < 45 ? i : i < 73 ? 78 + (i - 45) : i < 86 ? 106 + (i - 73) : i < 116 ? 120 + (i - 86) : i < 137 ? 150 + (i - 116)
+         : i < 147 ? 172 + (i - 137) : i < 154 ? 182 + (i - 147) : 46 + (i - 154);
+}
+__host__ __device__ constexpr int rec_word_of_i(int k) { return 70 + k / 2; }
+// inverse: state index stored in record word w (-1: pad / not a float64 word)
+__host__ __device__ constexpr int d_of_rec_word(int w) {
+    return w < 45 ? w : w == 45 ? -1 : w < 69 ? 154 + (w - 46) : w < 78 ? -1 : w < 106 ? 45 + (w - 78) : w < 119 ? 73 + (w - 106)
+         : w == 119 ? -1 : w < 150 ? 86 + (w - 120) : w < 171 ? 116 + (w - 150) : w == 171 ? -1 : w < 182 ? 137 + (w - 172)
+         : w < 189 ? 147 + (w - 182) : -1;
+}
+// pages a visit reads (a prefix) and writes (bit mask)
+constexpr int kPagesAll = 6;
 
 // stages of runOptimization a patch can wait in (PatchOptimizer.cpp:48-76), see the PIPE visit
 enum { T_F1 = 1, T_BQ = 2, T_BQDONE = 3, T_F2 = 4, T_RS = 5, T_F3 = 6 };
@@ -112,7 +136,7 @@ constexpr int kCtlNextSlot = kCtlNextIdx + 8;   // next never-used record
 constexpr int kCtlDone = kCtlNextSlot + 8;      // finished patches
 constexpr int kCtlAbort = kCtlDone + 8;         // watchdog / internal-error flag
 constexpr int kCtlStats = kCtlAbort + 8;         // SK_STATS builds: 64 counters
-constexpr int kCtlWords = kCtlStats + 64;
+constexpr int kCtlWords = kCtlStats + 80;
 constexpr int kSlotBits = 18;                   // records per launch <= 262144
 constexpr unsigned kSlotMask = (1u << kSlotBits) - 1u;
 constexpr unsigned kTagMask = (1u << (32 - kSlotBits)) - 1u;
@@ -191,51 +215,151 @@ __device__ __noinline__ void sk_push(SkWs ws, int q, bool pred, int rec) {
 }
 
 // ---- record <-> registers / LDS ------------------------------------------------------------------------------
+// 16-byte sc1 accesses, 16 per batch: one page (256 B) of one record per lane with a single wait.  (The compiler
+// does not see the loads of an asm statement as outstanding, so the wait is part of the statement.)
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+struct Page { v4u q[16]; };
+#ifdef SK_NT
+#define SK_POL " sc1 nt\n"
+#else
+#define SK_POL " sc1\n"
+#endif
+
+__device__ __forceinline__ void load_page(const u64* p, Page& g) {
+    asm volatile(
+        "global_load_dwordx4 %0, %16, off" SK_POL
+        "global_load_dwordx4 %1, %16, off offset:16" SK_POL
+        "global_load_dwordx4 %2, %16, off offset:32" SK_POL
+        "global_load_dwordx4 %3, %16, off offset:48" SK_POL
+        "global_load_dwordx4 %4, %16, off offset:64" SK_POL
+        "global_load_dwordx4 %5, %16, off offset:80" SK_POL
+        "global_load_dwordx4 %6, %16, off offset:96" SK_POL
+        "global_load_dwordx4 %7, %16, off offset:112" SK_POL
+        "global_load_dwordx4 %8, %16, off offset:128" SK_POL
+        "global_load_dwordx4 %9, %16, off offset:144" SK_POL
+        "global_load_dwordx4 %10, %16, off offset:160" SK_POL
+        "global_load_dwordx4 %11, %16, off offset:176" SK_POL
+        "global_load_dwordx4 %12, %16, off offset:192" SK_POL
+        "global_load_dwordx4 %13, %16, off offset:208" SK_POL
+        "global_load_dwordx4 %14, %16, off offset:224" SK_POL
+        "global_load_dwordx4 %15, %16, off offset:240" SK_POL
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(g.q[0]), "=&v"(g.q[1]), "=&v"(g.q[2]), "=&v"(g.q[3]), "=&v"(g.q[4]), "=&v"(g.q[5]), "=&v"(g.q[6]), "=&v"(g.q[7]),
+          "=&v"(g.q[8]), "=&v"(g.q[9]), "=&v"(g.q[10]), "=&v"(g.q[11]), "=&v"(g.q[12]), "=&v"(g.q[13]), "=&v"(g.q[14]), "=&v"(g.q[15])
+        : "v"(p)
+        : "memory");
+}
+__device__ __forceinline__ void store_page(u64* p, const Page& g) {
+    asm volatile(
+        "global_store_dwordx4 %16, %0, off" SK_POL
+        "global_store_dwordx4 %16, %1, off offset:16" SK_POL
+        "global_store_dwordx4 %16, %2, off offset:32" SK_POL
+        "global_store_dwordx4 %16, %3, off offset:48" SK_POL
+        "global_store_dwordx4 %16, %4, off offset:64" SK_POL
+        "global_store_dwordx4 %16, %5, off offset:80" SK_POL
+        "global_store_dwordx4 %16, %6, off offset:96" SK_POL
+        "global_store_dwordx4 %16, %7, off offset:112" SK_POL
+        "global_store_dwordx4 %16, %8, off offset:128" SK_POL
+        "global_store_dwordx4 %16, %9, off offset:144" SK_POL
+        "global_store_dwordx4 %16, %10, off offset:160" SK_POL
+        "global_store_dwordx4 %16, %11, off offset:176" SK_POL
+        "global_store_dwordx4 %16, %12, off offset:192" SK_POL
+        "global_store_dwordx4 %16, %13, off offset:208" SK_POL
+        "global_store_dwordx4 %16, %14, off offset:224" SK_POL
+        "global_store_dwordx4 %16, %15, off offset:240" SK_POL
+        "s_nop 1"
+        :
+        : "v"(g.q[0]), "v"(g.q[1]), "v"(g.q[2]), "v"(g.q[3]), "v"(g.q[4]), "v"(g.q[5]), "v"(g.q[6]), "v"(g.q[7]), "v"(g.q[8]),
+          "v"(g.q[9]), "v"(g.q[10]), "v"(g.q[11]), "v"(g.q[12]), "v"(g.q[13]), "v"(g.q[14]), "v"(g.q[15]), "v"(p)
+        : "memory");
+}
+__device__ __forceinline__ u64 page_word(const Page& g, int k) {  // k = 0..31, compile-time
+    return ((u64)g.q[k / 2][2 * (k & 1) + 1] << 32) | (u64)g.q[k / 2][2 * (k & 1)];
+}
+__device__ __forceinline__ void set_page_word(Page& g, int k, u64 v) {
+    g.q[k / 2][2 * (k & 1)] = (unsigned)v;
+    g.q[k / 2][2 * (k & 1) + 1] = (unsigned)(v >> 32);
+}
+
 __device__ __forceinline__ void load_ps(const u64* rec, PipeState& ps) {
+    Page g;
+    load_page(rec + kRecPS, g);  // words 192..223: PipeState (24) + the first 8 words of the image list
     u64 w[24];
 #pragma unroll
-    for (int k = 0; k < 24; k++) w[k] = ldc(rec + kRecPS + k);
+    for (int k = 0; k < 24; k++) w[k] = page_word(g, k);
     __builtin_memcpy(&ps, w, sizeof(ps));
 }
 __device__ __forceinline__ void store_ps(u64* rec, const PipeState& ps) {
     u64 w[24];
     __builtin_memcpy(w, &ps, sizeof(ps));
 #pragma unroll
-    for (int k = 0; k < 24; k++) stc(rec + kRecPS + k, w[k]);
+    for (int k = 0; k < 24; k += 2) {
+        v4u q;
+        q[0] = (unsigned)w[k]; q[1] = (unsigned)(w[k] >> 32); q[2] = (unsigned)w[k + 1]; q[3] = (unsigned)(w[k + 1] >> 32);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" : : "v"(rec + kRecPS + k), "v"(q) : "memory");
+    }
 }
 
-// optimiser state of one patch: record -> LDS slot `slot` ([index][slot]) and back
-__device__ __noinline__ void page_in(const u64* rec, int slot) {
-    for (int i0 = 0; i0 < 176; i0 += 8) {
-        u64 w[8];
+// optimiser state: record page PG -> LDS slot `slot` ([index][slot]) and back
+template <int PG>
+__device__ __forceinline__ void page_to_lds(const Page& g, int slot) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) w[k] = ldc(rec + kRecD + i0 + k);
-#pragma unroll
-        for (int k = 0; k < 8; k++) bq_lds_d[(i0 + k) * BQ_SLOTS + slot] = __longlong_as_double((long long)w[k]);
+    for (int k = 0; k < kPageWords; k++) {
+        constexpr int w0 = PG * kPageWords;
+        const int w = w0 + k;
+        const int di = d_of_rec_word(w);
+        if (di >= 0) bq_lds_d[di * BQ_SLOTS + slot] = __longlong_as_double((long long)page_word(g, k));
+        else if (w >= 70 && w < 77) {
+            const u64 v = page_word(g, k);
+            const int i0 = 2 * (w - 70);
+            bq_lds_i[i0 * BQ_SLOTS + slot] = (int)(unsigned)v;
+            if (i0 + 1 < BQ_NI) bq_lds_i[(i0 + 1) * BQ_SLOTS + slot] = (int)(v >> 32);
+        }
     }
-    u64 w[8];
-    w[0] = ldc(rec + kRecD + 176);
-#pragma unroll
-    for (int k = 0; k < 7; k++) w[1 + k] = ldc(rec + kRecI + k);
-    bq_lds_d[176 * BQ_SLOTS + slot] = __longlong_as_double((long long)w[0]);
-#pragma unroll
-    for (int k = 0; k < 13; k++) bq_lds_i[k * BQ_SLOTS + slot] = (int)(w[1 + k / 2] >> (32 * (k & 1)));
 }
-__device__ __noinline__ void page_out(u64* rec, int slot) {
-    for (int i0 = 0; i0 < 176; i0 += 8) {
-        u64 w[8];
+template <int PG>
+__device__ __forceinline__ void lds_to_page(Page& g, int slot) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) w[k] = (u64)__double_as_longlong(bq_lds_d[(i0 + k) * BQ_SLOTS + slot]);
-#pragma unroll
-        for (int k = 0; k < 8; k++) stc(rec + kRecD + i0 + k, w[k]);
+    for (int k = 0; k < kPageWords; k++) {
+        constexpr int w0 = PG * kPageWords;
+        const int w = w0 + k;
+        const int di = d_of_rec_word(w);
+        u64 v = 0;
+        if (di >= 0) v = (u64)__double_as_longlong(bq_lds_d[di * BQ_SLOTS + slot]);
+        else if (w >= 70 && w < 77) {
+            const int i0 = 2 * (w - 70);
+            const unsigned lo = (unsigned)bq_lds_i[i0 * BQ_SLOTS + slot];
+            const unsigned hi = (i0 + 1 < BQ_NI) ? (unsigned)bq_lds_i[(i0 + 1) * BQ_SLOTS + slot] : 0u;
+            v = ((u64)hi << 32) | lo;
+        }
+        set_page_word(g, k, v);
     }
-    stc(rec + kRecD + 176, (u64)__double_as_longlong(bq_lds_d[176 * BQ_SLOTS + slot]));
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const unsigned lo = (unsigned)bq_lds_i[(2 * k) * BQ_SLOTS + slot];
-        const unsigned hi = (2 * k + 1 < 13) ? (unsigned)bq_lds_i[(2 * k + 1) * BQ_SLOTS + slot] : 0u;
-        stc(rec + kRecI + k, ((u64)hi << 32) | lo);
-    }
+}
+template <int PG>
+__device__ __forceinline__ void page_in_one(const u64* rec, int slot) {
+    Page g;
+    load_page(rec + PG * kPageWords, g);
+    page_to_lds<PG>(g, slot);
+}
+template <int PG>
+__device__ __forceinline__ void page_out_one(u64* rec, int slot) {
+    Page g;
+    lds_to_page<PG>(g, slot);
+    store_page(rec + PG * kPageWords, g);
+}
+// the first `npages` pages of the state
+__device__ __noinline__ void page_in(const u64* rec, int slot, int npages) {
+    page_in_one<0>(rec, slot); page_in_one<1>(rec, slot); page_in_one<2>(rec, slot); page_in_one<3>(rec, slot);
+    if (npages > 4) { page_in_one<4>(rec, slot); page_in_one<5>(rec, slot); }
+}
+// the pages whose bit is set in `mask`
+__device__ __noinline__ void page_out(u64* rec, int slot, unsigned mask) {
+    if (mask & 1u) page_out_one<0>(rec, slot);
+    if (mask & 2u) page_out_one<1>(rec, slot);
+    if (mask & 4u) page_out_one<2>(rec, slot);
+    if (mask & 8u) page_out_one<3>(rec, slot);
+    if (mask & 16u) page_out_one<4>(rec, slot);
+    if (mask & 32u) page_out_one<5>(rec, slot);
 }
 
 // image list: record <-> the lane's private row
@@ -250,6 +374,11 @@ __device__ __forceinline__ void row_out(u64* rec, const uint16_t* row) {
 #pragma unroll
     for (int k = 0; k < kRowWords; k++) stc(rec + kRecRow + k, ((const u64*)row)[k]);
 }
+// single state words of a record (the PIPE visit reads xfinal / minf / nevals of a finished optimisation)
+__device__ __forceinline__ double rec_d(const u64* rec, int state_index) {
+    return __longlong_as_double((long long)ldc(rec + rec_word_of_d(state_index)));
+}
+__device__ __forceinline__ int rec_i(const u64* rec, int k) { return (int)(ldc(rec + rec_word_of_i(k)) >> (32 * (k & 1))); }
 
 // ---- outputs of a finished patch (PatchOptimizer::optimize copy-out, PatchOptimizer.cpp:86-103) ----------------
 __device__ __noinline__ void write_outputs(DevScene sc, DevBatch b, const PipeState& ps, const uint16_t* row, bool ok_,
@@ -382,7 +511,14 @@ __device__ __noinline__ bool visit_eval(DevScene sc, DevOptions o, SkWs ws) {
     r.obj = 2.0; r.keep = 0ull; r.incc_sum = 0.0f; r.ngrabs = 0;
     const u64 pending = __ballot(active && ps.op != OP_NONE);
     SKV_T(tc);
+#ifndef SK_EVAL_COMPACT
+    // 49 lanes per grab, sums through LDS: neighbouring lanes read neighbouring texels, 2.1 k wave-cycles per grab
     wave_eval_packed<true>(sc, o, recrow, pending, q, r, *reinterpret_cast<EvalLds*>(sk_lds));
+#else
+    // one lane per usable (request, image) grab: 4x fewer instructions but every lane gathers from its own cache
+    // lines (13x L1 fill amplification): 3.4 k wave-cycles per grab measured (profiles/r02/stream_kernel)
+    r = wave_eval_compact<true>(sc, o, recrow, pending, q, r);
+#endif
     SKV_T(td);
     if (active) {
         ps.res_f = r.obj; ps.res_mask = r.keep; ps.res_sum = r.incc_sum; ps.ngrabs += r.ngrabs; ps.op = OP_NONE;
@@ -417,8 +553,16 @@ __device__ __noinline__ bool visit_block(DevScene sc, DevOptions o, SkWs ws, int
     B.slot = lane < SK_P ? lane : 0;
     PipeState ps;
     __builtin_memset(&ps, 0, sizeof(ps));
-    if (active) { page_in(R, lane); load_ps(R, ps); }
+    // what this block reads (a prefix of the record) and may write (pages): see the record layout
+    const int in_pages = (q == Q_L60) ? 4 : kPagesAll;
+    const unsigned out_pages = (q == Q_L60) ? 0x07u : (q == Q_L90) ? 0x1fu : (q == Q_L210 || q == Q_L230) ? 0x27u : 0x3fu;
+#ifdef SK_POISON
+    for (int k = lane; k < kSkLdsBytes / 8; k += 64) ((u64*)sk_lds)[k] = 0xfff8dead0000beefull;  // NaN: a page-set bug shows
     wave_lds_sync();
+#endif
+    if (active) { page_in(R, lane, in_pages); load_ps(R, ps); }
+    wave_lds_sync();
+    // (AE rewrites zmat, whose tail shares page 5 with vlag / wsuma: all six pages go back)
     SKV_T(tc);
     int label = bq::LRET_DONE;
     constexpr unsigned cheap = (1u << bq::L20) | (1u << bq::L650) | (1u << bq::L680) | (1u << bq::L360) | (1u << bq::L720);
@@ -461,7 +605,7 @@ __device__ __noinline__ bool visit_block(DevScene sc, DevOptions o, SkWs ws, int
         else if (label == bq::L230) nq = Q_L230;
         else if (label == bq::L190) nq = Q_RESC;
         else atomicExch((int*)(ws.ctl + kCtlAbort), 3);
-        page_out(R, lane);
+        page_out(R, lane, out_pages);
         store_ps(R, ps);
     }
     drain_stores();
@@ -530,9 +674,7 @@ __device__ __noinline__ bool visit_pipe(DevScene sc, DevOptions o, DevBatch b, S
             {
                 OptFields F;
                 __builtin_memcpy(&F, ps.F, sizeof(F));
-                const double xf[3] = {__longlong_as_double((long long)ldc(R + kRecD + O_xfinal)),
-                                      __longlong_as_double((long long)ldc(R + kRecD + O_xfinal + 1)),
-                                      __longlong_as_double((long long)ldc(R + kRecD + O_xfinal + 2))};
+                const double xf[3] = {rec_d(R, O_xfinal), rec_d(R, O_xfinal + 1), rec_d(R, O_xfinal + 2)};
                 set_center_norm(F, o, xf, ps.c, ps.n);
             }
             nimg = add_images_v(sc, o, row, nimg, HPMVS_F3(ps.c), HPMVS_F3(ps.n), ps.scale);
@@ -584,15 +726,13 @@ __device__ __noinline__ bool visit_pipe(DevScene sc, DevOptions o, DevBatch b, S
             int nev = 0;
             if (started) { fminv = BQS(minf); xf0 = BQA(xfinal, 0); xf1 = BQA(xfinal, 1); xf2 = BQA(xfinal, 2); nev = BQN(nevals); }
             else if (ps.have_bq) {
-                fminv = __longlong_as_double((long long)ldc(R + kRecD + O_minf));
-                xf0 = __longlong_as_double((long long)ldc(R + kRecD + O_xfinal));
-                xf1 = __longlong_as_double((long long)ldc(R + kRecD + O_xfinal + 1));
-                xf2 = __longlong_as_double((long long)ldc(R + kRecD + O_xfinal + 2));
-                nev = (int)(ldc(R + kRecI + I_nevals / 2) >> (32 * (I_nevals & 1)));
+                fminv = rec_d(R, O_minf);
+                xf0 = rec_d(R, O_xfinal); xf1 = rec_d(R, O_xfinal + 1); xf2 = rec_d(R, O_xfinal + 2);
+                nev = rec_i(R, I_nevals);
             }
             write_outputs(sc, b, ps, row, okdone, fminv, xf0, xf1, xf2, nev);
         } else {
-            if (started) page_out(R, lane);
+            if (started) page_out(R, lane, 63u);  // bq_start wrote the whole state
             store_ps(R, ps);
             row_out(R, row);
         }
@@ -649,6 +789,8 @@ __global__ void __launch_bounds__(64, 2) stream_kernel(DevScene sc, DevOptions o
     long long st_[40];
     for (int k = 0; k < 40; k++) st_[k] = 0;
     const long long tstart_ = clock64();
+    if (blockIdx.x == 0 && lane == 0) g_evdbg = L.ctl + kCtlStats + 56;  // evaluator timers land in shard 0's block
+    __syncthreads();
 #endif
     for (;;) {
         // ---- queue fill levels, one lane per queue

@@ -5,6 +5,8 @@ import os, sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 from hpmvs_amd import api, synth
 a = sys.argv[1:]
+if a and a[0].endswith('.so'):
+    api.LIB_PATH = a[0]; a = a[1:]
 views, w, h, n, sl = (int(a[0]), int(a[1]), int(a[2]), int(a[3]), int(a[4])) if len(a) >= 5 else (12, 1920, 1080, 100000, 4)
 dev = torch.device('cuda', 0)
 scene = synth.make_scene(views, w, h, n_waves=24, device=dev)
