@@ -215,151 +215,107 @@ __device__ __noinline__ void sk_push(SkWs ws, int q, bool pred, int rec) {
 }
 
 // ---- record <-> registers / LDS ------------------------------------------------------------------------------
-// 16-byte sc1 accesses, 16 per batch: one page (256 B) of one record per lane with a single wait.  (The compiler
-// does not see the loads of an asm statement as outstanding, so the wait is part of the statement.)
+// Records are accessed through a raw buffer resource with sc1 (write-through / L1-bypassing) 16-byte accesses
+// (__builtin_amdgcn_raw_buffer_load/store_b128, aux = 16: the compiler tracks them like any other load, so a whole
+// set of pages is in flight behind one wait).  State pages move COOPERATIVELY: 16 consecutive lanes carry the 16
+// chunks of one 256-byte page of one record, so every store instruction writes four whole pages (full cache lines;
+// per-lane 16-byte sc1 stores measured 2.7x write amplification at the memory side) and the LDS side is a
+// transposition ([index][slot] <-> record order).
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
-struct Page { v4u q[16]; };
-#ifdef SK_NT
-#define SK_POL " sc1 nt\n"
-#else
-#define SK_POL " sc1\n"
-#endif
-
-__device__ __forceinline__ void load_page(const u64* p, Page& g) {
-    asm volatile(
-        "global_load_dwordx4 %0, %16, off" SK_POL
-        "global_load_dwordx4 %1, %16, off offset:16" SK_POL
-        "global_load_dwordx4 %2, %16, off offset:32" SK_POL
-        "global_load_dwordx4 %3, %16, off offset:48" SK_POL
-        "global_load_dwordx4 %4, %16, off offset:64" SK_POL
-        "global_load_dwordx4 %5, %16, off offset:80" SK_POL
-        "global_load_dwordx4 %6, %16, off offset:96" SK_POL
-        "global_load_dwordx4 %7, %16, off offset:112" SK_POL
-        "global_load_dwordx4 %8, %16, off offset:128" SK_POL
-        "global_load_dwordx4 %9, %16, off offset:144" SK_POL
-        "global_load_dwordx4 %10, %16, off offset:160" SK_POL
-        "global_load_dwordx4 %11, %16, off offset:176" SK_POL
-        "global_load_dwordx4 %12, %16, off offset:192" SK_POL
-        "global_load_dwordx4 %13, %16, off offset:208" SK_POL
-        "global_load_dwordx4 %14, %16, off offset:224" SK_POL
-        "global_load_dwordx4 %15, %16, off offset:240" SK_POL
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(g.q[0]), "=&v"(g.q[1]), "=&v"(g.q[2]), "=&v"(g.q[3]), "=&v"(g.q[4]), "=&v"(g.q[5]), "=&v"(g.q[6]), "=&v"(g.q[7]),
-          "=&v"(g.q[8]), "=&v"(g.q[9]), "=&v"(g.q[10]), "=&v"(g.q[11]), "=&v"(g.q[12]), "=&v"(g.q[13]), "=&v"(g.q[14]), "=&v"(g.q[15])
-        : "v"(p)
-        : "memory");
+constexpr int kSc1 = 16;  // aux / cache-policy bit of the buffer intrinsics: sc1
+struct RecBuf { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ RecBuf make_recbuf(const SkWs& ws) {
+    RecBuf b;
+    b.r = __builtin_amdgcn_make_buffer_rsrc((void*)ws.recs, 0, ws.n_recs * (int)(kRecWords * sizeof(u64)), 0x00020000);
+    return b;
 }
-__device__ __forceinline__ void store_page(u64* p, const Page& g) {
-    asm volatile(
-        "global_store_dwordx4 %16, %0, off" SK_POL
-        "global_store_dwordx4 %16, %1, off offset:16" SK_POL
-        "global_store_dwordx4 %16, %2, off offset:32" SK_POL
-        "global_store_dwordx4 %16, %3, off offset:48" SK_POL
-        "global_store_dwordx4 %16, %4, off offset:64" SK_POL
-        "global_store_dwordx4 %16, %5, off offset:80" SK_POL
-        "global_store_dwordx4 %16, %6, off offset:96" SK_POL
-        "global_store_dwordx4 %16, %7, off offset:112" SK_POL
-        "global_store_dwordx4 %16, %8, off offset:128" SK_POL
-        "global_store_dwordx4 %16, %9, off offset:144" SK_POL
-        "global_store_dwordx4 %16, %10, off offset:160" SK_POL
-        "global_store_dwordx4 %16, %11, off offset:176" SK_POL
-        "global_store_dwordx4 %16, %12, off offset:192" SK_POL
-        "global_store_dwordx4 %16, %13, off offset:208" SK_POL
-        "global_store_dwordx4 %16, %14, off offset:224" SK_POL
-        "global_store_dwordx4 %16, %15, off offset:240" SK_POL
-        "s_nop 1"
-        :
-        : "v"(g.q[0]), "v"(g.q[1]), "v"(g.q[2]), "v"(g.q[3]), "v"(g.q[4]), "v"(g.q[5]), "v"(g.q[6]), "v"(g.q[7]), "v"(g.q[8]),
-          "v"(g.q[9]), "v"(g.q[10]), "v"(g.q[11]), "v"(g.q[12]), "v"(g.q[13]), "v"(g.q[14]), "v"(g.q[15]), "v"(p)
-        : "memory");
+__device__ __forceinline__ v4u rec_load16(RecBuf b, int rec, int word) {
+    return __builtin_amdgcn_raw_buffer_load_b128(b.r, rec * (int)(kRecWords * sizeof(u64)) + word * 8, 0, kSc1);
 }
-__device__ __forceinline__ u64 page_word(const Page& g, int k) {  // k = 0..31, compile-time
-    return ((u64)g.q[k / 2][2 * (k & 1) + 1] << 32) | (u64)g.q[k / 2][2 * (k & 1)];
-}
-__device__ __forceinline__ void set_page_word(Page& g, int k, u64 v) {
-    g.q[k / 2][2 * (k & 1)] = (unsigned)v;
-    g.q[k / 2][2 * (k & 1) + 1] = (unsigned)(v >> 32);
+__device__ __forceinline__ void rec_store16(RecBuf b, int rec, int word, v4u v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, b.r, rec * (int)(kRecWords * sizeof(u64)) + word * 8, 0, kSc1);
 }
 
-__device__ __forceinline__ void load_ps(const u64* rec, PipeState& ps) {
-    Page g;
-    load_page(rec + kRecPS, g);  // words 192..223: PipeState (24) + the first 8 words of the image list
-    u64 w[24];
+__device__ __forceinline__ void load_ps(RecBuf b, int rec, PipeState& ps) {
+    v4u q[12];
 #pragma unroll
-    for (int k = 0; k < 24; k++) w[k] = page_word(g, k);
-    __builtin_memcpy(&ps, w, sizeof(ps));
+    for (int k = 0; k < 12; k++) q[k] = rec_load16(b, rec, kRecPS + 2 * k);
+    __builtin_memcpy(&ps, q, sizeof(ps));
 }
-__device__ __forceinline__ void store_ps(u64* rec, const PipeState& ps) {
-    u64 w[24];
-    __builtin_memcpy(w, &ps, sizeof(ps));
+__device__ __forceinline__ void store_ps(RecBuf b, int rec, const PipeState& ps) {
+    v4u q[12];
+    __builtin_memcpy(q, &ps, sizeof(ps));
 #pragma unroll
-    for (int k = 0; k < 24; k += 2) {
-        v4u q;
-        q[0] = (unsigned)w[k]; q[1] = (unsigned)(w[k] >> 32); q[2] = (unsigned)w[k + 1]; q[3] = (unsigned)(w[k + 1] >> 32);
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" : : "v"(rec + kRecPS + k), "v"(q) : "memory");
+    for (int k = 0; k < 12; k++) rec_store16(b, rec, kRecPS + 2 * k, q[k]);
+}
+
+// state word w (record order, run-time) of LDS slot `slot`
+__device__ __forceinline__ u64 lds_state_word(int w, int slot) {
+    const int di = d_of_rec_word(w);
+    if (di >= 0) return (u64)__double_as_longlong(bq_lds_d[di * BQ_SLOTS + slot]);
+    if (w >= 70 && w < 77) {
+        const int i0 = 2 * (w - 70);
+        const unsigned lo = (unsigned)bq_lds_i[i0 * BQ_SLOTS + slot];
+        const unsigned hi = (i0 + 1 < BQ_NI) ? (unsigned)bq_lds_i[(i0 + 1) * BQ_SLOTS + slot] : 0u;
+        return ((u64)hi << 32) | lo;
+    }
+    return 0ull;
+}
+__device__ __forceinline__ void set_lds_state_word(int w, int slot, u64 v) {
+    const int di = d_of_rec_word(w);
+    if (di >= 0) bq_lds_d[di * BQ_SLOTS + slot] = __longlong_as_double((long long)v);
+    else if (w >= 70 && w < 77) {
+        const int i0 = 2 * (w - 70);
+        bq_lds_i[i0 * BQ_SLOTS + slot] = (int)(unsigned)v;
+        if (i0 + 1 < BQ_NI) bq_lds_i[(i0 + 1) * BQ_SLOTS + slot] = (int)(v >> 32);
     }
 }
+constexpr int kCoopSteps = (SK_P + 3) / 4;  // four records per instruction
 
-// optimiser state: record page PG -> LDS slot `slot` ([index][slot]) and back
-template <int PG>
-__device__ __forceinline__ void page_to_lds(const Page& g, int slot) {
+// pages 0..npages-1 of the records of slots 0..n-1 (lane s holds the record of slot s) -> LDS.  Wave-uniform call.
+__device__ __noinline__ void page_in_coop(RecBuf b, int myrec, int n, int npages) {
+    const int lane = lane_id();
+    const int sub = lane >> 4, chunk = lane & 15;
+    v4u q[kPagesAll][kCoopSteps];
 #pragma unroll
-    for (int k = 0; k < kPageWords; k++) {
-        constexpr int w0 = PG * kPageWords;
-        const int w = w0 + k;
-        const int di = d_of_rec_word(w);
-        if (di >= 0) bq_lds_d[di * BQ_SLOTS + slot] = __longlong_as_double((long long)page_word(g, k));
-        else if (w >= 70 && w < 77) {
-            const u64 v = page_word(g, k);
-            const int i0 = 2 * (w - 70);
-            bq_lds_i[i0 * BQ_SLOTS + slot] = (int)(unsigned)v;
-            if (i0 + 1 < BQ_NI) bq_lds_i[(i0 + 1) * BQ_SLOTS + slot] = (int)(v >> 32);
+    for (int pg = 0; pg < kPagesAll; pg++)
+#pragma unroll
+        for (int st = 0; st < kCoopSteps; st++) {
+            const int slot = 4 * st + sub;
+            const int rec = shfl_i(myrec, slot & 63);
+            q[pg][st] = v4u{0u, 0u, 0u, 0u};
+            if (pg < npages && slot < n) q[pg][st] = rec_load16(b, rec, pg * kPageWords + 2 * chunk);
+        }
+#pragma unroll
+    for (int pg = 0; pg < kPagesAll; pg++)
+#pragma unroll
+        for (int st = 0; st < kCoopSteps; st++) {
+            const int slot = 4 * st + sub;
+            if (pg < npages && slot < n) {
+                const int w = pg * kPageWords + 2 * chunk;
+                set_lds_state_word(w, slot, ((u64)q[pg][st][1] << 32) | q[pg][st][0]);
+                set_lds_state_word(w + 1, slot, ((u64)q[pg][st][3] << 32) | q[pg][st][2]);
+            }
+        }
+}
+// the pages in `pages` of the slots in `slots` (bit s <=> slot s) LDS -> records.  Wave-uniform call.
+__device__ __noinline__ void page_out_coop(RecBuf b, int myrec, u64 slots, unsigned pages) {
+    const int lane = lane_id();
+    const int sub = lane >> 4, chunk = lane & 15;
+#pragma unroll
+    for (int pg = 0; pg < kPagesAll; pg++) {
+        if (!((pages >> pg) & 1u)) continue;
+#pragma unroll
+        for (int st = 0; st < kCoopSteps; st++) {
+            const int slot = 4 * st + sub;
+            const int rec = shfl_i(myrec, slot & 63);
+            if (slot < SK_P && ((slots >> slot) & 1ull)) {
+                const int w = pg * kPageWords + 2 * chunk;
+                const u64 w0 = lds_state_word(w, slot), w1 = lds_state_word(w + 1, slot);
+                rec_store16(b, rec, w, v4u{(unsigned)w0, (unsigned)(w0 >> 32), (unsigned)w1, (unsigned)(w1 >> 32)});
+            }
         }
     }
-}
-template <int PG>
-__device__ __forceinline__ void lds_to_page(Page& g, int slot) {
-#pragma unroll
-    for (int k = 0; k < kPageWords; k++) {
-        constexpr int w0 = PG * kPageWords;
-        const int w = w0 + k;
-        const int di = d_of_rec_word(w);
-        u64 v = 0;
-        if (di >= 0) v = (u64)__double_as_longlong(bq_lds_d[di * BQ_SLOTS + slot]);
-        else if (w >= 70 && w < 77) {
-            const int i0 = 2 * (w - 70);
-            const unsigned lo = (unsigned)bq_lds_i[i0 * BQ_SLOTS + slot];
-            const unsigned hi = (i0 + 1 < BQ_NI) ? (unsigned)bq_lds_i[(i0 + 1) * BQ_SLOTS + slot] : 0u;
-            v = ((u64)hi << 32) | lo;
-        }
-        set_page_word(g, k, v);
-    }
-}
-template <int PG>
-__device__ __forceinline__ void page_in_one(const u64* rec, int slot) {
-    Page g;
-    load_page(rec + PG * kPageWords, g);
-    page_to_lds<PG>(g, slot);
-}
-template <int PG>
-__device__ __forceinline__ void page_out_one(u64* rec, int slot) {
-    Page g;
-    lds_to_page<PG>(g, slot);
-    store_page(rec + PG * kPageWords, g);
-}
-// the first `npages` pages of the state
-__device__ __noinline__ void page_in(const u64* rec, int slot, int npages) {
-    page_in_one<0>(rec, slot); page_in_one<1>(rec, slot); page_in_one<2>(rec, slot); page_in_one<3>(rec, slot);
-    if (npages > 4) { page_in_one<4>(rec, slot); page_in_one<5>(rec, slot); }
-}
-// the pages whose bit is set in `mask`
-__device__ __noinline__ void page_out(u64* rec, int slot, unsigned mask) {
-    if (mask & 1u) page_out_one<0>(rec, slot);
-    if (mask & 2u) page_out_one<1>(rec, slot);
-    if (mask & 4u) page_out_one<2>(rec, slot);
-    if (mask & 8u) page_out_one<3>(rec, slot);
-    if (mask & 16u) page_out_one<4>(rec, slot);
-    if (mask & 32u) page_out_one<5>(rec, slot);
 }
 
 // image list: record <-> the lane's private row
@@ -446,6 +402,7 @@ __device__ __noinline__ bool visit_fetch(DevScene sc, DevOptions o, DevBatch b, 
     PipeState ps;
     __builtin_memset(&ps, 0, sizeof(ps));
     u64* R = ws.recs + (size_t)(active ? rec : 0) * kRecWords;
+    const RecBuf rb = make_recbuf(ws);
     if (active) {
         const int idx = ws.idx_base + i0 + lane;
         ps.idx = idx;
@@ -472,7 +429,7 @@ __device__ __noinline__ bool visit_fetch(DevScene sc, DevOptions o, DevBatch b, 
         } while (0);
         ps.nimg = nimg;
         if (finished) write_outputs(sc, b, ps, row, false, 0.0, 0.0, 0.0, 0.0, 0);
-        else { store_ps(R, ps); row_out(R, row); }
+        else { store_ps(rb, rec, ps); row_out(R, row); }
     }
     drain_stores();
     sk_push(ws, Q_EVAL, to_eval, rec);
@@ -494,7 +451,8 @@ __device__ __noinline__ bool visit_eval(DevScene sc, DevOptions o, SkWs ws) {
     u64* R = ws.recs + (size_t)(active ? rec : 0) * kRecWords;
     PipeState ps;
     __builtin_memset(&ps, 0, sizeof(ps));
-    if (active) load_ps(R, ps);
+    const RecBuf rb = make_recbuf(ws);
+    if (active) load_ps(rb, rec, ps);
     const uint16_t* recrow = (const uint16_t*)(R + kRecRow);
     PackedReq q;
     q.obj_mode = (ps.op == OP_OBJ) ? 1 : 0;
@@ -560,7 +518,9 @@ __device__ __noinline__ bool visit_block(DevScene sc, DevOptions o, SkWs ws, int
     for (int k = lane; k < kSkLdsBytes / 8; k += 64) ((u64*)sk_lds)[k] = 0xfff8dead0000beefull;  // NaN: a page-set bug shows
     wave_lds_sync();
 #endif
-    if (active) { page_in(R, lane, in_pages); load_ps(R, ps); }
+    const RecBuf rb = make_recbuf(ws);
+    page_in_coop(rb, rec, n, in_pages);
+    if (active) load_ps(rb, rec, ps);
     wave_lds_sync();
     // (AE rewrites zmat, whose tail shares page 5 with vlag / wsuma: all six pages go back)
     SKV_T(tc);
@@ -605,9 +565,10 @@ __device__ __noinline__ bool visit_block(DevScene sc, DevOptions o, SkWs ws, int
         else if (label == bq::L230) nq = Q_L230;
         else if (label == bq::L190) nq = Q_RESC;
         else atomicExch((int*)(ws.ctl + kCtlAbort), 3);
-        page_out(R, lane, out_pages);
-        store_ps(R, ps);
+        store_ps(rb, rec, ps);
     }
+    wave_lds_sync();
+    page_out_coop(rb, rec, n >= 64 ? ~0ull : ((1ull << n) - 1ull), out_pages);
     drain_stores();
     SKV_T(te);
     sk_push(ws, Q_EVAL, nq == Q_EVAL, rec);
@@ -640,8 +601,9 @@ __device__ __noinline__ bool visit_pipe(DevScene sc, DevOptions o, DevBatch b, S
     bool to_eval = false, fail = false, okdone = false, started = false;
     const double lbv[3] = {-HUGE_VAL, -23.99999, -23.99999};  // PatchOptimizer.cpp:326-336
     const double ubv[3] = {HUGE_VAL, 23.99999, 23.99999};
+    const RecBuf rb = make_recbuf(ws);
     if (active) {
-        load_ps(R, ps);
+        load_ps(rb, rec, ps);
         row_in(R, row);
         int nimg = ps.nimg;
         switch (ps.stage) {
@@ -732,11 +694,12 @@ __device__ __noinline__ bool visit_pipe(DevScene sc, DevOptions o, DevBatch b, S
             }
             write_outputs(sc, b, ps, row, okdone, fminv, xf0, xf1, xf2, nev);
         } else {
-            if (started) page_out(R, lane, 63u);  // bq_start wrote the whole state
-            store_ps(R, ps);
+            store_ps(rb, rec, ps);
             row_out(R, row);
         }
     }
+    wave_lds_sync();
+    page_out_coop(rb, rec, __ballot(active && started && !(fail || okdone)), 0x3fu);  // bq_start wrote the whole state
     drain_stores();
     sk_push(ws, Q_EVAL, to_eval, rec);
     sk_push(ws, Q_FREE, fail || okdone, rec);

@@ -18,7 +18,7 @@ csv.field_size_limit(1 << 30)
 
 def main():
     d, prefix = sys.argv[1], sys.argv[2]
-    pats = sys.argv[3:] or ["optimize_kernel", "half_resize_kernel", "objective_kernel", "inccs_kernel"]
+    pats = sys.argv[3:] or ["optimize_kernel", "stream_kernel", "half_resize_kernel", "objective_kernel", "inccs_kernel"]
     traces = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
     stats = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
     for f in traces:
