@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="weak: seeds per GPU fixed; strong: one batch cut across the ranks (default: the workload's)")
     ap.add_argument("--patches", type=int, default=0, help="override the workload's seed count")
+    ap.add_argument("--order", default="as-is", choices=["as-is", "tiles"],
+                    help="tiles: host-side bucket sort of the round by (reference image, 256-px tile), SURVEY 8e")
     ap.add_argument("--cpu-sample", type=int, default=32768, help="patches of the parity sample")
     ap.add_argument("--cpu-timing-sample", type=int, default=262144, help="patches of the all-core CPU-baseline run")
     ap.add_argument("--cpu-sample-1core", type=int, default=16384, help="patches of the 1-core CPU run")
@@ -154,6 +156,11 @@ def main():
     if scaling == "strong" and world > 1:
         seeds = synth.Seeds(center=seeds.center[lo:hi], normal=seeds.normal[lo:hi], scale=seeds.scale[lo:hi],
                             n_images=seeds.n_images[lo:hi], images=seeds.images[lo:hi], truth=seeds.truth[lo:hi])
+    if args.order == "tiles":
+        P0 = np.array([list(api.camera_from_nvm(v.f, v.q, v.c, v.width, v.height, scene.max_level).P0) for v in scene.views])
+        perm = dd.tile_order(seeds.center, seeds.images, seeds.n_images, P0)
+        seeds = synth.Seeds(center=seeds.center[perm], normal=seeds.normal[perm], scale=seeds.scale[perm],
+                            n_images=seeds.n_images[perm], images=seeds.images[perm], truth=seeds.truth[perm])
     pristine = device_batch(seeds, dev, max_images)
     work = {k: v.clone() for k, v in pristine.items()}
     opts = api.default_options()
@@ -257,7 +264,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": args.workload, "views": views, "image": f"{W}x{H}", "pyramid_levels": 6,
                    "seeds_per_gpu": n_seeds, "seeds_per_step_all_gpus": n_job, "start_level": start_level,
-                   "max_images": max_images,
+                   "max_images": max_images, "order": args.order,
                    "parallelism": f"patch-shard x{world} + all-gather of {RECORD_BYTES} B records"},
         "host_to_host": h2h,
         "successes_per_sec_rank0_extrapolated": n_job * float(ok.mean()) * args.steps / elapsed,
@@ -337,9 +344,9 @@ def main():
                          np.array_equal(np.array(p.color[:], dtype=np.float32), col_g[k]) and
                          p.nevals == nev_g[k] and list(p.images[:p.n_images]) == list(img_g[k, :nim_g[k]]))
             dncc.append(abs(unrob(p.fmin) - unrob(fmin_g[k])))
-            dd = np.linalg.norm(np.array(p.center[:3]) - cen_g[k, :3]) / float(seeds.scale[k])
+            ddist = np.linalg.norm(np.array(p.center[:3]) - cen_g[k, :3]) / float(seeds.scale[k])
             cs = float(np.clip(np.dot(np.array(p.normal[:3]), nor_g[k, :3]), -1, 1))
-            basin.append(dd < 0.25 and np.degrees(np.arccos(cs)) < 2.0)
+            basin.append(ddist < 0.25 and np.degrees(np.arccos(cs)) < 2.0)
         out["cpu_baseline"] = {
             "value": mt / tc, "unit": "patches/s", "cores": cores,
             "kind": "port",

@@ -36,6 +36,23 @@ def shard_range(n: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def tile_order(center, images, n_images, cameras_P0, tile_px: int = 256) -> np.ndarray:
+    """SURVEY 8e's host-side bucket sort: a permutation that groups the patches of a round by (reference image,
+    256-px tile of the projected centre in that image), so that wavefronts working on neighbouring queue entries
+    sample neighbouring pixels.  Patches are independent, so the order changes no result -- only which cache
+    lines a wavefront's taps share.  cameras_P0: [n_views, 12] level-0 projection rows (hpmvs_camera.P0)."""
+    center = np.asarray(center, dtype=np.float64)
+    ref = np.where(np.asarray(n_images) > 0, np.asarray(images)[:, 0], 0).astype(np.int64)
+    P = np.asarray(cameras_P0, dtype=np.float64).reshape(-1, 3, 4)[ref]
+    X = np.concatenate([center[:, :3], np.ones((len(center), 1))], axis=1)
+    r = np.einsum("nij,nj->ni", P, X)
+    z = np.where(np.abs(r[:, 2]) > 1e-12, r[:, 2], 1.0)
+    tx = np.clip(np.floor(r[:, 0] / z / tile_px), -1, 1 << 15).astype(np.int64)
+    ty = np.clip(np.floor(r[:, 1] / z / tile_px), -1, 1 << 15).astype(np.int64)
+    key = (ref << 40) | ((ty + 1) << 20) | (tx + 1)
+    return np.argsort(key, kind="stable")
+
+
 def pack_records(center, normal, color, scale, fmin, ok, n_images, images, check: bool = True) -> torch.Tensor:
     """SoA outputs -> [n, 192] uint8 records (same layout on every rank, any device).
 
