@@ -400,8 +400,17 @@ BQ_HD_NOINLINE void trsbox(BqRef B) {
 
     enum { CG_RESTART, CG_NEXT, BOUNDARY, ALT_SETUP, ALT_ITER, FINISH };
     int st = CG_RESTART;
-    for (;;) {
-        BQ_PROF_BEGIN(tcg_);
+    // The lanes of a wavefront that are in here run different patches and need different numbers of conjugate-
+    // gradient and boundary iterations.  One loop over "whatever state each lane is in" executes the CG block and
+    // the (3x longer) boundary block in every pass while ANY lane still needs either; the state graph has no edge
+    // from the boundary search back to CG, so the two phases run as two loops: lanes that finished CG wait for the
+    // others, then all boundary searches advance together.  Per lane the operations and their order are unchanged.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BQ_ANY(c) __any(c)
+#else
+#define BQ_ANY(c) (c)
+#endif
+    while (BQ_ANY(st == CG_RESTART || st == CG_NEXT)) {
         if (st == CG_RESTART) { beta = 0.0; st = CG_NEXT; }
         if (st == CG_NEXT) {
             stepsq = 0.0;
@@ -471,8 +480,8 @@ BQ_HD_NOINLINE void trsbox(BqRef B) {
             }
             st = BOUNDARY;
         }
-        BQ_PROF_END(tcg_, 16);
-        BQ_PROF_BEGIN(tas_);
+    }
+    while (BQ_ANY(st == BOUNDARY || st == ALT_SETUP || st == ALT_ITER)) {
         if (st == BOUNDARY) { crvmin = 0.0; st = ALT_SETUP; }
         if (st == ALT_SETUP) {
             if (nact >= 2) { st = FINISH; continue; }
@@ -490,8 +499,6 @@ BQ_HD_NOINLINE void trsbox(BqRef B) {
             for (int i = 0; i < 3; i++) hred[i] = hs[i];
             st = ALT_ITER;
         }
-        BQ_PROF_END(tas_, 17);
-        BQ_PROF_BEGIN(tai_);
         if (st == ALT_ITER) {
             ++iterc;
             temp = gredsq * dredsq - dredg * dredg;
@@ -529,8 +536,6 @@ BQ_HD_NOINLINE void trsbox(BqRef B) {
             shs = 0.0; dhs = 0.0; dhd = 0.0;
             for (int i = 0; i < 3; i++)
                 if (xbdi.get(i) == 0.0) { shs += s[i] * hs[i]; dhs += d_[i] * hs[i]; dhd += d_[i] * hred[i]; }
-            BQ_PROF_END(tai_, 18);
-            BQ_PROF_BEGIN(tan_);
             redmax = 0.0; isav = 0; redsav = 0.0;
             iu = (int)(angbd * 17. + 3.1);
             BQ_PROF_COUNT(57, 1);
@@ -555,7 +560,6 @@ BQ_HD_NOINLINE void trsbox(BqRef B) {
                 }
             }
 #undef BQ_ANGLE_STEP
-            BQ_PROF_END(tan_, 19);
             if (isav == 0) { st = FINISH; continue; }
             if (isav < iu) {
                 temp = (rdnext - rdprev) / (redmax + redmax - rdprev - rdnext);
@@ -586,8 +590,8 @@ BQ_HD_NOINLINE void trsbox(BqRef B) {
             if (sdec > qred * .01) { st = ALT_ITER; continue; }
             st = FINISH;
         }
-        if (st == FINISH) break;
     }
+#undef BQ_ANY
     BQ_PROF_COUNT(59, 1);
     double dsq = 0.0;
     for (int i = 0; i < 3; i++) {

@@ -4,9 +4,10 @@ from hpmvs_amd import api, synth
 api.LIB_PATH='/tmp/libhpmvs_prof.so' if len(sys.argv)<2 else sys.argv[1]
 L=api.lib()
 dev=torch.device('cuda',0)
-scene=synth.make_scene(12,1920,1080,n_waves=24,device=dev)
+V,W_,H_,N_=(int(sys.argv[2]),int(sys.argv[3]),int(sys.argv[4]),int(sys.argv[5])) if len(sys.argv)>5 else (12,1920,1080,100000)
+scene=synth.make_scene(V,W_,H_,n_waves=24,device=dev)
 g=api.Scene(scene)
-seeds=synth.make_seeds(scene,100000,start_level=4,max_images=32)
+seeds=synth.make_seeds(scene,N_,start_level=4,max_images=32)
 b=api.Batch.from_seeds(seeds)
 api.optimize_batch(g,b)
 b=api.Batch.from_seeds(seeds)
