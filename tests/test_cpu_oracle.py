@@ -376,3 +376,135 @@ def test_selftest_problem_set_host_state_machine_vs_genuine_bobyqa():
         assert hashlib.sha256(r[4].tobytes()).hexdigest() == g["trace_sha256"], k
         assert resc[k] == g["rescue_calls"]
     assert sum(1 for c in resc if c) >= 10
+
+
+def test_sample_texture_and_inccs_match_an_independent_numpy_restatement(tiny_scene, tiny_seeds, oracle_scene):
+    """A second restatement of sampleTexture / Image::getColor / Patch2d::normalize / dot / setINCCs, written
+    from the reference source lines (PatchOptimizer.cpp:448-548, Image.h:89-115, Camera.h:44-63,
+    Camera.cpp:92-99, Patch2d.hpp:37-84) with numpy float32 scalars (one IEEE rounding per operation), must give
+    the C oracle's textures, pyramid levels, window geometry and INCC values bit for bit.  It cannot catch a
+    misreading shared by both (the reference itself does not build here: Eigen / glog absent), but it does catch
+    slips of either implementation."""
+    from oracle import oracle as orc
+    f32 = np.float32
+    o = orc.default_options()
+
+    def normalized(v):
+        # left-to-right squared norm: ((a0*a0 + a1*a1) + a2*a2) [+ a3*a3]
+        acc = f32(f32(v[0] * v[0]) + f32(v[1] * v[1]))
+        for t in v[2:]:
+            acc = f32(acc + f32(t * t))
+        if acc > 0:
+            n = np.sqrt(acc, dtype=f32)
+            return np.array([f32(t / n) for t in v], dtype=f32)
+        return np.array(v, dtype=f32)
+
+    def dot(a, b):
+        acc = f32(f32(a[0] * b[0]) + f32(a[1] * b[1]))
+        for x, y in zip(a[2:], b[2:]):
+            acc = f32(acc + f32(x * y))
+        return acc
+
+    def cross(a, b):
+        return np.array([f32(f32(a[1] * b[2]) - f32(a[2] * b[1])), f32(f32(a[2] * b[0]) - f32(a[0] * b[2])),
+                         f32(f32(a[0] * b[1]) - f32(a[1] * b[0]))], dtype=f32)
+
+    def project(cam, X, level):
+        P = np.array(cam.P[level], dtype=f32).reshape(3, 4)
+        r = [f32(f32(f32(f32(P[k, 0] * X[0]) + f32(P[k, 1] * X[1])) + f32(P[k, 2] * X[2])) + f32(P[k, 3] * X[3])) for k in range(3)]
+        if r[2] <= 0:
+            return np.array([-65535.0, -65535.0], dtype=f32)
+        lo, hi = f32(-2147483648.0), f32(2147483648.0)
+        return np.array([max(lo, min(hi, f32(r[0] / r[2]))), max(lo, min(hi, f32(r[1] / r[2])))], dtype=f32)
+
+    def get_color(img, x, y):
+        W = img.shape[1]
+        lx, ly = int(x), int(y)
+        dx1 = f32(x - f32(lx)); dx0 = f32(f32(1) - dx1)
+        dy1 = f32(y - f32(ly)); dy0 = f32(f32(1) - dy1)
+        f00, f01, f10, f11 = f32(dx0 * dy0), f32(dx0 * dy1), f32(dx1 * dy0), f32(dx1 * dy1)
+        flat = img.reshape(-1)
+        i0 = 3 * (ly * W + lx); i1 = i0 + 3 * W
+        out = []
+        for c in range(3):
+            v = f32(f32(0) + f32(f32(f32(flat[i0 + c]) * f00) + f32(f32(flat[i1 + c]) * f01)))
+            v = f32(v + f32(f32(f32(flat[i0 + 3 + c]) * f10) + f32(f32(flat[i1 + 3 + c]) * f11)))
+            out.append(v)
+        return out
+
+    def sample(view, cam, pc, scale, px, py, pz):
+        d = np.array([f32(cam.center[k] - pc[k]) for k in range(4)], dtype=f32)
+        if float(dot(normalized(d), pz)) < math.cos(float(o.MAX_ANGLE)):
+            return None
+        e = np.array([f32(pc[k] - cam.center[k]) for k in range(4)], dtype=f32)
+        fz = np.sqrt(dot(e, e), dtype=f32)
+        fsum = f32(f32(cam.K0[0]) + f32(cam.K0[4]))
+        lv = f32(math.log2(float(f32(scale * fsum)) / (2.0 * float(fz))))
+        lvl = max(0, min(o.MAXLEVEL - 1, int(math.copysign(math.floor(abs(float(lv)) + 0.5), float(lv)))))  # std::round
+        c = project(cam, pc, lvl)
+        dx = project(cam, np.array([f32(pc[k] + px[k]) for k in range(4)], dtype=f32), lvl) - c
+        dy = project(cam, np.array([f32(pc[k] + py[k]) for k in range(4)], dtype=f32), lvl) - c
+        h = f32(3.5)
+        cs = [[f32(f32(c[k] + s1 * f32(h * dx[k])) + s2 * f32(h * dy[k])) for k in range(2)] for s1, s2 in ((-1, -1), (1, -1), (-1, 1), (1, 1))]
+        img = view(lvl)
+        if min(q[0] for q in cs) < 3 or min(q[1] for q in cs) < 3 or max(q[0] for q in cs) >= img.shape[1] - 3 or max(q[1] for q in cs) >= img.shape[0] - 3:
+            return None
+        tex = []
+        l = [cs[0][0], cs[0][1]]
+        for yy in range(7):
+            cc = [l[0], l[1]]
+            l = [f32(l[0] + dy[0]), f32(l[1] + dy[1])]
+            for xx in range(7):
+                tex += get_color(img, cc[0], cc[1])
+                cc = [f32(cc[0] + dx[0]), f32(cc[1] + dx[1])]
+        ave = [f32(0)] * 3
+        for i in range(49):
+            for ch in range(3):
+                ave[ch] = f32(ave[ch] + tex[3 * i + ch])
+        ave = [f32(a / f32(49)) for a in ave]
+        a2 = f32(0)
+        for i in range(49):
+            ff = [f32(ave[ch] - tex[3 * i + ch]) for ch in range(3)]
+            a2 = f32(a2 + f32(f32(f32(ff[0] * ff[0]) + f32(ff[1] * ff[1])) + f32(ff[2] * ff[2])))
+        a2 = np.sqrt(f32(a2 / f32(147)), dtype=f32)
+        if a2 == 0:
+            a2 = f32(1)
+        tex = [f32(f32(tex[k] - ave[k % 3]) / a2) for k in range(147)]
+        return np.array(tex, dtype=f32), lvl, np.array([c[0], c[1], dx[0], dx[1], dy[0], dy[1]], dtype=f32)
+
+    P = orc.patches_from_seeds(tiny_seeds)
+    checked = 0
+    for k in range(len(P)):
+        p = P[k]
+        if p.n_images < 3 or checked >= 10:
+            continue
+        pc = np.array(p.center[:], dtype=f32); n = np.array(p.normal[:], dtype=f32); scale = f32(p.scale)
+        ref = oracle_scene.camera(p.images[0])
+        z = normalized(n[:3]); y = normalized(cross(z, np.array(ref.xaxis[:], dtype=f32))); x = normalized(cross(y, z))
+        x = np.array([f32(t * scale) for t in x], dtype=f32); y = np.array([f32(t * scale) for t in y], dtype=f32)
+        fs = dot(normalized(y), normalized(np.array(ref.yaxis[:], dtype=f32)))
+        y = np.array([f32(t * fs) for t in y], dtype=f32)
+        px = np.append(x, f32(0)); py = np.append(y, f32(0))
+        texs = []
+        for slot in range(p.n_images):
+            v = p.images[slot]
+            mine = sample(lambda lvl, v=v: oracle_scene.level(v, lvl), oracle_scene.camera(v), pc, scale, px, py, n)
+            ok, tex, lvl, geo = orc.sample_texture(oracle_scene, p, 0, slot)
+            assert ok == (mine is not None), (k, slot)
+            if ok:
+                assert lvl == mine[1] and np.array_equal(geo, mine[2]) and np.array_equal(tex, mine[0]), (k, slot)
+            texs.append(mine[0] if mine is not None else None)
+        inc = orc.inccs(oracle_scene, p, 0, 0)
+        for slot in range(1, p.n_images):
+            if texs[0] is None:
+                want = f32(2)
+            elif texs[slot] is None:
+                want = f32(2)
+            else:
+                acc = f32(0)
+                for a, b in zip(texs[0], texs[slot]):
+                    acc = f32(acc + f32(a * b))
+                want = f32(f32(1) - f32(acc / f32(147)))
+            assert inc[slot] == want, (k, slot, inc[slot], want)
+        checked += 1
+    assert checked >= 8
