@@ -294,3 +294,29 @@ def test_invalid_image_ids_are_rejected_not_dereferenced(tiny_seeds, oracle_scen
     P[0].images[0] = -1; P[1].images[1] = 1000; P[2].images[2] = 3
     orc.optimize_batch(oracle_scene, P, n_threads=1)
     assert [p.stage for p in P] == [101, 101, 101]
+
+
+def test_batch_order_does_not_matter(tiny_scene, tiny_seeds, gpu_scene):
+    """Patches are independent (PatchOptimizer.cpp:78-103): refining a permuted batch gives the permuted results,
+    byte for byte -- the property the host-side tile sort (distributed.tile_order) and the patch-index
+    sharding across GPUs rely on."""
+    from hpmvs_amd import api
+    from hpmvs_amd import distributed as dd
+    P0 = np.array([list(api.camera_from_nvm(v.f, v.q, v.c, v.width, v.height, tiny_scene.max_level).P0)
+                   for v in tiny_scene.views])
+    perm = dd.tile_order(tiny_seeds.center, tiny_seeds.images, tiny_seeds.n_images, P0, tile_px=64)
+    assert sorted(perm.tolist()) == list(range(len(perm))) and not np.array_equal(perm, np.arange(len(perm)))
+    a = api.Batch.from_seeds(tiny_seeds)
+    b = api.Batch.from_seeds(tiny_seeds, perm)
+    api.optimize_batch(gpu_scene, a)
+    api.optimize_batch(gpu_scene, b)
+    for f in ("ok", "center", "normal", "n_images", "images", "color", "fmin", "x", "nevals", "stage", "ngrabs"):
+        assert np.array_equal(getattr(a, f)[perm], getattr(b, f)), f
+    # and the shards of a 3-way split are the corresponding slices of the whole
+    n = a.n
+    for r in range(3):
+        lo, hi = dd.shard_range(n, r, 3)
+        s = api.Batch.from_seeds(tiny_seeds, np.arange(lo, hi))
+        api.optimize_batch(gpu_scene, s)
+        for f in ("ok", "center", "normal", "n_images", "images", "fmin", "nevals", "stage"):
+            assert np.array_equal(getattr(s, f), getattr(a, f)[lo:hi]), (r, f)
