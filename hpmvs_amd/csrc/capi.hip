@@ -63,14 +63,6 @@ struct hpmvs_scene {
     mutable bool slot_used[kQueueSlots] = {};
     mutable std::mutex mu;
     mutable bool timed = false;
-    // throughput kernel (kernel_stream.hip): one workspace, grown on demand; launches that use it are serialised
-    // by stream_done; stream_abort (pinned host) receives the kernel's give-up flag after every launch
-    mutable void* stream_ws = nullptr;
-    mutable size_t stream_ws_bytes = 0;
-    mutable hipEvent_t stream_done = nullptr;
-    mutable bool stream_used = false;
-    mutable int* stream_abort = nullptr;
-    mutable int last_kernel = 0;  // 0 = wavefront-bound kernel, 1 = stream kernel
     // Small host-pointer batches (the unchanged callers' optimize() = batch of 1, and what a combiner makes of
     // concurrent callers) are staged through persistent blocks: pinned host + device memory and a stream per
     // entry, one H2D and one D2H copy per call, no hipMalloc / hipFree
@@ -80,16 +72,6 @@ struct hpmvs_scene {
     mutable StageEntry stage[kStageEntries];
     mutable std::atomic<unsigned> stage_next{0};
 };
-
-// Which refinement kernel serves a batch: the wavefront-bound kernel (kernel_optimize.hip) unless HPMVS_KERNEL=stream
-// selects the stream kernel (kernel_stream.hip: patches queue per optimiser block in HBM).  The stream kernel is
-// bit-identical (tests run both) and runs the float64 blocks 2.2x cheaper per patch, but its state paging and
-// queue polling still cost more than that saves, so it is opt-in for now.
-static bool use_stream_kernel(int n) {
-    (void)n;
-    if (const char* e = getenv("HPMVS_KERNEL")) return !strcmp(e, "stream");
-    return false;
-}
 
 // Workspace hand-out (call with s->mu held).  Before a workspace is reused the launch that used it last must
 // have finished: more than kQueueSlots launches in flight against one scene (e.g. 256 OpenMP threads each
@@ -314,9 +296,6 @@ int hpmvs_scene_destroy(hpmvs_scene* s) {
         if (e.dev) hipFree(e.dev);
         if (e.host) hipHostFree(e.host);
     }
-    if (s->stream_ws) hipFree(s->stream_ws);
-    if (s->stream_done) hipEventDestroy(s->stream_done);
-    if (s->stream_abort) hipHostFree(s->stream_abort);
     for (int k = 0; k < kQueueSlots; k++) if (s->slot_done[k]) hipEventDestroy(s->slot_done[k]);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
@@ -475,45 +454,11 @@ DevScene dev_scene(const hpmvs_scene* s) {
 
 }  // namespace
 
-static int take_stream_abort(const hpmvs_scene* s) {
-    int code = 0;
-    if (s->stream_abort)
-        for (int k = 0; k < 16; k++) { if (s->stream_abort[k] && !code) code = s->stream_abort[k]; s->stream_abort[k] = 0; }
-    return code;
-}
-
 // One refinement launch on `st` (call with s->mu held): picks the kernel, hands out / zeroes its workspace and
 // brackets it with the scene's event pair.
 static int enqueue_refinement(const hpmvs_scene* s, const DevOptions& d, const DevBatch& batch, hipStream_t st) {
     int rc;
-    if (const int code = take_stream_abort(s))
-        return fail(HPMVS_ERR_HIP, "stream kernel of an earlier launch gave up (code " + std::to_string(code) + "): results of that launch are incomplete");
-    if (use_stream_kernel(batch.n)) {
-        const int n_recs = stream_records_for(batch.n);
-        const size_t need = stream_workspace_bytes(s->n_cus, n_recs);
-        if (s->stream_used) HIPCHK(hipEventSynchronize(s->stream_done));
-        if (need > s->stream_ws_bytes) {
-            if (s->stream_ws) HIPCHK(hipFree(s->stream_ws));
-            s->stream_ws = nullptr; s->stream_ws_bytes = 0;
-            HIPCHK(hipMalloc(&s->stream_ws, need));
-            s->stream_ws_bytes = need;
-        }
-        if (!s->stream_done) HIPCHK(hipEventCreateWithFlags(&s->stream_done, hipEventDisableTiming));
-        if (!s->stream_abort) {
-            HIPCHK(hipHostMalloc((void**)&s->stream_abort, sizeof(int) * 16));
-            memset(s->stream_abort, 0, sizeof(int) * 16);
-        }
-        HIPCHK(hipMemsetAsync(s->stream_ws, 0, stream_workspace_zero_bytes(n_recs), st));
-        HIPCHK(hipEventRecord(s->ev0, st));
-        launch_stream(dev_scene(s), d, batch, s->stream_ws, s->n_cus, n_recs, st);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(s->ev1, st));
-        HIPCHK(hipMemcpy2DAsync(s->stream_abort, sizeof(int), (char*)s->stream_ws + stream_abort_offset(), stream_shard_stride(),
-                                sizeof(int), (size_t)stream_shards(), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipEventRecord(s->stream_done, st));
-        s->stream_used = true;
-        s->last_kernel = 1;
-    } else {
+    {
         int32_t* q;
         int slot;
         if ((rc = acquire_workspace(s, &q, &slot))) return rc;
@@ -525,7 +470,6 @@ static int enqueue_refinement(const hpmvs_scene* s, const DevOptions& d, const D
         launch_optimize(dev_scene(s), d, batch, q, s->n_cus, st);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(s->ev1, st));
-        s->last_kernel = 0;
     }
     s->timed = true;
     return HPMVS_OK;
@@ -620,22 +564,6 @@ extern "C" int hpmvs_selftest_bobyqa(int device, int n, const int32_t* kind, con
     return HPMVS_OK;
 }
 
-extern "C" int hpmvs_debug_stream_stats(const hpmvs_scene* s, unsigned long long* out64) {  // SK_STATS builds only
-    if (!s || !s->stream_ws || !out64) return HPMVS_ERR_ARG;
-    for (int k = 0; k < 80; k++) out64[k] = 0;   // caller's buffer holds 80 counters
-    for (int sh = 0; sh < stream_shards(); sh++) {
-        unsigned long long t[80];
-        HIPCHK(hipMemcpy(t, (char*)s->stream_ws + sh * stream_shard_stride() + stream_stats_offset(), 80 * 8, hipMemcpyDeviceToHost));
-        for (int k = 0; k < 80; k++) out64[k] += t[k];
-    }
-    return HPMVS_OK;
-}
-// after a synchronised launch: did the stream kernel give up?
-static int check_stream_abort(const hpmvs_scene* s) {
-    if (const int code = take_stream_abort(s))
-        return fail(HPMVS_ERR_HIP, "stream kernel gave up (code " + std::to_string(code) + ")");
-    return HPMVS_OK;
-}
 
 
 // ---- pooled staging of a small host batch -------------------------------------------------------------------------
@@ -692,7 +620,6 @@ static int optimize_small_host_batch(const hpmvs_scene* s, const hpmvs_options* 
     }
     HIPCHK(hipMemcpyAsync(h, e.dev, L.total, hipMemcpyDeviceToHost, e.st));  // inputs come back refined in place
     HIPCHK(hipStreamSynchronize(e.st));
-    if ((rc = check_stream_abort(s))) return rc;
     memcpy(b->center, h + L.off_center, 16 * n); memcpy(b->normal, h + L.off_normal, 16 * n);
     memcpy(b->n_images, h + L.off_nimg, 4 * n); memcpy(b->images, h + L.off_images, 4 * n * m);
     memcpy(b->ok, h + L.off_ok, n);
@@ -729,7 +656,6 @@ int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_pat
         }
         if (!on_device) {
             HIPCHK(hipStreamSynchronize(st));
-            if ((rc = check_stream_abort(s))) return rc;
         }
     }
     if (!on_device) {
@@ -795,7 +721,6 @@ int hpmvs_init_patches_batch(const hpmvs_scene* s, const hpmvs_options* o, int s
         }
         if (!on_device) {
             HIPCHK(hipStreamSynchronize(st));
-            if ((rc = check_stream_abort(s))) return rc;
         }
     }
     if (!on_device) {
@@ -856,7 +781,6 @@ int hpmvs_expand_batch(const hpmvs_scene* s, const hpmvs_options* o, int mode, c
     }
     if (!on_device) {
         HIPCHK(hipStreamSynchronize(st));
-        if ((rc = check_stream_abort(s))) return rc;
         const DevBatch& D = sg.d;
         const size_t m = (size_t)out->n;
         if ((rc = stage_out(out->center, D.center, 4 * m))) return rc;

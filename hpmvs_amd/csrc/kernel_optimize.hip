@@ -10,10 +10,10 @@
 //     assureImageAngles / optimizePatch / ... / setRefImage) and the BOBYQA state machine
 //     (bobyqa3.hpp).  This is "phase A"; it ends when the lane needs photometric data.
 //   * Photometric work is done by the WHOLE WAVE for all posted requests at once ("phase B",
-//     wave_eval_packed in photometric.hpp): the (request, image) pairs become jobs, one lane each
-//     prepares its image, the usable jobs are packed into chunks of 8 staging slots, lanes 0..48
-//     fetch the 7x7 window texels, and the reference's sequential float32 sums are formed
-//     lane-per-image from LDS-staged values.  The results go back to the requesting lanes.
+//     wave_eval_rows in photometric.hpp): the (request, image) pairs become jobs, one lane each
+//     prepares its image; then nine 7-lane groups (one lane per window ROW) each serve one request,
+//     grab by grab, forming the reference's sequential float32 sums as DPP chains through the
+//     group's lanes.  No LDS, no barriers; the results go back to the requesting lanes.
 //
 //   Patches finish at different times (40-1000 evaluations); a finished lane immediately pulls the
 //   next patch from the queue, so slots stay busy until the queue drains.
@@ -28,20 +28,13 @@
 // optimiser state of the kP patches a wavefront owns lives in LDS (see bobyqa3.hpp)
 #include "prof.h"
 #define BQ_STATE_LDS 1
-#ifndef HPMVS_EVAL_JOBS
-#define HPMVS_EVAL_PACKED 1  // measured on C1: packed evaluator 38.2 ms, lane-per-grab evaluator 46.8 ms (13 slots) here
-#endif
 #ifndef BQ_P
-#ifdef HPMVS_EVAL_PACKED
-#define BQ_P 10
-#else
 #define BQ_P 13
 #endif
-#endif
-// Single-wavefront workgroups: 10 x 1468 B of optimiser state + 5.4 KB of texel staging = 20.1 KB of LDS, 8 per
-// CU.  (The image lists, touched a dozen times per patch, live in a global-memory workspace, not in LDS.
-// Multi-wavefront workgroups -- sharing the staging buffers under a lock, or scheduling the BOBYQA blocks of all
-// their slots cooperatively -- were measured 5-25 % slower, DESIGN.md section 6, and are gone.)
+// Single-wavefront workgroups: 13 x 1468 B of optimiser state = 19.1 KB of LDS, 8 per CU; the photometric
+// evaluator (wave_eval_rows) needs no LDS.  (The image lists, touched a dozen times per patch, live in a
+// global-memory workspace.  Multi-wavefront workgroups -- sharing staging buffers under a lock, or scheduling the
+// BOBYQA blocks of all their slots cooperatively -- were measured 5-25 % slower in round 1)
 #define BQ_SLOTS BQ_P
 #include "bobyqa3.hpp"
 #include "launch.h"
@@ -62,9 +55,6 @@ constexpr size_t kCounterBytes = 1024;  // head of the launch workspace: work-qu
 #define HPMVS_WAVES_PER_EU 2
 #endif
 __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
-#ifdef HPMVS_EVAL_PACKED
-    __shared__ EvalLds evlds;  // texel staging of the packed (49-lanes-per-grab) evaluator
-#endif
     const int lane = lane_id();
     // this wavefront's image-list rows in the launch workspace (behind the counter block)
     uint16_t* lists = (uint16_t*)((char*)queue + kCounterBytes) + (size_t)blockIdx.x * kP * kRow;
@@ -239,11 +229,7 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
             for (int k = 0; k < 3; k++) { q.c[k] = c[k]; q.zax[k] = (op == OP_OBJ) ? az[k] : n[k]; q.px[k] = ax[k]; q.py[k] = ay[k]; }
             PackedRes r;
             r.obj = 2.0; r.keep = 0ull; r.incc_sum = 0.0f; r.ngrabs = 0;
-#ifdef HPMVS_EVAL_PACKED
-            wave_eval_packed<false>(sc, o, row, pending, q, r, evlds);
-#else
-            r = wave_eval_jobs<false>(sc, o, row, pending, q, r);  // one lane per (request, image): no LDS staging
-#endif
+            wave_eval_rows<false>(sc, o, (const uint16_t*)row, pending, q, r, nullptr);
             if (op != OP_NONE) {
                 res_f = r.obj;
                 res_mask = r.keep;
@@ -274,11 +260,8 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
 static int max_workgroups(int n_cus) {
     // workgroups per CU: LDS (optimiser state per wavefront, one staging buffer per workgroup) and the
     // waves-per-SIMD limit
-#ifdef HPMVS_EVAL_PACKED
-    const int lds_per_wg = (int)(sizeof(double) * BQ_ND * kP + sizeof(int) * BQ_NI * kP) + (int)sizeof(EvalLds) + 16;
-#else
-    const int lds_per_wg = (int)(sizeof(double) * BQ_ND * kP + sizeof(int) * BQ_NI * kP) + 16;
-#endif
+    int lds_per_wg = (int)(sizeof(double) * BQ_ND * kP + sizeof(int) * BQ_NI * kP) + 16;
+    lds_per_wg = (lds_per_wg + 511) & ~511;  // LDS allocation granule
     int per_cu = (160 * 1024) / lds_per_wg;
     if (per_cu > 4 * HPMVS_WAVES_PER_EU) per_cu = 4 * HPMVS_WAVES_PER_EU;
     return n_cus * per_cu;

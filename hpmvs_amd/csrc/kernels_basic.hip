@@ -50,44 +50,54 @@ void launch_half_resize(const uint8_t* src, int w, int h, uint8_t* dst, hipStrea
 }
 
 // ------------------------------------------------------------------------------------------
-// objective_fn for a batch: one wavefront per patch, grid-stride.
-__global__ void __launch_bounds__(256) objective_kernel(DevScene sc, DevOptions o, DevBatch b,
-                                                        const double* __restrict__ xs, double* __restrict__ f_out,
-                                                        int32_t* __restrict__ ngrabs_out) {
-    __shared__ EvalLds lds[4];
-    EvalLds& L = lds[threadIdx.x >> 6];
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int p = wave; p < b.n; p += nwaves) {
-        const int nimg = b.n_images[p];
-        const int32_t* list = b.images + (size_t)p * b.max_images;
-        double f = 2.0;
-        int ngr = 0;
-        // image ids come straight from the caller: a list that is longer than its row, or an id outside the scene,
-        // is answered with the plateau value 2.0 (what objective_fn returns when the reference grab fails), never
-        // dereferenced
-        bool ids_ok = nimg > 0 && nimg <= kMaxImages && nimg <= b.max_images;
-        if (ids_ok) {
-            const int l = lane_id();
-            const int id = (l < nimg) ? list[l] : 0;
-            ids_ok = !__any(id < 0 || id >= sc.n_views);
+// objective_fn / setINCCs for a batch, through the product evaluator (wave_eval_rows): a wavefront takes kGroups
+// patches at a time, lane r < kGroups posts the request of patch base + r -- the same request / job / group
+// machinery the refinement kernel drives, so the photometric parity tests exercise the product code.
+
+// image ids come straight from the caller: a list that is longer than its row, or an id outside the scene, is
+// answered with the plateau value (2.0), never dereferenced
+__device__ __forceinline__ bool list_ok(const DevScene& sc, const DevBatch& b, int p, int nimg) {
+    if (!(nimg > 0 && nimg <= kMaxImages && nimg <= b.max_images)) return false;
+    const int32_t* list = b.images + (size_t)p * b.max_images;
+    bool bad = false;
+    for (int k = 0; k < nimg; k++) { const int id = list[k]; bad |= (id < 0 || id >= sc.n_views); }
+    return !bad;
+}
+
+__global__ void __launch_bounds__(64) objective_kernel(DevScene sc, DevOptions o, DevBatch b,
+                                                       const double* __restrict__ xs, double* __restrict__ f_out,
+                                                       int32_t* __restrict__ ngrabs_out) {
+    const int lane = lane_id();
+    for (int base = blockIdx.x * kGroups; base < b.n; base += gridDim.x * kGroups) {
+        const int p = base + lane;
+        const bool mine = lane < kGroups && p < b.n;
+        PackedReq q;
+        q.obj_mode = 1; q.ref = 0; q.robust = 0; q.nimg = 0; q.thr = 0.0f; q.scale = 1.0f;
+        for (int k = 0; k < 3; k++) { q.c[k] = 0.0f; q.zax[k] = 0.0f; q.px[k] = 0.0f; q.py[k] = 0.0f; }
+        const int32_t* list = b.images;
+        bool ok = false;
+        if (mine) {
+            const int nimg = b.n_images[p];
+            ok = list_ok(sc, b, p, nimg);
+            if (ok) {
+                list = b.images + (size_t)p * b.max_images;
+                const float c0[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
+                OptFields F;
+                set_optimization_fields(sc.views[list[0]], c0, F);
+                const double x[3] = {xs[3 * p], xs[3 * p + 1], xs[3 * p + 2]};
+                float c[3], n[3], px[3], py[3], pz[3];
+                set_center_norm(F, o, x, c, n);
+                calc_patch_axes(sc.views[list[0]].xaxis, sc.views[list[0]].yaxis, n, b.scale[p], px, py, pz);
+                q.nimg = nimg; q.scale = b.scale[p];
+                for (int k = 0; k < 3; k++) { q.c[k] = c[k]; q.zax[k] = pz[k]; q.px[k] = px[k]; q.py[k] = py[k]; }
+            }
         }
-        if (ids_ok) {
-            const float c0[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
-            OptFields F;
-            set_optimization_fields(sc.views[list[0]], c0, F);
-            const double x[3] = {xs[3 * p], xs[3 * p + 1], xs[3 * p + 2]};
-            float c[3], n[3];
-            set_center_norm(F, o, x, c, n);
-            float px[3], py[3], pz[3];
-            calc_patch_axes(sc.views[list[0]].xaxis, sc.views[list[0]].yaxis, n, b.scale[p], px, py, pz);
-            const EvalResult r = wave_eval_exact(sc, o, list, nimg, 0, c, n, b.scale[p], px, py, pz, 1, 0, L);
-            f = r.obj;
-            ngr = r.ngrabs;
-        }
-        if (lane_id() == 0) {
-            f_out[p] = f;
-            if (ngrabs_out) ngrabs_out[p] = ngr;
+        PackedRes r;
+        r.obj = 2.0; r.keep = 0ull; r.incc_sum = 0.0f; r.ngrabs = 0;
+        wave_eval_rows<false>(sc, o, list, __ballot(mine && ok), q, r, nullptr);
+        if (mine) {
+            f_out[p] = ok ? r.obj : 2.0;
+            if (ngrabs_out) ngrabs_out[p] = ok ? r.ngrabs : 0;
         }
     }
 }
@@ -95,49 +105,61 @@ __global__ void __launch_bounds__(256) objective_kernel(DevScene sc, DevOptions 
 void launch_objective(const DevScene& sc, const DevOptions& o, const DevBatch& b, const double* xs, double* f_out,
                       int32_t* ngrabs_out, hipStream_t st) {
     if (b.n <= 0) return;
-    const int waves_per_block = 4;
-    int blocks = (b.n + waves_per_block - 1) / waves_per_block;
+    int blocks = (b.n + kGroups - 1) / kGroups;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(objective_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, st, sc, o, b, xs, f_out,
-                       ngrabs_out);
+    hipLaunchKernelGGL(objective_kernel, dim3(blocks), dim3(64), 0, st, sc, o, b, xs, f_out, ngrabs_out);
 }
 
-// setINCCs(ref_idx, robust) for a batch
-__global__ void __launch_bounds__(256) inccs_kernel(DevScene sc, DevOptions o, DevBatch b, int ref_idx, int robust,
-                                                    float* __restrict__ out) {
-    __shared__ EvalLds lds[4];
-    EvalLds& L = lds[threadIdx.x >> 6];
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int p = wave; p < b.n; p += nwaves) {
-        const int nimg = b.n_images[p];
-        const int32_t* list = b.images + (size_t)p * b.max_images;
-        const int lane = lane_id();
-        float mine = 2.0f;
-        bool ids_ok = nimg > 0 && nimg <= kMaxImages && nimg <= b.max_images && ref_idx >= 0 && ref_idx < nimg;
-        if (ids_ok) {  // same validation as objective_kernel: bad lists give inccs = 2.0 for every image
-            const int id = (lane < nimg) ? list[lane] : 0;
-            ids_ok = !__any(id < 0 || id >= sc.n_views);
+// setINCCs(ref_idx, robust) for a batch: out[p][k] = inccs[k] for k < n_images, 0 beyond
+__global__ void __launch_bounds__(64) inccs_kernel(DevScene sc, DevOptions o, DevBatch b, int ref_idx, int robust,
+                                                   float* __restrict__ out) {
+    const int lane = lane_id();
+    for (int base = blockIdx.x * kGroups; base < b.n; base += gridDim.x * kGroups) {
+        const int p = base + lane;
+        const bool mine = lane < kGroups && p < b.n;
+        PackedReq q;
+        q.obj_mode = 0; q.ref = ref_idx; q.robust = robust; q.nimg = 0; q.thr = 0.0f; q.scale = 1.0f;
+        for (int k = 0; k < 3; k++) { q.c[k] = 0.0f; q.zax[k] = 0.0f; q.px[k] = 0.0f; q.py[k] = 0.0f; }
+        const int32_t* list = b.images;
+        float* row = out;
+        int nimg = 0;
+        bool ok = false;
+        if (mine) {
+            nimg = b.n_images[p];
+            row = out + (size_t)p * b.max_images;
+            // same validation as objective_kernel: bad lists give inccs = 2.0 for every image
+            ok = list_ok(sc, b, p, nimg) && ref_idx >= 0 && ref_idx < nimg;
+            if (ok) {
+                list = b.images + (size_t)p * b.max_images;
+                const float n[3] = {b.normal[4 * p], b.normal[4 * p + 1], b.normal[4 * p + 2]};
+                float px[3], py[3], pz[3];
+                calc_patch_axes(sc.views[list[ref_idx]].xaxis, sc.views[list[ref_idx]].yaxis, n, b.scale[p], px, py, pz);
+                q.nimg = nimg; q.scale = b.scale[p];
+                for (int k = 0; k < 3; k++) { q.c[k] = b.center[4 * p + k]; q.zax[k] = n[k]; q.px[k] = px[k]; q.py[k] = py[k]; }
+            }
         }
-        if (ids_ok) {
-            const float c[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
-            const float n[3] = {b.normal[4 * p], b.normal[4 * p + 1], b.normal[4 * p + 2]};
-            float px[3], py[3], pz[3];
-            calc_patch_axes(sc.views[list[ref_idx]].xaxis, sc.views[list[ref_idx]].yaxis, n, b.scale[p], px, py, pz);
-            const EvalResult r = wave_eval_exact(sc, o, list, nimg, ref_idx, c, n, b.scale[p], px, py, pz, 0, robust, L);
-            mine = r.incc_lane;
+        PackedRes r;
+        r.obj = 2.0; r.keep = 0ull; r.incc_sum = 0.0f; r.ngrabs = 0;
+        wave_eval_rows<true>(sc, o, list, __ballot(mine && ok), q, r, row);
+        if (mine) {
+            // the evaluator stored the grabbed images' values and the reference image's 0 (r.keep = grabbed mask);
+            // the rest is 2.0
+            const bool refok = ok && r.ngrabs > 0;
+            for (int k = 0; k < b.max_images; k++) {
+                const bool grabbed = refok && ((r.keep >> k) & 1ull);
+                if (k >= nimg) row[k] = 0.0f;
+                else if (!grabbed) row[k] = 2.0f;
+            }
         }
-        if (lane < b.max_images) out[(size_t)p * b.max_images + lane] = (lane < nimg) ? mine : 0.0f;
     }
 }
 
 void launch_inccs(const DevScene& sc, const DevOptions& o, const DevBatch& b, int ref_idx, int robust, float* out,
                   hipStream_t st) {
     if (b.n <= 0) return;
-    const int waves_per_block = 4;
-    int blocks = (b.n + waves_per_block - 1) / waves_per_block;
+    int blocks = (b.n + kGroups - 1) / kGroups;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(inccs_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, st, sc, o, b, ref_idx, robust, out);
+    hipLaunchKernelGGL(inccs_kernel, dim3(blocks), dim3(64), 0, st, sc, o, b, ref_idx, robust, out);
 }
 
 // ------------------------------------------------------------------------------------------

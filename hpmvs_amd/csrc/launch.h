@@ -34,18 +34,5 @@ void launch_unpack_records(const void* records, int n, const DevBatch& b, hipStr
 void launch_selftest(int n, const int* kind, const double* params, const double* x0, const double* lb, const double* ub,
                      int maxeval, double* xfinal, double* minf, int* rc, int* nevals, int* rescues, double* trace,
                      int trace_cap, hipStream_t st);
-// Throughput form (kernel_stream.hip): patches stream through per-block queues; `n_recs` in-flight patch records
-// per shard (stream_records_for(n)).
-// The first stream_workspace_zero_bytes(n_recs) bytes of the workspace must be zero when the kernel starts; after
-// the launch the int at byte offset stream_abort_offset() is non-zero iff the kernel gave up (internal error).
-int stream_records_for(int n);
-size_t stream_workspace_bytes(int n_cus, int n_recs);
-size_t stream_workspace_zero_bytes(int n_recs);
-size_t stream_abort_offset();
-size_t stream_stats_offset();  // SK_STATS builds: 64 u64 counters
-size_t stream_shard_stride();  // the control blocks of the shards are this many bytes apart
-int stream_shards();
-void launch_stream(const DevScene& sc, const DevOptions& o, const DevBatch& b, void* workspace, int n_cus, int n_recs,
-                   hipStream_t st);
 
 }  // namespace hpmvs

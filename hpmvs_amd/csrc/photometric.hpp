@@ -192,285 +192,33 @@ __device__ __forceinline__ float div_by(float a, double inv_w) { return (float)(
 
 __device__ __forceinline__ float robustincc(float rhs) { return rhs / (1 + 3 * rhs); }  // PatchOptimizer.h:92-94
 
-struct EvalResult {
-    double obj;       // OBJ: objective_fn value
-    float incc_lane;  // INCC: lane v holds inccs[v]
-    float incc_sum;   // INCC: sequential float sum of inccs (std::accumulate, PatchOptimizer.cpp:165)
-    int ngrabs;       // grabs that passed the gates
-};
-
 // ------------------------------------------------------------------------------------------
-// EXACT-ORDER evaluator.
+// ROW-LANE exact-order evaluator: every photometric request a wave has pending, 9 grabs per pass, no LDS.
 //
-// BOBYQA on this objective amplifies a 1e-9 relative perturbation of f into a different basin for
-// 7-8 % of patches (tests/sensitivity_probe.py), so "close" objective values are not good enough
-// for parity: the objective has to be the reference's float32 arithmetic bit for bit, including
-// the SEQUENTIAL summation order of Patch2d::normalize / dot (Patch2d.hpp:37-84) and the
-// incremental sample stepping of sampleTexture (PatchOptimizer.cpp:511-526).  A wave reduction
-// cannot do that, but the sums of DIFFERENT images are independent, so:
-//   1. lanes 0..48 fetch the raw texels of up to kChunk images (all tap loads of a chunk are issued
-//      before any is consumed) and stage them in LDS in the reference's data[(y*7+x)*3+c] layout;
-//   2. lane (m*3+c) forms the channel mean of image m sequentially over the 49 pixels;
-//   3. lane m forms the variance sum sequentially; 4. lanes 0..48 normalise in place;
-//   5. lane m forms the 147-term dot product with the reference texture sequentially.
-// Built with -ffp-contract=off, every float operation is the one the CPU executes.
-#ifndef HPMVS_CHUNK
-#define HPMVS_CHUNK 7
-#endif
-constexpr int kChunk = HPMVS_CHUNK;  // images per chunk besides the reference texture
-constexpr int kPlane = 52;           // floats per staged channel plane (49 + 3: 16-byte aligned planes)
-constexpr int kTexStride = 164;      // floats per staging slot (16-byte multiple; 164 mod 64 = 36 spreads the per-slot float4 reads over distinct LDS banks): 3 planes of raw texels, later reused for the
-                                     // 49 squared deviations and then the 147 products ref[k]*img[k]
-struct alignas(16) EvalLds {
-    float buf[(kChunk + 1) * kTexStride];  // slot 0: reference image, slots 1..kChunk: chunk members
-    float ave[(kChunk + 1) * 4];           // per slot: channel means, then sqrt(variance)
-    double inv[kChunk + 1];                // per slot: 1 / sqrt(variance) in float64 (see div_by)
-};
-
-__device__ __forceinline__ void wave_lds_sync() {
-    // single wavefront: DS operations execute in issue order; this only stops the compiler from
-    // moving LDS accesses across the hand-over between lanes
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// sequential float sum of N contiguous LDS floats (16-byte aligned, padded to a multiple of 4) by one
-// lane: float4 reads, adds strictly in index order
-template <int N>
-__device__ __forceinline__ float seq_sum(const float* p) {
-    const float4* p4 = reinterpret_cast<const float4*>(p);
-    float a = 0.0f;
-    constexpr int Q = N / 4;
-#pragma unroll 6
-    for (int q = 0; q < Q; q++) {
-        const float4 u = p4[q];
-        a += u.x; a += u.y; a += u.z; a += u.w;
-    }
-    if (N % 4) {
-        const float4 u = p4[Q];
-        if (N % 4 >= 1) a += u.x;
-        if (N % 4 >= 2) a += u.y;
-        if (N % 4 >= 3) a += u.z;
-    }
-    return a;
-}
-
-struct Taps { uint2 a, b; float f00, f01, f10, f11; };
-
-// address + weights of the texel this lane samples (sampleTexture's stepping: l += dy per row,
-// c += dx per column, PatchOptimizer.cpp:511-526), and the two tap loads
-__device__ __forceinline__ Taps issue_taps(float tlx, float tly, float dxx, float dxy, float dyx, float dyy,
-                                           const uint8_t* pix, int W, int ixx, int iyy) {
-    // x += step taken `iyy` / `ixx` times: fma(m, step, x) with m in {0, 1} is the same single rounding
-    // as x + step (m*step is exact) and leaves x untouched for m = 0
-    float x = tlx, y = tly;
-#pragma unroll
-    for (int k = 0; k < kTex - 1; k++) { const float m = (k < iyy) ? 1.0f : 0.0f; x = __builtin_fmaf(m, dyx, x); y = __builtin_fmaf(m, dyy, y); }
-#pragma unroll
-    for (int k = 0; k < kTex - 1; k++) { const float m = (k < ixx) ? 1.0f : 0.0f; x = __builtin_fmaf(m, dxx, x); y = __builtin_fmaf(m, dxy, y); }
-    const int lx = (int)x, ly = (int)y;
-    const uint8_t* p0 = pix + 3 * (ly * W + lx);
-    Taps t;
-    t.a = load8(p0);
-    t.b = load8(p0 + 3 * W);
-    const float dx1 = x - (float)lx, dx0 = 1.0f - dx1;
-    const float dy1 = y - (float)ly, dy0 = 1.0f - dy1;
-    t.f00 = dx0 * dy0; t.f01 = dx0 * dy1; t.f10 = dx1 * dy0; t.f11 = dx1 * dy1;
-    return t;
-}
-
-// Image::getColor (Image.h:104-113) in its evaluation order
-__device__ __forceinline__ void texel(const Taps& t, float& r, float& g, float& b) {
-    r = 0.0f; g = 0.0f; b = 0.0f;
-    r += (float)(t.a.x & 0xff) * t.f00 + (float)(t.b.x & 0xff) * t.f01;
-    g += (float)((t.a.x >> 8) & 0xff) * t.f00 + (float)((t.b.x >> 8) & 0xff) * t.f01;
-    b += (float)((t.a.x >> 16) & 0xff) * t.f00 + (float)((t.b.x >> 16) & 0xff) * t.f01;
-    r += (float)(t.a.x >> 24) * t.f10 + (float)(t.b.x >> 24) * t.f11;
-    g += (float)(t.a.y & 0xff) * t.f10 + (float)(t.b.y & 0xff) * t.f11;
-    b += (float)((t.a.y >> 8) & 0xff) * t.f10 + (float)((t.b.y >> 8) & 0xff) * t.f11;
-}
-
-// px, py, pz: calculatePatchAxis output for the reference image's camera (wave-uniform, computed by
-// the requesting lane in phase A / by the caller).
-template <typename ListT>
-__device__ __forceinline__ EvalResult wave_eval_exact(const DevScene& sc, const DevOptions& o, const ListT* list,
-                                                      int nimg, int ref_slot, const float* c, const float* n,
-                                                      float scale, const float* px, const float* py, const float* pz,
-                                                      int obj_mode, int robust, EvalLds& L) {
-    EvalResult res;
-    res.obj = 2.0; res.incc_lane = 2.0f; res.incc_sum = 0.0f; res.ngrabs = 0;
-    const int lane = lane_id();
-    const bool active = lane < kTexPix;
-    const int sl = active ? lane : kTexPix - 1;
-    const int iyy = sl / kTex, ixx = sl % kTex;
-    PH_T(t1);
-    float zax[3];
-    for (int k = 0; k < 3; k++) zax[k] = obj_mode ? pz[k] : n[k];
-
-    Prep P;
-    P.ok = 0; P.tlx = P.tly = P.dxx = P.dxy = P.dyx = P.dyy = 0.0f; P.pix = nullptr; P.W = 0;
-    if (lane < nimg) P = prep_image(sc.views[(int)list[lane]], o, c, scale, px, py, zax);
-    PH_T(t2);
-    PH_ADD(t1, t2, 13);
-
-    const unsigned long long okmask = __ballot(P.ok != 0);
-    if (!((okmask >> ref_slot) & 1ull)) {
-        if (!obj_mode) {
-            float s = 0.0f;
-            for (int k = 0; k < nimg; k++) s += 2.0f;
-            res.incc_sum = s;
-        }
-        return res;
-    }
-    unsigned long long todo = okmask & ~(1ull << ref_slot);
-    int ngr = 1, nok = 0;
-    double val = 0.0;
-    float mine = (lane == ref_slot) ? 0.0f : 2.0f;
-    float refn0 = 0.0f, refn1 = 0.0f, refn2 = 0.0f;  // this lane's normalised reference texel
-    bool first = true;
-    while (first || todo) {
-        // ---- members of this chunk: the lowest set bits of `todo`, ascending image index
-        unsigned long long chunk = 0ull, t = todo;
-        for (int k = 0; k < kChunk && t; k++) { chunk |= t & (~t + 1ull); t &= t - 1ull; }
-        todo = t;
-        const int nm = __popcll(chunk);
-        // lane s in 1..nm knows which image it stands for; slot 0 is the reference image
-        int member = ref_slot;
-        if (lane >= 1 && lane <= nm) {
-            unsigned long long u = chunk;
-            for (int j = 1; j < lane; j++) u &= u - 1ull;
-            member = __ffsll((long long)u) - 1;
-        }
-        const int s0 = first ? 0 : 1;
-        PH_T(t3);
-        // ---- 1. fetch: issue every tap load of the chunk, then convert; stage the raw texels as
-        //         three channel planes per slot (plane c at buf[c*kPlane + pixel])
-        Taps taps[kChunk + 1];
-        float rr[kChunk + 1], gg[kChunk + 1], bb[kChunk + 1];
-#pragma unroll
-        for (int s = 0; s <= kChunk; s++) {
-            if (s >= s0 && s <= nm) {
-                const int v = bcast_i(member, s);
-                taps[s] = issue_taps(bcast_f(P.tlx, v), bcast_f(P.tly, v), bcast_f(P.dxx, v), bcast_f(P.dxy, v),
-                                     bcast_f(P.dyx, v), bcast_f(P.dyy, v), bcast_p(P.pix, v), bcast_i(P.W, v), ixx, iyy);
-            }
-        }
-#pragma unroll
-        for (int s = 0; s <= kChunk; s++) {
-            rr[s] = gg[s] = bb[s] = 0.0f;
-            if (s >= s0 && s <= nm) {
-                texel(taps[s], rr[s], gg[s], bb[s]);
-                if (active) {
-                    float* bp = &L.buf[s * kTexStride];
-                    bp[lane] = rr[s]; bp[kPlane + lane] = gg[s]; bp[2 * kPlane + lane] = bb[s];
-                }
-            }
-        }
-        wave_lds_sync();
-        PH_T(t4);
-        PH_ADD(t3, t4, 14);
-
-        // ---- 2. channel means (Patch2d.hpp:51-58): lane m*3+c adds the 49 texels of plane c of slot m in order
-        {
-            const int m = lane / 3, ch = lane - 3 * m;
-            if (m >= s0 && m <= nm) L.ave[m * 4 + ch] = div_by(seq_sum<49>(&L.buf[m * kTexStride + ch * kPlane]), 1.0 / 49.0);
-        }
-        wave_lds_sync();
-        // ---- 3. squared deviations per pixel (Patch2d.hpp:62-69), computed by the pixel lanes ...
-#pragma unroll
-        for (int s = 0; s <= kChunk; s++) {
-            if (s >= s0 && s <= nm && active) {
-                const float4 av = *reinterpret_cast<const float4*>(&L.ave[s * 4]);
-                const float f0 = av.x - rr[s], f1 = av.y - gg[s], f2 = av.z - bb[s];
-                L.buf[s * kTexStride + lane] = f0 * f0 + f1 * f1 + f2 * f2;
-            }
-        }
-        wave_lds_sync();
-        // ---- ... and summed in pixel order by lane m
-        if (lane >= s0 && lane <= nm) {
-            float v2 = sqrtf(div_by(seq_sum<49>(&L.buf[lane * kTexStride]), 1.0 / 147.0));
-            if (v2 == 0.0f) v2 = 1.0f;
-            L.inv[lane] = recip64(v2);
-        }
-        wave_lds_sync();
-        PH_T(t5);
-        PH_ADD(t4, t5, 15);
-
-        // ---- 4. normalise (Patch2d.hpp:75-83) in registers; products with the reference texture
-        //         (Patch2d.hpp:41) staged in the reference's element order (pixel*3 + channel)
-#pragma unroll
-        for (int s = 0; s <= kChunk; s++) {
-            if (s >= s0 && s <= nm) {
-                const float4 av = *reinterpret_cast<const float4*>(&L.ave[s * 4]);
-                float r = rr[s], g = gg[s], b = bb[s];
-                const double iv = L.inv[s];
-                r -= av.x; r = div_by(r, iv);
-                g -= av.y; g = div_by(g, iv);
-                b -= av.z; b = div_by(b, iv);
-                if (s == 0) { refn0 = r; refn1 = g; refn2 = b; }
-                else if (active) {
-                    float* bp = &L.buf[s * kTexStride + 3 * lane];
-                    bp[0] = refn0 * r; bp[1] = refn1 * g; bp[2] = refn2 * b;
-                }
-            }
-        }
-        wave_lds_sync();
-        PH_T(t6);
-        PH_ADD(t5, t6, 20);
-
-        // ---- 5. NCC: lane m adds the 147 products in order (Patch2d.hpp:37-44)
-        float raw = 2.0f;
-        if (lane >= 1 && lane <= nm) raw = 1.0f - div_by(seq_sum<147>(&L.buf[lane * kTexStride]), 1.0 / 147.0);
-        PH_T(t7);
-        PH_ADD(t6, t7, 21);
-
-        // ---- deliver in ascending image order
-        for (int s = 1; s <= nm; s++) {
-            const int v = bcast_i(member, s);
-            const float e = bcast_f(raw, s);
-            ngr++;
-            if (obj_mode) {
-                val += (double)robustincc(e);
-                nok++;
-            } else if (lane == v) {
-                mine = robust ? robustincc(e) : e;
-            }
-        }
-        wave_lds_sync();
-        first = false;
-        PH_T(t8);
-        PH_ADD(t7, t8, 22);
-    }
-    res.ngrabs = ngr;
-    if (obj_mode) {
-        res.obj = (nok < o.MIN_IMAGES_PER_PATCH - 1) ? 2.0 : val / (double)nok;
-    } else {
-        res.incc_lane = mine;
-        float s = 0.0f;
-        for (int k = 0; k < nimg; k++) s += bcast_f(mine, k);
-        res.incc_sum = s;
-    }
-    return res;
-}
-
-// ------------------------------------------------------------------------------------------
-// PACKED exact-order evaluator: every request a wave has pending, in one pass.
+// BOBYQA on this objective amplifies a 1e-9 relative perturbation of f into a different basin for 7-8 % of
+// patches (tests/sensitivity_probe.py), so the objective has to be the reference's float32 arithmetic bit for
+// bit, including the SEQUENTIAL summation order of Patch2d::normalize / dot (Patch2d.hpp:37-84) and the
+// incremental sample stepping of sampleTexture (PatchOptimizer.cpp:511-526).  A wave reduction cannot do
+// that.  Rounds 1-2 gave a grab 49 lanes (one per texel) and handed the sequential sums to single lanes through
+// an LDS staging buffer: 5 barriers, ~280 issued instructions per grab, 8 of 64 lanes busy during the sums, and
+// 5.4 KB of LDS per wavefront that the optimiser state could not use.  Here a grab gets SEVEN lanes, one per
+// ROW of the 7x7 window (lane = 7*group + yy, nine groups per wavefront):
+//   * lane yy steps to its row start with the reference's incremental adds and samples its 7 texels itself
+//     (14 independent 8-byte tap loads in flight per lane, all of them before the first conversion);
+//   * a sequential sum over the window in pixel order is a chain through the 7 lanes of the group: lane yy adds
+//     its 7 (or 21) terms in order onto the value lane yy-1 hands over (v_add_f32_dpp wave_shr:1: the hand-over
+//     is fused into the first add); seven stages, every lane executes every stage, the stage's own lane keeps
+//     the result.  Three channel means run as three independent chains (ILP), then one chain for the squared
+//     deviations and one 147-term chain for the dot product -- exactly Patch2d.hpp's operation order;
+//   * a group serves ONE request from start to end: the reference image first (its normalised texels stay in
+//     the group's registers), then the other usable images in ascending index, so the per-request
+//     accumulations (objective_fn's float64 sum, setINCCs' values) happen in the reference's loop order inside
+//     the group and no texture ever crosses lanes.  Idle groups pull the next pending request.
+// Per grab ~120 issued instructions, no LDS, no barrier; the optimiser state gets the whole 160 KB.
 //
-// wave_eval_exact serves ONE request and leaves most lanes idle: a typical objective_fn request has
-// 3-4 usable images, i.e. 3-4 of the 8 staging slots, 3-4 lanes on the sequential sums, 3-4 lanes of
-// prep_image.  All of that is latency, not throughput (profiles/r02: 17 k cycles per request with
-// the wave alone on its CU).  Here the (request, image) pairs of ALL pending requests become "jobs":
-//   1. one lane per job runs prep_image (request data fetched from the requesting lane with
-//      ds_bpermute);
-//   2. the usable jobs are laid out as one sequence -- per request: reference image first, then the
-//      other images in ascending index -- and cut into chunks of 8 staging slots, regardless of
-//      request boundaries (the normalised reference texel and the per-request accumulators live in
-//      registers and simply persist across a cut);
-//   3. each chunk runs the same five steps as wave_eval_exact (fetch+stage, channel means, variance,
-//      normalise+products, 147-term sum); results are delivered per request in image order.
-// Per image the float32 operations and their order are exactly those of wave_eval_exact (and of the
-// reference); only the interleaving of independent images changes.
+// Before the passes every (request, image) pair is a "job" of its own lane (up to two sets of 64 jobs): the
+// job lane runs prep_image (gates, level, projected window) with the request's data fetched from the
+// requesting lane by ds_bpermute; the groups fetch the geometry of their current grab from the job lane.
 struct PackedReq {   // registers of the requesting lane (valid where its `pending` bit is set)
     int obj_mode;    // 1: objective_fn (reference image = list[0]); 0: setINCCs against list[ref]
     int ref, robust, nimg;
@@ -484,631 +232,369 @@ struct PackedRes {
     int ngrabs;               // added to
 };
 
+__device__ __forceinline__ void wave_lds_sync() {
+    // single wavefront: DS operations execute in issue order; this only stops the compiler from
+    // moving LDS accesses across the hand-over between lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float shfl_f(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
 }
 __device__ __forceinline__ int shfl_i(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
-
-// end of a setINCCs request: sequential float sum of the per-image values (lane k holds inccs[k]) and the
-// filterImagesNCC mask; out of line so that the unrolled delivery loop carries one copy
-__device__ __noinline__ void incc_finalize(float mine, int np, float thr, unsigned long long& keep, float& sum) {
-    float s = 0.0f;
-    for (int k = 0; k < np; k++) s += bcast_f(mine, k);
-    sum = s;
-    keep = __ballot(mine < 1.0f - thr);
+__device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v, int src_lane) {
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), src_lane);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), src_lane);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
-// image id `i` of the list at `row`.  COHERENT: the list was written by ANOTHER wavefront during this launch
-// (stream kernel: write-through sc1 stores), so the read bypasses this CU's L1 (sc1 load, 4-byte granule).
-template <bool COHERENT>
-__device__ __forceinline__ int list_id(const uint16_t* row, int i) {
-    if (COHERENT) {
-        const unsigned int w = __hip_atomic_load((const unsigned int*)(row + (i & ~1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return (i & 1) ? (int)(w >> 16) : (int)(w & 0xffffu);
+struct Taps { uint2 a, b; float f00, f01, f10, f11; };
+
+// Image::getColor (Image.h:104-113) in its evaluation order
+__device__ __forceinline__ void texel(const Taps& t, float& r, float& g, float& b) {
+    r = 0.0f; g = 0.0f; b = 0.0f;
+    r += (float)(t.a.x & 0xff) * t.f00 + (float)(t.b.x & 0xff) * t.f01;
+    g += (float)((t.a.x >> 8) & 0xff) * t.f00 + (float)((t.b.x >> 8) & 0xff) * t.f01;
+    b += (float)((t.a.x >> 16) & 0xff) * t.f00 + (float)((t.b.x >> 16) & 0xff) * t.f01;
+    r += (float)(t.a.x >> 24) * t.f10 + (float)(t.b.x >> 24) * t.f11;
+    g += (float)(t.a.y & 0xff) * t.f10 + (float)(t.b.y & 0xff) * t.f11;
+    b += (float)((t.a.y >> 8) & 0xff) * t.f10 + (float)((t.b.y >> 8) & 0xff) * t.f11;
+}
+
+constexpr int kGroups = 9;               // grabs per pass: nine 7-lane groups, lane 63 is spare
+constexpr int kRowVals = 3 * kTex;       // 21 float32 values (7 texels x RGB) per lane
+
+// value held by lane - 1 (lane 0 receives 0): DPP wave_shr:1, folded by the compiler into the consuming add
+__device__ __forceinline__ float lane_prev(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+
+// Sequential float32 sum over a group's window in pixel order: lane yy contributes v[0..N-1] in order, lane
+// yy+1 continues from lane yy's total.  ((0 + row0.v0) + row0.v1 ...) + row1.v0 ... -- the summation order of
+// Patch2d::normalize / dot.  The total is valid on lane yy == 6 of the group.
+template <int N>
+__device__ __forceinline__ float row_chain(const float (&v)[N], int yy) {
+    float out = 0.0f;
+#pragma unroll
+    for (int s = 0; s < kTex; s++) {
+        float a = (s == 0) ? 0.0f : lane_prev(out);
+#pragma unroll
+        for (int i = 0; i < N; i++) a += v[i];
+        out = (yy == s) ? a : out;
     }
-    return (int)row[i];
+    return out;
 }
 
-// myrow: the calling lane's own image list (uint16 ids, 4-byte aligned; read only for lanes with a pending
-// request).  Must be called by all 64 lanes.
-template <bool COHERENT>
-__device__ __forceinline__ void wave_eval_packed(const DevScene& sc, const DevOptions& o, const uint16_t* myrow,
-                                                 unsigned long long pending, const PackedReq& q, PackedRes& out,
-                                                 EvalLds& L) {
-    const unsigned long long rowbits_ = (unsigned long long)myrow;
-    const int row_lo_ = (int)(rowbits_ & 0xffffffffull), row_hi_ = (int)(rowbits_ >> 32);
-    constexpr int S = kChunk + 1;  // staging slots
+// list: the calling lane's own image list (ids; read only for lanes with a pending request).  Must be called by
+// all 64 lanes.  WRITE_INCCS (the stand-alone setINCCs kernel): `incc_out` is the requesting lane's output row;
+// the values of the usable images and the 0 of the reference image are stored there, and out.keep returns the
+// mask of the grabbed images instead of the thresholded one.
+template <bool WRITE_INCCS, typename ListT>
+__device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOptions& o, const ListT* list,
+                                               unsigned long long pending, const PackedReq& q, PackedRes& out,
+                                               float* incc_out) {
     const int lane = lane_id();
-    const bool active = lane < kTexPix;
-    const int sl = active ? lane : kTexPix - 1;
-    const int iyy = sl / kTex, ixx = sl % kTex;
+    const int grp = lane / kTex;            // 0..9; 9 = the spare lane
+    const int yy = lane - grp * kTex;       // window row of this lane
+    const bool glane = grp < kGroups;
+    const int last = glane ? grp * kTex + (kTex - 1) : lane;  // lane that ends the group's chains
     const int q_refsel = q.obj_mode ? 0 : q.ref;
+    const unsigned long long listbits = (unsigned long long)list;
+    const int list_lo = (int)(listbits & 0xffffffffull), list_hi = (int)(listbits >> 32);
+    const unsigned long long outbits = (unsigned long long)incc_out;
 
     unsigned long long rem = pending;
     while (rem) {
-        // ---- a batch of requests whose jobs fit the 64 lanes (at least one request)
+        // ---- a batch of whole requests whose jobs fit two sets of 64 job lanes (at least one request)
         unsigned long long batch = 0ull;
         int J = 0;
         for (unsigned long long t = rem; t; t &= t - 1ull) {
             const int p = __ffsll((long long)t) - 1;
             const int np = bcast_i(q.nimg, p);
-            if (batch && J + np > 64) break;
+            if (batch && J + np > 128) break;
             batch |= 1ull << p;
             J += np;
         }
         rem &= ~batch;
         PH_T(t1);
-        // ---- job of this lane: (request myp, image index myi)
-        int myp = -1, myi = 0;
+        // ---- jobs of this lane: job `lane` of set A and job 64 + `lane` of set B -> (request, image index)
+        int myoff = 0;  // requesting lanes: index of my request's first job
+        int jpA = -1, jiA = 0, jpB = -1, jiB = 0;
         {
             int off = 0;
             for (unsigned long long t = batch; t; t &= t - 1ull) {
                 const int p = __ffsll((long long)t) - 1;
                 const int np = bcast_i(q.nimg, p);
-                if (lane >= off && lane < off + np) { myp = p; myi = lane - off; }
+                if (lane == p) myoff = off;
+                if (lane >= off && lane < off + np) { jpA = p; jiA = lane - off; }
+                if (lane + 64 >= off && lane + 64 < off + np) { jpB = p; jiB = lane + 64 - off; }
                 off += np;
             }
         }
-        const int src = myp >= 0 ? myp : 0;
-        float c[3], zax[3], pxa[3], pya[3];
+        auto prep_job = [&](int jp, int ji) {
+            const int src = jp >= 0 ? jp : 0;
+            float c[3], zax[3], pxa[3], pya[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            c[k] = shfl_f(q.c[k], src); zax[k] = shfl_f(q.zax[k], src);
-            pxa[k] = shfl_f(q.px[k], src); pya[k] = shfl_f(q.py[k], src);
+            for (int k = 0; k < 3; k++) {
+                c[k] = shfl_f(q.c[k], src); zax[k] = shfl_f(q.zax[k], src);
+                pxa[k] = shfl_f(q.px[k], src); pya[k] = shfl_f(q.py[k], src);
+            }
+            const float scale = shfl_f(q.scale, src);
+            const unsigned long long lb = ((unsigned long long)(unsigned int)shfl_i(list_hi, src) << 32) |
+                                          (unsigned long long)(unsigned int)shfl_i(list_lo, src);
+            Prep P;
+            P.ok = 0; P.tlx = P.tly = P.dxx = P.dxy = P.dyx = P.dyy = 0.0f; P.pix = nullptr; P.W = 0;
+            if (jp >= 0) P = prep_image(sc.views[(int)((const ListT*)lb)[ji]], o, c, scale, pxa, pya, zax);
+            return P;
+        };
+        const Prep PA = prep_job(jpA, jiA);
+        Prep PB;
+        PB.ok = 0; PB.tlx = PB.tly = PB.dxx = PB.dxy = PB.dyx = PB.dyy = 0.0f; PB.pix = nullptr; PB.W = 0;
+        const bool two_sets = J > 64;
+        if (two_sets) PB = prep_job(jpB, jiB);
+        const unsigned long long okA = __ballot(PA.ok != 0), okB = __ballot(PB.ok != 0);
+        const unsigned long long pixA = (unsigned long long)PA.pix, pixB = (unsigned long long)PB.pix;
+        const int pixA_lo = (int)(pixA & 0xffffffffull), pixA_hi = (int)(pixA >> 32);
+        const int pixB_lo = (int)(pixB & 0xffffffffull), pixB_hi = (int)(pixB >> 32);
+
+        // ---- per request, on its requesting lane: which images are usable (bits myoff .. myoff+nimg-1 of okB:okA)
+        const bool inbatch = (batch >> lane) & 1ull;
+        unsigned long long myok = 0ull;
+        if (inbatch) {
+            unsigned long long lo;
+            if (myoff < 64) { lo = okA >> myoff; if (myoff > 0) lo |= okB << (64 - myoff); }
+            else lo = okB >> (myoff - 64);
+            myok = (q.nimg >= 64) ? lo : (lo & ((1ull << q.nimg) - 1ull));
         }
-        const float scale = shfl_f(q.scale, src);
-        Prep P;
-        P.ok = 0; P.tlx = P.tly = P.dxx = P.dxy = P.dyx = P.dyy = 0.0f; P.pix = nullptr; P.W = 0;
-        const unsigned long long rb_ = ((unsigned long long)(unsigned int)shfl_i(row_hi_, src) << 32) |
-                                       (unsigned long long)(unsigned int)shfl_i(row_lo_, src);
-        if (myp >= 0) P = prep_image(sc.views[list_id<COHERENT>((const uint16_t*)rb_, myi)], o, c, scale, pxa, pya, zax);
-        const unsigned long long okmask = __ballot(P.ok != 0);
+        const bool refok = inbatch && q.nimg > 0 && ((myok >> q_refsel) & 1ull);
+        unsigned long long todo = __ballot(refok);
+        if (inbatch && !refok) {  // sampleTexture false for the reference image: plateau value / all 2.0
+            if (q.obj_mode) out.obj = 2.0;
+            else {
+                float s = 0.0f;
+                for (int k = 0; k < q.nimg; k++) s += 2.0f;
+                out.keep = 0ull;
+                out.incc_sum = s;
+            }
+        }
         PH_T(t2);
         PH_ADD(t1, t2, 13);
 
-        // ---- position of every usable job in the slot sequence
-        int pos = -1;
-        bool isref = false;
-        int E = 0;
-        unsigned long long refok = 0ull;  // requests whose reference image passed the gates
-        {
-            int off = 0;
-            for (unsigned long long t = batch; t; t &= t - 1ull) {
-                const int p = __ffsll((long long)t) - 1;
-                const int np = bcast_i(q.nimg, p);
-                const int refp = bcast_i(q_refsel, p);
-                if (np > 0 && ((okmask >> (off + refp)) & 1ull)) {
-                    refok |= 1ull << p;
-                    const unsigned long long R = (np >= 64 ? ~0ull : ((1ull << np) - 1ull)) << off;
-                    const unsigned long long okr = okmask & R;
-                    const unsigned long long others = okr & ~(1ull << (off + refp));
-                    if (myp == p && P.ok) {
-                        if (myi == refp) { pos = E; isref = true; }
-                        else pos = E + 1 + __popcll(others & ((1ull << lane) - 1ull));
-                    }
-                    E += __popcll(okr);
-                }
-                off += np;
-            }
-        }
-        const unsigned long long refjobs = __ballot(isref);
-
-        // ---- per-request running state (persists across chunk cuts)
-        int cur = -1, cur_obj = 0, cur_rob = 0, nok = 0, ngr = 0;
-        double val = 0.0;
-        float mine = 2.0f;
-        float refn0 = 0.0f, refn1 = 0.0f, refn2 = 0.0f;
-        // OBJ results are parked on the requesting lane and divided once, lane-parallel, after the last chunk
+        // OBJ results are parked on the requesting lane and divided once, lane-parallel, after the last pass
         double d_val = 0.0;
         int d_nok = -1;
-        auto finalize = [&]() {
-            if (cur_obj) {
-                if (lane == cur) { d_val = val; d_nok = nok; out.ngrabs += ngr; }
-            } else {
-                unsigned long long keep;
-                float s;
-                incc_finalize(mine, bcast_i(q.nimg, cur), bcast_f(q.thr, cur), keep, s);
-                if (lane == cur) { out.keep = keep; out.incc_sum = s; out.ngrabs += ngr; }
-            }
-        };
 
-        for (int cb = 0; cb < E; cb += S) {
-            const int ns = (E - cb < S) ? E - cb : S;
+        // ---- state of the request my group serves (identical on the 7 lanes of a group)
+        int g_req = -1, g_off = 0, g_ref = 0, g_mode = 0, g_rob = 0, g_cur = 0, g_nok = 0, g_ngr = 0, g_nextk = 0, g_np = 0;
+        bool g_isref = false;
+        unsigned long long g_ok = 0ull, g_okall = 0ull, g_keep = 0ull, g_out = 0ull;
+        float g_thr = 0.0f, g_sum = 0.0f;
+        double g_val = 0.0;
+        float refn[kRowVals];  // my row of the normalised reference texture
+#pragma unroll
+        for (int i = 0; i < kRowVals; i++) refn[i] = 0.0f;
+
+        for (;;) {
             PH_T(t3);
-            // job lane of every slot (wave-uniform), also kept per lane for the dynamic delivery loop
-            int jl[S];
-            unsigned int refslots = 0u;
-#pragma unroll
-            for (int s = 0; s < S; s++) {
-                const unsigned long long m = __ballot(pos == cb + s);
-                jl[s] = m ? __ffsll((long long)m) - 1 : 0;
-                if (s < ns && ((refjobs >> jl[s]) & 1ull)) refslots |= 1u << s;
-            }
-            // ---- 1. fetch + stage
-            Taps taps[S];
-            float rr[S], gg[S], bb[S];
-#pragma unroll
-            for (int s = 0; s < S; s++) {
-                if (s < ns) {
-                    const int v = jl[s];
-                    taps[s] = issue_taps(bcast_f(P.tlx, v), bcast_f(P.tly, v), bcast_f(P.dxx, v), bcast_f(P.dxy, v),
-                                         bcast_f(P.dyx, v), bcast_f(P.dyy, v), bcast_p(P.pix, v), bcast_i(P.W, v), ixx, iyy);
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < S; s++) {
-                rr[s] = gg[s] = bb[s] = 0.0f;
-                if (s < ns) {
-                    texel(taps[s], rr[s], gg[s], bb[s]);
-                    if (active) {
-                        float* bp = &L.buf[s * kTexStride];
-                        bp[lane] = rr[s]; bp[kPlane + lane] = gg[s]; bp[2 * kPlane + lane] = bb[s];
+            // ---- 1. idle groups take the next pending requests, in request order
+            {
+                unsigned long long idle = __ballot(glane && yy == 0 && g_req < 0);
+                while (todo && idle) {
+                    const int p = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    const int gl = __ffsll((long long)idle) - 1;  // first lane of the group
+                    idle &= idle - 1ull;
+                    const int r_off = bcast_i(myoff, p), r_np = bcast_i(q.nimg, p), r_ref = bcast_i(q_refsel, p);
+                    const int r_mode = bcast_i(q.obj_mode, p), r_rob = bcast_i(q.robust, p);
+                    const float r_thr = bcast_f(q.thr, p);
+                    const unsigned long long r_ok = bcast_u64(myok, p);
+                    const unsigned long long r_out = WRITE_INCCS ? bcast_u64(outbits, p) : 0ull;
+                    if (lane - yy == gl) {
+                        g_req = p; g_off = r_off; g_np = r_np; g_ref = r_ref; g_mode = r_mode; g_rob = r_rob; g_thr = r_thr;
+                        g_okall = r_ok; g_ok = r_ok & ~(1ull << r_ref); g_out = r_out;
+                        g_cur = r_ref; g_isref = true;
                     }
                 }
             }
-            wave_lds_sync();
+            const bool act = glane && g_req >= 0;
+            if (!__any(act)) break;
+
+            // ---- 2. window geometry of my group's grab, from its job lane
+            float tlx, tly, dxx, dxy, dyx, dyy;
+            const uint8_t* pix;
+            int W;
+            {
+                const int j = g_off + g_cur;
+                const int src = j & 63;
+                tlx = shfl_f(PA.tlx, src); tly = shfl_f(PA.tly, src);
+                dxx = shfl_f(PA.dxx, src); dxy = shfl_f(PA.dxy, src);
+                dyx = shfl_f(PA.dyx, src); dyy = shfl_f(PA.dyy, src);
+                W = shfl_i(PA.W, src);
+                int plo = shfl_i(pixA_lo, src), phi = shfl_i(pixA_hi, src);
+                if (two_sets) {
+                    const bool sb = j >= 64;
+                    const float b0 = shfl_f(PB.tlx, src), b1 = shfl_f(PB.tly, src), b2 = shfl_f(PB.dxx, src),
+                                b3 = shfl_f(PB.dxy, src), b4 = shfl_f(PB.dyx, src), b5 = shfl_f(PB.dyy, src);
+                    const int b6 = shfl_i(PB.W, src), b7 = shfl_i(pixB_lo, src), b8 = shfl_i(pixB_hi, src);
+                    tlx = sb ? b0 : tlx; tly = sb ? b1 : tly; dxx = sb ? b2 : dxx; dxy = sb ? b3 : dxy;
+                    dyx = sb ? b4 : dyx; dyy = sb ? b5 : dyy; W = sb ? b6 : W; plo = sb ? b7 : plo; phi = sb ? b8 : phi;
+                }
+                pix = (const uint8_t*)(((unsigned long long)(unsigned int)phi << 32) | (unsigned long long)(unsigned int)plo);
+            }
+
+            // ---- 3. my row of the window: sampleTexture's stepping (l += dy per row, c += dx per column,
+            //         PatchOptimizer.cpp:511-526); all 14 tap loads are issued before the first conversion
+            float t[kRowVals];
+            {
+                // x += step taken `yy` times: fma(m, step, x) with m in {0, 1} is the same single rounding as
+                // x + step (m * step is exact) and leaves x untouched for m = 0
+                float x = tlx, y = tly;
+#pragma unroll
+                for (int k = 0; k < kTex - 1; k++) { const float m = (k < yy) ? 1.0f : 0.0f; x = __builtin_fmaf(m, dyx, x); y = __builtin_fmaf(m, dyy, y); }
+                uint2 ta[kTex], tb[kTex];
+                float wx[kTex], wy[kTex];
+                int toff[kTex];
+#pragma unroll
+                for (int xx = 0; xx < kTex; xx++) {
+                    const int lx = (int)x, ly = (int)y;
+                    wx[xx] = x - (float)lx; wy[xx] = y - (float)ly;
+                    toff[xx] = 3 * (ly * W + lx);
+                    ta[xx] = make_uint2(0u, 0u); tb[xx] = make_uint2(0u, 0u);
+                    x += dxx; y += dxy;
+                }
+                if (act) {
+#pragma unroll
+                    for (int xx = 0; xx < kTex; xx++) {
+                        const uint8_t* p0 = pix + toff[xx];
+                        ta[xx] = load8(p0);
+                        tb[xx] = load8(p0 + 3 * W);
+                    }
+                }
+#pragma unroll
+                for (int xx = 0; xx < kTex; xx++) {
+                    Taps tp;
+                    tp.a = ta[xx]; tp.b = tb[xx];
+                    const float dx1 = wx[xx], dx0 = 1.0f - dx1;
+                    const float dy1 = wy[xx], dy0 = 1.0f - dy1;
+                    tp.f00 = dx0 * dy0; tp.f01 = dx0 * dy1; tp.f10 = dx1 * dy0; tp.f11 = dx1 * dy1;
+                    texel(tp, t[3 * xx], t[3 * xx + 1], t[3 * xx + 2]);
+                }
+            }
             PH_T(t4);
             PH_ADD(t3, t4, 14);
-            // ---- 2. channel means
+
+            // ---- 4. Patch2d::normalize (Patch2d.hpp:46-84): channel means, variance, normalisation
+            float a0, a1, a2;
             {
-                const int m = lane / 3, ch = lane - 3 * m;
-                if (m < ns) L.ave[m * 4 + ch] = div_by(seq_sum<49>(&L.buf[m * kTexStride + ch * kPlane]), 1.0 / 49.0);
-            }
-            wave_lds_sync();
-            // ---- 3. variance
+                float vr[kTex], vg[kTex], vb[kTex];
 #pragma unroll
-            for (int s = 0; s < S; s++) {
-                if (s < ns && active) {
-                    const float4 av = *reinterpret_cast<const float4*>(&L.ave[s * 4]);
-                    const float f0 = av.x - rr[s], f1 = av.y - gg[s], f2 = av.z - bb[s];
-                    L.buf[s * kTexStride + lane] = f0 * f0 + f1 * f1 + f2 * f2;
+                for (int xx = 0; xx < kTex; xx++) { vr[xx] = t[3 * xx]; vg[xx] = t[3 * xx + 1]; vb[xx] = t[3 * xx + 2]; }
+                const float s0 = row_chain<kTex>(vr, yy), s1 = row_chain<kTex>(vg, yy), s2 = row_chain<kTex>(vb, yy);
+                a0 = div_by(shfl_f(s0, last), 1.0 / 49.0);
+                a1 = div_by(shfl_f(s1, last), 1.0 / 49.0);
+                a2 = div_by(shfl_f(s2, last), 1.0 / 49.0);
+            }
+            double iv;
+            {
+                float sq[kTex];
+#pragma unroll
+                for (int xx = 0; xx < kTex; xx++) {
+                    const float f0 = a0 - t[3 * xx], f1 = a1 - t[3 * xx + 1], f2 = a2 - t[3 * xx + 2];
+                    sq[xx] = f0 * f0 + f1 * f1 + f2 * f2;
                 }
-            }
-            wave_lds_sync();
-            if (lane < ns) {
-                float v2 = sqrtf(div_by(seq_sum<49>(&L.buf[lane * kTexStride]), 1.0 / 147.0));
+                float v2 = sqrtf(div_by(shfl_f(row_chain<kTex>(sq, yy), last), 1.0 / 147.0));
                 if (v2 == 0.0f) v2 = 1.0f;
-                L.inv[lane] = recip64(v2);
+                iv = recip64(v2);
             }
-            wave_lds_sync();
             PH_T(t5);
             PH_ADD(t4, t5, 15);
-            // ---- 4. normalise; products with the request's reference texel
 #pragma unroll
-            for (int s = 0; s < S; s++) {
-                if (s < ns) {
-                    const float4 av = *reinterpret_cast<const float4*>(&L.ave[s * 4]);
-                    float r = rr[s], g = gg[s], b = bb[s];
-                    const double iv = L.inv[s];
-                    r -= av.x; r = div_by(r, iv);
-                    g -= av.y; g = div_by(g, iv);
-                    b -= av.z; b = div_by(b, iv);
-                    if ((refslots >> s) & 1u) { refn0 = r; refn1 = g; refn2 = b; }
-                    else if (active) {
-                        float* bp = &L.buf[s * kTexStride + 3 * lane];
-                        bp[0] = refn0 * r; bp[1] = refn1 * g; bp[2] = refn2 * b;
+            for (int xx = 0; xx < kTex; xx++) {
+                t[3 * xx] = div_by(t[3 * xx] - a0, iv);
+                t[3 * xx + 1] = div_by(t[3 * xx + 1] - a1, iv);
+                t[3 * xx + 2] = div_by(t[3 * xx + 2] - a2, iv);
+            }
+            // ---- 5. Patch2d::dot with the request's reference texture (Patch2d.hpp:37-44)
+            float raw, rob;
+            {
+                float pr[kRowVals];
+#pragma unroll
+                for (int i = 0; i < kRowVals; i++) {
+                    refn[i] = g_isref ? t[i] : refn[i];
+                    pr[i] = refn[i] * t[i];
+                }
+                PH_T(t6);
+                PH_ADD(t5, t6, 20);
+                raw = 1.0f - div_by(shfl_f(row_chain<kRowVals>(pr, yy), last), 1.0 / 147.0);
+                rob = robustincc(raw);
+                PH_T(t7);
+                PH_ADD(t6, t7, 21);
+            }
+            PH_T(t7b);
+
+            // ---- 6. the request's accumulations, in the reference's loop order (identical on the group's lanes)
+            if (act) {
+                if (g_isref) {
+                    g_ngr = 1; g_val = 0.0; g_nok = 0; g_keep = 0ull; g_sum = 0.0f; g_nextk = 0;
+                    if (WRITE_INCCS) { if (yy == 0 && g_out) ((float*)g_out)[g_ref] = 0.0f; }
+                } else {
+                    g_ngr++;
+                    if (g_mode) {  // objective_fn (PatchOptimizer.cpp:299-309)
+                        g_val += (double)rob;
+                        g_nok++;
+                    } else {       // setINCCs (PatchOptimizer.cpp:462-472)
+                        const float e = g_rob ? rob : raw;
+                        if (e < 1.0f - g_thr) g_keep |= 1ull << g_cur;
+                        // std::accumulate over inccs in index order: the images between the previous usable one
+                        // and this one hold 2.0 (or 0.0 for the reference image: adding it changes nothing)
+                        const unsigned long long below = (1ull << g_cur) - 1ull, done = (1ull << g_nextk) - 1ull;
+                        const int gap = __popcll(~g_okall & ~(1ull << g_ref) & below & ~done);
+                        for (int r = 0; r < gap; r++) g_sum += 2.0f;
+                        g_sum += e;
+                        g_nextk = g_cur + 1;
+                        if (WRITE_INCCS) { if (yy == 0 && g_out) ((float*)g_out)[g_cur] = e; }
                     }
                 }
             }
-            wave_lds_sync();
-            PH_T(t6);
-            PH_ADD(t5, t6, 20);
-            // ---- 5. NCC sums
-            float raw = 2.0f;
-            if (lane < ns && !((refslots >> lane) & 1u)) raw = 1.0f - div_by(seq_sum<147>(&L.buf[lane * kTexStride]), 1.0 / 147.0);
-            const float rob = robustincc(raw);  // lane-parallel: one division for the whole chunk
-            PH_T(t7);
-            PH_ADD(t6, t7, 21);
-            // ---- deliver in sequence order
-#pragma unroll
-            for (int s = 0; s < S; s++) {
-                if (s >= ns) break;
-                const int v = jl[s];
-                if ((refslots >> s) & 1u) {
-                    if (cur >= 0) finalize();
-                    cur = bcast_i(myp, v);
-                    cur_obj = bcast_i(q.obj_mode, cur);
-                    cur_rob = bcast_i(q.robust, cur);
-                    const int refi = bcast_i(myi, v);
-                    val = 0.0; nok = 0; ngr = 1;
-                    mine = (lane == refi) ? 0.0f : 2.0f;
-                } else {
-                    ngr++;
-                    if (cur_obj) { val += (double)bcast_f(rob, s); nok++; }
-                    else if (lane == bcast_i(myi, v)) mine = cur_rob ? bcast_f(rob, s) : bcast_f(raw, s);
-                }
-            }
-            wave_lds_sync();
-            PH_T(t8);
-            PH_ADD(t7, t8, 22);
-        }
-        if (cur >= 0) finalize();
-        if (d_nok >= 0) out.obj = (d_nok < o.MIN_IMAGES_PER_PATCH - 1) ? 2.0 : d_val / (double)d_nok;
-        // ---- requests whose reference image failed the gates (sampleTexture false for image `ref`)
-        for (unsigned long long t = batch & ~refok; t; t &= t - 1ull) {
-            const int p = __ffsll((long long)t) - 1;
-            const int np = bcast_i(q.nimg, p);
-            if (lane == p) {
-                if (q.obj_mode) out.obj = 2.0;
+            // ---- 7. next image of the request, or hand the results to the requesting lane
+            bool fin = false;
+            if (act) {
+                if (g_ok) { g_cur = __ffsll((long long)g_ok) - 1; g_ok &= g_ok - 1ull; g_isref = false; }
                 else {
-                    float s = 0.0f;
-                    for (int k = 0; k < np; k++) s += 2.0f;
-                    out.keep = 0ull;
-                    out.incc_sum = s;
+                    fin = true;
+                    if (!g_mode) {
+                        const unsigned long long all = (g_np >= 64) ? ~0ull : ((1ull << g_np) - 1ull);
+                        const unsigned long long done = (g_nextk >= 64) ? ~0ull : ((1ull << g_nextk) - 1ull);
+                        const int gap = __popcll(~g_okall & ~(1ull << g_ref) & all & ~done);
+                        for (int r = 0; r < gap; r++) g_sum += 2.0f;
+                        if (0.0f < 1.0f - g_thr) g_keep |= 1ull << g_ref;          // inccs[ref] = 0
+                        if (2.0f < 1.0f - g_thr) g_keep |= ~g_okall & all;          // failed grabs hold 2.0
+                    }
                 }
             }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// LANE-PER-GRAB exact-order evaluator: every (request, image) pair is one lane.
-//
-// The packed evaluator above spreads ONE grab over 49 lanes and has to hand the reference's sequential float32
-// sums to single lanes through LDS (5 barriers and ~2.1 k wave-cycles per grab).  Here a lane does a whole
-// sampleTexture by itself, exactly like the CPU thread of the reference does: the 49 bilinear taps in the
-// reference's incremental stepping order (PatchOptimizer.cpp:511-526), the 147 raw values in registers,
-// Patch2d::normalize's three sequential passes (Patch2d.hpp:46-84) and the 147-term dot product
-// (Patch2d.hpp:37-44) with the request's reference texture, whose normalised values are read from the lane that
-// grabbed the reference image with ds_bpermute (no LDS allocation, no barriers).  Up to 64 grabs advance per
-// pass, the sums need no staging, and every float operation is the reference's in the reference's order.
-// Requests are packed into passes like in wave_eval_packed (whole requests, <= 64 jobs per pass).
-__device__ __forceinline__ void grab_window(const Prep& P, float (&t)[3 * kTexPix]) {
-    float lx = P.tlx, ly = P.tly;  // row start: l += dy per row, c += dx per column
-#pragma unroll
-    for (int yy = 0; yy < kTex; yy++) {
-        float cx = lx, cy = ly;
-#pragma unroll
-        for (int xx = 0; xx < kTex; xx++) {
-            const int ix = (int)cx, iy = (int)cy;
-            const uint8_t* p0 = P.pix + 3 * (iy * P.W + ix);
-            Taps tp;
-            tp.a = load8(p0);
-            tp.b = load8(p0 + 3 * P.W);
-            const float dx1 = cx - (float)ix, dx0 = 1.0f - dx1;
-            const float dy1 = cy - (float)iy, dy0 = 1.0f - dy1;
-            tp.f00 = dx0 * dy0; tp.f01 = dx0 * dy1; tp.f10 = dx1 * dy0; tp.f11 = dx1 * dy1;
-            const int k = 3 * (yy * kTex + xx);
-            texel(tp, t[k], t[k + 1], t[k + 2]);
-            cx += P.dxx; cy += P.dxy;
-        }
-        lx += P.dyx; ly += P.dyy;
-        // one row of taps (14 loads) in flight at a time: without this fence the scheduler hoists all 98 loads
-        // of the window and spills the texture to scratch
-        asm volatile("" ::: "memory");
-    }
-}
-
-// Patch2d::normalize (Patch2d.hpp:46-84) on a register-resident texture
-__device__ __forceinline__ void normalize_window(float (&t)[3 * kTexPix]) {
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-    for (int i = 0; i < kTexPix; i++) { s0 += t[3 * i]; s1 += t[3 * i + 1]; s2 += t[3 * i + 2]; }
-    const float a0 = div_by(s0, 1.0 / 49.0), a1 = div_by(s1, 1.0 / 49.0), a2 = div_by(s2, 1.0 / 49.0);
-    float q = 0.0f;
-#pragma unroll
-    for (int i = 0; i < kTexPix; i++) {
-        const float f0 = a0 - t[3 * i], f1 = a1 - t[3 * i + 1], f2 = a2 - t[3 * i + 2];
-        q += f0 * f0 + f1 * f1 + f2 * f2;
-    }
-    float v2 = sqrtf(div_by(q, 1.0 / 147.0));
-    if (v2 == 0.0f) v2 = 1.0f;
-    const double iv = recip64(v2);
-#pragma unroll
-    for (int i = 0; i < kTexPix; i++) {
-        t[3 * i] = div_by(t[3 * i] - a0, iv);
-        t[3 * i + 1] = div_by(t[3 * i + 1] - a1, iv);
-        t[3 * i + 2] = div_by(t[3 * i + 2] - a2, iv);
-    }
-}
-
-// myrow: the calling lane's own image list (uint16 ids; only read for lanes with a pending request).
-// Must be called by all 64 lanes (wave-uniform control flow around every cross-lane operation).
-#ifndef HPMVS_EVAL_JOBS_INLINE
-#define HPMVS_EVAL_JOBS_ATTR __noinline__
-#else
-#define HPMVS_EVAL_JOBS_ATTR __forceinline__
-#endif
-// (out of line by default: its ~200 VGPRs -- the 147 texture values -- then do not compete with the caller's
-//  long-lived per-patch registers inside the tap loop; the arguments travel by value, in registers)
-template <bool COHERENT>
-__device__ HPMVS_EVAL_JOBS_ATTR PackedRes wave_eval_jobs(DevScene sc, DevOptions o, const uint16_t* myrow,
-                                                       unsigned long long pending, PackedReq q, PackedRes out) {
-    const int lane = lane_id();
-    const int q_refsel = q.obj_mode ? 0 : q.ref;
-    const unsigned long long rowbits = (unsigned long long)myrow;
-    const int row_lo = (int)(rowbits & 0xffffffffull), row_hi = (int)(rowbits >> 32);
-
-    unsigned long long rem = pending;
-    while (rem) {
-        // ---- a pass: whole requests whose jobs fit the 64 lanes (at least one request)
-        unsigned long long batch = 0ull;
-        int J = 0;
-        for (unsigned long long t = rem; t; t &= t - 1ull) {
-            const int p = __ffsll((long long)t) - 1;
-            const int np = bcast_i(q.nimg, p);
-            if (batch && J + np > 64) break;
-            batch |= 1ull << p;
-            J += np;
-        }
-        rem &= ~batch;
-        PH_T(t1);
-        // ---- job of this lane (request myp, image index myi); each requesting lane learns where its jobs sit
-        int myp = -1, myi = 0, refl = 0, myoff = 0, maxnp = 0;
-        {
-            int off = 0;
-            for (unsigned long long t = batch; t; t &= t - 1ull) {
-                const int p = __ffsll((long long)t) - 1;
-                const int np = bcast_i(q.nimg, p);
-                const int refp = bcast_i(q_refsel, p);
-                if (lane >= off && lane < off + np) { myp = p; myi = lane - off; refl = off + refp; }
-                if (lane == p) myoff = off;
-                maxnp = np > maxnp ? np : maxnp;
-                off += np;
-            }
-        }
-        const int src = myp >= 0 ? myp : 0;
-        float c[3], zax[3], pxa[3], pya[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            c[k] = shfl_f(q.c[k], src); zax[k] = shfl_f(q.zax[k], src);
-            pxa[k] = shfl_f(q.px[k], src); pya[k] = shfl_f(q.py[k], src);
-        }
-        const float scale = shfl_f(q.scale, src);
-        const unsigned long long rb = ((unsigned long long)(unsigned int)shfl_i(row_hi, src) << 32) |
-                                      (unsigned long long)(unsigned int)shfl_i(row_lo, src);
-        Prep P;
-        P.ok = 0; P.tlx = P.tly = P.dxx = P.dxy = P.dyx = P.dyy = 0.0f; P.pix = nullptr; P.W = 0;
-        if (myp >= 0) P = prep_image(sc.views[list_id<COHERENT>((const uint16_t*)rb, myi)], o, c, scale, pxa, pya, zax);
-        const unsigned long long okmask = __ballot(P.ok != 0);
-        PH_T(t2);
-        PH_ADD(t1, t2, 13);
-
-        // ---- the grab: sampleTexture + normalize, one lane per (request, image) whose reference image is usable
-        const bool refok = (okmask >> refl) & 1ull;
-        const bool work = myp >= 0 && P.ok && refok;
-        float t[3 * kTexPix];
-#pragma unroll
-        for (int k = 0; k < 3 * kTexPix; k++) t[k] = 0.0f;
-        if (work) {
-            grab_window(P, t);
-            normalize_window(t);
-        }
-        PH_T(t3);
-        PH_ADD(t2, t3, 14);
-        // ---- Patch2d::dot with the reference texture (held by lane refl)
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 3 * kTexPix; k++) acc += shfl_f(t[k], refl) * t[k];
-        const float raw = 1.0f - div_by(acc, 1.0 / 147.0);
-        const float rob = robustincc(raw);
-        PH_T(t4);
-        PH_ADD(t3, t4, 21);
-
-        // ---- delivery: every requesting lane walks its own jobs in image order
-        const bool mine = (batch >> lane) & 1ull;
-        const int np = mine ? q.nimg : 0;
-        const bool myrefok = mine && np > 0 && ((okmask >> (myoff + q_refsel)) & 1ull);
-        double val = 0.0;
-        float isum = 0.0f;
-        unsigned long long keep = 0ull;
-        int nok = 0, ngr = myrefok ? 1 : 0;
-        for (int i = 0; i < maxnp; i++) {
-            const int jl = (myoff + i) & 63;
-            const float e_raw = shfl_f(raw, jl), e_rob = shfl_f(rob, jl);
-            if (i < np) {
-                const bool jok = myrefok && ((okmask >> jl) & 1ull);
-                if (q.obj_mode) {
-                    if (jok && i != q_refsel) { val += (double)e_rob; nok++; ngr++; }
-                } else {
-                    float e = 2.0f;
-                    if (myrefok && i == q_refsel) e = 0.0f;
-                    else if (jok) { e = q.robust ? e_rob : e_raw; ngr++; }
-                    isum += e;
-                    if (e < 1.0f - q.thr) keep |= 1ull << i;
+            for (unsigned long long fm = __ballot(fin && yy == 0); fm; fm &= fm - 1ull) {
+                const int gl = __ffsll((long long)fm) - 1;
+                const int p = bcast_i(g_req, gl);
+                const int r_mode = bcast_i(g_mode, gl), r_nok = bcast_i(g_nok, gl), r_ngr = bcast_i(g_ngr, gl);
+                const double r_val = bcast_d(g_val, gl);
+                const unsigned long long r_keep = bcast_u64(WRITE_INCCS ? g_okall : g_keep, gl);  // WRITE_INCCS: which images were grabbed
+                const float r_sum = bcast_f(g_sum, gl);
+                if (lane == p) {
+                    out.ngrabs += r_ngr;
+                    if (r_mode) { d_val = r_val; d_nok = r_nok; }
+                    else { out.keep = r_keep; out.incc_sum = r_sum; }
                 }
             }
+            if (fin) g_req = -1;
+            PH_T(t8);
+            PH_ADD(t7b, t8, 22);
         }
-        if (mine) {
-            out.ngrabs += ngr;
-            if (q.obj_mode) out.obj = (!myrefok || nok < o.MIN_IMAGES_PER_PATCH - 1) ? 2.0 : val / (double)nok;
-            else { out.keep = myrefok ? keep : 0ull; out.incc_sum = isum; }
-        }
-        PH_T(t5);
-        PH_ADD(t4, t5, 22);
+        if (d_nok >= 0) out.obj = (d_nok < o.MIN_IMAGES_PER_PATCH - 1) ? 2.0 : d_val / (double)d_nok;
     }
-    return out;
 }
 
-// ------------------------------------------------------------------------------------------
-// Lane-per-grab evaluator with COMPACTION, for wavefronts that hold many requests (the stream kernel's EVAL visit:
-// 64 requests of 64 different patches).  wave_eval_jobs gives a lane to every attached image, usable or not; with
-// the long image lists after addImages most of them fail sampleTexture's gates (angle, level, window inside the
-// image) and their lanes idle through the 5 k-instruction grab.  Here
-//   phase 1  one lane per (request, image) runs ONLY the gates (prep_image, ~300 instructions): every request gets
-//            the bit mask of its usable images;
-//   phase 2  whole requests are packed by their USABLE image count, <= 64 grabs per pass, every lane of a pass
-//            does a real grab (gates recomputed for the chosen image: cheaper than carrying 8 registers per job
-//            through LDS); reference textures travel by ds_bpermute inside the pass as in wave_eval_jobs.
-// Delivery walks each request's images in ascending index, unusable ones contributing the reference's constants
-// (2.0 for a failed grab, PatchOptimizer.cpp:458-470), so every sum is formed in the reference's order.
-#ifdef SK_STATS
-__device__ unsigned long long* g_evdbg = nullptr;  // 16 counters, set by the stream kernel (stats builds only)
-#define EV_T(v) const long long v = clock64()
-#define EV_ACC(i, a, b) do { if (lane_id() == 0 && g_evdbg) atomicAdd(g_evdbg + (i), (unsigned long long)((b) - (a))); } while (0)
-#else
-#define EV_T(v) do { } while (0)
-#define EV_ACC(i, a, b) do { } while (0)
-#endif
-template <bool COHERENT>
-__device__ __noinline__ PackedRes wave_eval_compact(DevScene sc, DevOptions o, const uint16_t* myrow,
-                                                    unsigned long long pending, PackedReq q, PackedRes out) {
-    const int lane = lane_id();
-    const int q_refsel = q.obj_mode ? 0 : q.ref;
-    const unsigned long long rowbits = (unsigned long long)myrow;
-    const int row_lo = (int)(rowbits & 0xffffffffull), row_hi = (int)(rowbits >> 32);
-    const bool has_req = (pending >> lane) & 1ull;
-
-    // ---------------- phase 1: gates only
-    unsigned long long mymask = 0ull;  // requesting lanes: bit i <=> image i of the list passes the gates
-    EV_T(e0);
-    for (unsigned long long rem = pending; rem;) {
-        EV_ACC(1, 0, 1);
-        unsigned long long batch = 0ull;
-        int J = 0;
-        for (unsigned long long t = rem; t; t &= t - 1ull) {
-            const int p = __ffsll((long long)t) - 1;
-            const int np = bcast_i(q.nimg, p);
-            if (batch && J + np > 64) break;
-            batch |= 1ull << p;
-            J += np;
-        }
-        rem &= ~batch;
-        int myp = -1, myi = 0, myoff = 0;
-        {
-            int off = 0;
-            for (unsigned long long t = batch; t; t &= t - 1ull) {
-                const int p = __ffsll((long long)t) - 1;
-                const int np = bcast_i(q.nimg, p);
-                if (lane >= off && lane < off + np) { myp = p; myi = lane - off; }
-                if (lane == p) myoff = off;
-                off += np;
-            }
-        }
-        const int src = myp >= 0 ? myp : 0;
-        float c[3], zax[3], pxa[3], pya[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            c[k] = shfl_f(q.c[k], src); zax[k] = shfl_f(q.zax[k], src);
-            pxa[k] = shfl_f(q.px[k], src); pya[k] = shfl_f(q.py[k], src);
-        }
-        const float scale = shfl_f(q.scale, src);
-        const unsigned long long rb = ((unsigned long long)(unsigned int)shfl_i(row_hi, src) << 32) |
-                                      (unsigned long long)(unsigned int)shfl_i(row_lo, src);
-        int okj = 0;
-        if (myp >= 0) okj = prep_image(sc.views[list_id<COHERENT>((const uint16_t*)rb, myi)], o, c, scale, pxa, pya, zax).ok;
-        const unsigned long long okmask = __ballot(okj != 0);
-        if ((batch >> lane) & 1ull) {
-            const int np = q.nimg;
-            const unsigned long long m = (np >= 64) ? ~0ull : ((1ull << np) - 1ull);
-            mymask = (okmask >> myoff) & m;
-        }
-    }
-    const bool refok = has_req && q.nimg > 0 && ((mymask >> q_refsel) & 1ull);
-    if (has_req && !refok) {  // sampleTexture failed for the reference image (PatchOptimizer.cpp:291-293, 454-457)
-        if (q.obj_mode) out.obj = 2.0;
-        else {
-            float s2 = 0.0f;
-            for (int k = 0; k < q.nimg; k++) s2 += 2.0f;
-            out.keep = 0ull;
-            out.incc_sum = s2;
-        }
-    }
-    const int mycnt = refok ? __popcll(mymask) : 0;  // grabs of this request, reference image included
-    EV_T(e1);
-    EV_ACC(0, e0, e1);
-
-    // ---------------- phase 2: grabs
-    for (unsigned long long rem = __ballot(refok); rem;) {
-        EV_T(p0);
-        unsigned long long batch = 0ull;
-        int J = 0, maxnp = 0;
-        for (unsigned long long t = rem; t; t &= t - 1ull) {
-            const int p = __ffsll((long long)t) - 1;
-            const int cp = bcast_i(mycnt, p);
-            if (batch && J + cp > 64) break;
-            batch |= 1ull << p;
-            J += cp;
-            const int np = bcast_i(q.nimg, p);
-            maxnp = np > maxnp ? np : maxnp;
-        }
-        rem &= ~batch;
-        // ---- lane -> (request myp, j-th usable image); every requesting lane learns where its grabs sit
-        int myp = -1, myj = 0, myoff = 0;
-        {
-            int off = 0;
-            for (unsigned long long t = batch; t; t &= t - 1ull) {
-                const int p = __ffsll((long long)t) - 1;
-                const int cp = bcast_i(mycnt, p);
-                if (lane >= off && lane < off + cp) { myp = p; myj = lane - off; }
-                if (lane == p) myoff = off;
-                off += cp;
-            }
-        }
-        const int src = myp >= 0 ? myp : 0;
-        const unsigned long long pmask = ((unsigned long long)(unsigned int)shfl_i((int)(mymask >> 32), src) << 32) |
-                                         (unsigned long long)(unsigned int)shfl_i((int)(mymask & 0xffffffffull), src);
-        const int prefsel = shfl_i(q_refsel, src);
-        const int poff = shfl_i(myoff, src);
-        int myi = 0, refl = 0;
-        if (myp >= 0) {
-            unsigned long long m = pmask;
-            for (int t = 0; t < myj; t++) m &= m - 1ull;  // drop the myj lowest usable images
-            myi = __ffsll((long long)m) - 1;
-            refl = poff + __popcll(pmask & ((1ull << prefsel) - 1ull));
-        }
-        float c[3], zax[3], pxa[3], pya[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            c[k] = shfl_f(q.c[k], src); zax[k] = shfl_f(q.zax[k], src);
-            pxa[k] = shfl_f(q.px[k], src); pya[k] = shfl_f(q.py[k], src);
-        }
-        const float scale = shfl_f(q.scale, src);
-        const unsigned long long rb = ((unsigned long long)(unsigned int)shfl_i(row_hi, src) << 32) |
-                                      (unsigned long long)(unsigned int)shfl_i(row_lo, src);
-        float t[3 * kTexPix];
-#pragma unroll
-        for (int k = 0; k < 3 * kTexPix; k++) t[k] = 0.0f;
-        EV_T(p1);
-        Prep P;
-        P.ok = 0; P.tlx = P.tly = P.dxx = P.dxy = P.dyx = P.dyy = 0.0f; P.pix = nullptr; P.W = 0;
-        if (myp >= 0) P = prep_image(sc.views[list_id<COHERENT>((const uint16_t*)rb, myi)], o, c, scale, pxa, pya, zax);
-        EV_T(p2);
-        if (myp >= 0) grab_window(P, t);   // P.ok holds: same inputs, same operations as in phase 1
-        EV_T(p3);
-        if (myp >= 0) normalize_window(t);
-        EV_T(p4);
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 3 * kTexPix; k++) acc += shfl_f(t[k], refl) * t[k];
-        const float raw = 1.0f - div_by(acc, 1.0 / 147.0);
-        const float rob = robustincc(raw);
-        EV_T(p5);
-
-        // ---- delivery: every requesting lane of the pass walks its image list in index order
-        const bool mine = (batch >> lane) & 1ull;
-        const int np = mine ? q.nimg : 0;
-        double val = 0.0;
-        float isum = 0.0f;
-        unsigned long long keep = 0ull;
-        int nok = 0;
-        for (int i = 0; i < maxnp; i++) {
-            const bool usable = mine && ((mymask >> i) & 1ull);
-            const int jl = (myoff + __popcll(mymask & ((1ull << i) - 1ull))) & 63;
-            const float e_raw = shfl_f(raw, jl), e_rob = shfl_f(rob, jl);
-            if (i < np) {
-                if (q.obj_mode) {
-                    if (usable && i != q_refsel) { val += (double)e_rob; nok++; }
-                } else {
-                    float e = 2.0f;
-                    if (i == q_refsel) e = 0.0f;
-                    else if (usable) e = q.robust ? e_rob : e_raw;
-                    isum += e;
-                    if (e < 1.0f - q.thr) keep |= 1ull << i;
-                }
-            }
-        }
-        if (mine) {
-            out.ngrabs += mycnt;
-            if (q.obj_mode) out.obj = (nok < o.MIN_IMAGES_PER_PATCH - 1) ? 2.0 : val / (double)nok;
-            else { out.keep = keep; out.incc_sum = isum; }
-        }
-        EV_T(p6);
-        EV_ACC(2, p0, p1); EV_ACC(3, p1, p2); EV_ACC(4, p2, p3); EV_ACC(5, p3, p4); EV_ACC(6, p4, p5); EV_ACC(7, p5, p6);
-        EV_ACC(8, 0, 1); EV_ACC(9, 0, (long long)J);
-    }
-    return out;
-}
 
 // ------------------------------------------------------------------------------------------
 // optimiser-variable <-> patch maps (per-lane scalar)
@@ -1238,5 +724,6 @@ __device__ __forceinline__ void parameters_from_center_norm(const OptFields& F, 
         x[k] = (v < ub[k]) ? v : ub[k];
     }
 }
+
 
 }  // namespace hpmvs
