@@ -89,6 +89,9 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
     s_prof[lane] = 0ull;
     __syncthreads();
 #endif
+    // results delivered by the list services (pipeline.hpp)
+    int res_n = 0, res_fail = 0;
+    float res_rgb[3] = {0, 0, 0};
     for (;;) {
         // ================= phase A: every lane advances its own patch until it needs the wave
         while (op == OP_NONE && stage != S_IDLE) {
@@ -111,19 +114,25 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
                     row[k] = (uint16_t)id;
                 }
                 if (bad_id) { fail_stage = 101; finish_fail = true; break; }  // image id outside the scene: rejected, never dereferenced
-                nimg = add_images_v(sc, o, row, nimg, HPMVS_F3(c), HPMVS_F3(n), scale);
+                op = OPL_ADD;  // addImages
+                stage = S_ADD1;
+                break;
+            }
+            case S_ADD1: {
+                nimg = res_n;
                 if (nimg < 0) { fail_stage = 100; finish_fail = true; break; }
                 if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 1; finish_fail = true; break; }
                 op = OP_INCC; req_ref = 0; req_robust = 0; req_thr = o.NCC_ALPHA_1;
                 stage = S_F1;
                 break;
             }
-            case S_F1: {  // filterImagesNCC(alpha1) result -> sortImages, assureImageAngles, optimizePatch start
-                nimg = apply_keep_mask(row, nimg, res_mask);
-                if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 2; finish_fail = true; break; }
-                nimg = sort_images_v(sc, o, row, nimg, HPMVS_F3(c), HPMVS_F3(n), scale);
-                if (!assure_image_angles_v(sc, o, row, nimg, HPMVS_F3(c))) { fail_stage = 3; finish_fail = true; break; }
-                if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 4; finish_fail = true; break; }
+            case S_F1:  // filterImagesNCC(alpha1) result -> the removal, sortImages, assureImageAngles
+                op = OPL_F1;
+                stage = S_F1B;
+                break;
+            case S_F1B: {  // optimizePatch start
+                nimg = res_n;
+                if (res_fail) { fail_stage = res_fail; finish_fail = true; break; }
                 set_optimization_fields(sc.views[row[0]], c, F);
                 double x0[3], dx[3];
                 parameters_from_center_norm(F, o, n, lbv, ubv, x0);
@@ -147,19 +156,25 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
                 // SUCCESS / STOPVAL / FTOL / XTOL only (PatchOptimizer.cpp:367-368); negative codes throw
                 if (!(nl_result >= 1 && nl_result <= 4)) { fail_stage = 4; finish_fail = true; break; }
                 { const double xf[3] = {BQA(xfinal, 0), BQA(xfinal, 1), BQA(xfinal, 2)}; set_center_norm(F, o, xf, c, n); }
-                nimg = add_images_v(sc, o, row, nimg, HPMVS_F3(c), HPMVS_F3(n), scale);
+                op = OPL_ADD;  // addImages
+                stage = S_ADD2;
+                break;
+            }
+            case S_ADD2: {
+                nimg = res_n;
                 if (nimg < 0) { fail_stage = 100; finish_fail = true; break; }
                 if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 5; finish_fail = true; break; }
                 op = OP_INCC; req_ref = 0; req_robust = 0; req_thr = o.NCC_ALPHA_2;
                 stage = S_F2;
                 break;
             }
-            case S_F2: {  // filterImagesNCC(alpha2) -> filterImagesByAngle, assureImageAngles, setRefImage start
-                nimg = apply_keep_mask(row, nimg, res_mask);
-                if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 6; finish_fail = true; break; }
-                nimg = filter_images_by_angle_v(sc, o, row, nimg, HPMVS_F3(c), HPMVS_F3(n));
-                if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 7; finish_fail = true; break; }
-                if (!assure_image_angles_v(sc, o, row, nimg, HPMVS_F3(c))) { fail_stage = 8; finish_fail = true; break; }
+            case S_F2:  // filterImagesNCC(alpha2) result -> the removal, filterImagesByAngle, assureImageAngles
+                op = OPL_F2;
+                stage = S_F2B;
+                break;
+            case S_F2B: {  // setRefImage start
+                nimg = res_n;
+                if (res_fail) { fail_stage = res_fail; finish_fail = true; break; }
                 ii = 0; refindex = -1; refbest = 3.402823466e+38f;
                 op = OP_REFSUM; req_ref = 0; req_robust = 1;
                 stage = S_RS;
@@ -178,10 +193,13 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
                 stage = S_F3;
                 break;
             }
-            case S_F3: {
-                nimg = apply_keep_mask(row, nimg, res_mask);
-                if (nimg < o.MIN_IMAGES_PER_PATCH) { fail_stage = 9; finish_fail = true; break; }
-                if (nimg > b.max_images) { fail_stage = 100; finish_fail = true; break; }
+            case S_F3:  // the last filterImagesNCC(alpha2) result -> the removal, Scene::getColor(patch)
+                op = OPL_F3;
+                stage = S_F3B;
+                break;
+            case S_F3B: {
+                nimg = res_n;
+                if (res_fail) { fail_stage = res_fail; finish_fail = true; break; }
                 finish_ok = true;
                 break;
             }
@@ -195,10 +213,7 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
                     b.normal[4 * idx + 3] = 0.0f;
                     b.n_images[idx] = nimg;
                     for (int k = 0; k < nimg && k < b.max_images; k++) b.images[(size_t)idx * b.max_images + k] = row[k];
-                    if (b.color) {
-                        const F3 rgb = patch_colour_v(sc, row, nimg, HPMVS_F3(c), scale);
-                        b.color[3 * idx] = rgb.x; b.color[3 * idx + 1] = rgb.y; b.color[3 * idx + 2] = rgb.z;
-                    }
+                    if (b.color) { b.color[3 * idx] = res_rgb[0]; b.color[3 * idx + 1] = res_rgb[1]; b.color[3 * idx + 2] = res_rgb[2]; }
                     if (b.ncc) b.ncc[idx] = 1.4f;  // PatchOptimizer.cpp:95
                 }
                 if (b.stage) b.stage[idx] = finish_ok ? 0 : fail_stage;
@@ -210,10 +225,44 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
                 stage = S_FETCH;
             }
         }
+        // ================= list services: the image-list passes, one request at a time, 64 lanes wide (pipeline.hpp)
+        {
+            wave_lds_sync();  // the lanes' own list writes (global workspace) before the cooperative reads
+            const unsigned long long lm = __ballot(op >= OPL_ADD);
+            if (lm) {
+                BQ_PROF_BEGIN(tls_);
+                for (unsigned long long t = lm; t; t &= t - 1ull) {
+                    const int p = __ffsll((long long)t) - 1;
+                    const int kind = bcast_i(op, p);
+                    uint16_t* prow = lists + p * kRow;
+                    const int pn = bcast_i(nimg, p);
+                    const U3 pc{bcast_f(c[0], p), bcast_f(c[1], p), bcast_f(c[2], p)};
+                    const U3 pnrm{bcast_f(n[0], p), bcast_f(n[1], p), bcast_f(n[2], p)};
+                    const float pscale = bcast_f(scale, p);
+                    const unsigned long long pmask = bcast_u64(res_mask, p);
+                    ListResult r;
+                    r.nimg = 0; r.fail = 0; r.rgb = U3{0.0f, 0.0f, 0.0f};
+                    if (kind == OPL_ADD) r.nimg = coop_add_images(sc, o, prow, pn, pc, pnrm, pscale);
+                    else if (kind == OPL_F1) r = coop_list_f1(sc, o, prow, pn, pmask, pc, pnrm, pscale);
+                    else if (kind == OPL_F2) r = coop_list_f2(sc, o, prow, pn, pmask, pc, pnrm);
+                    else r = coop_list_f3(sc, o, prow, pn, pmask, pc, pscale, b.max_images, b.color != nullptr);
+                    if (lane == p) {
+                        res_n = r.nimg; res_fail = r.fail;
+                        res_rgb[0] = r.rgb.x; res_rgb[1] = r.rgb.y; res_rgb[2] = r.rgb.z;
+                        op = OP_NONE;
+                    }
+                }
+                wave_lds_sync();
+                BQ_PROF_END(tls_, 24);
+                continue;  // the served lanes go on in phase A
+            }
+        }
+        BQ_PROF_BEGIN(tax_);
         if (op != OP_NONE) {  // calculatePatchAxis (PatchOptimizer.cpp:532-548), lane-parallel
             const DevView& RV = sc.views[row[op == OP_OBJ ? 0 : req_ref]];
             calc_patch_axes(RV.xaxis, RV.yaxis, n, scale, ax, ay, az);
         }
+        BQ_PROF_END(tax_, 17);
         // ================= phase B: the wave serves all posted requests in one packed pass
         wave_lds_sync();  // orders the lanes' image-list updates (global workspace) before the cross-lane reads of phase B
         unsigned long long pending = __ballot(op != OP_NONE);

@@ -370,6 +370,7 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
         }
         const bool refok = inbatch && q.nimg > 0 && ((myok >> q_refsel) & 1ull);
         unsigned long long todo = __ballot(refok);
+        const int mylen = __popcll(myok);  // grabs of my request
         if (inbatch && !refok) {  // sampleTexture false for the reference image: plateau value / all 2.0
             if (q.obj_mode) out.obj = 2.0;
             else {
@@ -402,8 +403,14 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
             {
                 unsigned long long idle = __ballot(glane && yy == 0 && g_req < 0);
                 while (todo && idle) {
-                    const int p = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1ull;
+                    // longest request first (fewest idle group-passes at the end of the round); scalar loop
+                    int p = 0, pl = -1;
+                    for (unsigned long long t = todo; t; t &= t - 1ull) {
+                        const int pp = __ffsll((long long)t) - 1;
+                        const int l = bcast_i(mylen, pp);
+                        if (l > pl) { pl = l; p = pp; }
+                    }
+                    todo &= ~(1ull << p);
                     const int gl = __ffsll((long long)idle) - 1;  // first lane of the group
                     idle &= idle - 1ull;
                     const int r_off = bcast_i(myoff, p), r_np = bcast_i(q.nimg, p), r_ref = bcast_i(q_refsel, p);

@@ -1,7 +1,19 @@
-// pipeline.hpp -- per-lane scalar device code of PatchOptimizer::runOptimization's image-list passes
-// (reference src/hpmvs/PatchOptimizer.cpp:105-284) and Scene::getColor(patch) (src/hpmvs/Scene.cpp:300-327),
-// shared by the two refinement kernels (kernel_optimize.hip: lane-bound patches, low latency;
-// kernel_stream.hip: patches streaming through per-block queues, high throughput).
+// pipeline.hpp -- the image-list passes of PatchOptimizer::runOptimization (reference
+// src/hpmvs/PatchOptimizer.cpp:105-284) and Scene::getColor(patch) (src/hpmvs/Scene.cpp:300-327) as
+// WAVE-COOPERATIVE device code: one request (one patch's list) at a time, lane k standing for list entry k
+// (or for covisible view k of a 64-wide chunk).
+//
+// Rounds 1-2 ran these passes as per-lane scalar code inside phase A of the refinement kernel: addImages walks up
+// to 49 covisible views serially (float64 log2, three divisions and ~30 scattered loads per view), sortImages is
+// O(m^2) over scratch-memory arrays, assureImageAngles evaluates up to m^2/2 acosf -- 87 k wave-cycles per call
+// while the other lanes of the wavefront waited: 14 % of the kernel at BASELINE configs[2]
+// (profiles/r03/phase_c2_rows.txt).  Here the per-entry work of a pass runs on 64 lanes at once and the
+// order-dependent parts (append order, greedy selection, stable compaction) are ballots, ranks and uniform
+// loops.  Every float operation per entry is the reference's, in the reference's order, so the resulting
+// lists are identical.
+//
+// All functions must be called by all 64 lanes with wave-uniform arguments (the caller reads the requesting
+// lane's values with v_readlane); `id` is the register copy of the list: lane k < nimg holds image id k.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -12,10 +24,13 @@ namespace hpmvs {
 
 namespace {
 
-enum Op { OP_NONE = 0, OP_OBJ = 1, OP_INCC = 2, OP_REFSUM = 3 };
+enum Op { OP_NONE = 0, OP_OBJ = 1, OP_INCC = 2, OP_REFSUM = 3,
+          OPL_ADD = 4, OPL_F1 = 5, OPL_F2 = 6, OPL_F3 = 7 };  // >= OPL_ADD: list services (this file)
 enum Stage {
-    S_FETCH = 0, S_F1, S_BQ, S_F2, S_RS, S_F3, S_IDLE
+    S_FETCH = 0, S_ADD1, S_F1, S_F1B, S_BQ, S_ADD2, S_F2, S_F2B, S_RS, S_F3, S_F3B, S_IDLE
 };
+
+struct U3 { float x, y, z; };  // a wave-uniform 3-vector
 
 __device__ __forceinline__ void ray_to_cam(const DevView& V, const float* c, float* ray) {
     // (camera.center_ - pCenter).normalized() on 4-vectors whose w components cancel
@@ -23,51 +38,84 @@ __device__ __forceinline__ void ray_to_cam(const DevView& V, const float* c, flo
     normalized3f(d, ray);
 }
 
-// PatchOptimizer::addImages (PatchOptimizer.cpp:225-258).  Returns the new count, or -1 on overflow.
-__device__ __noinline__ int add_images(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg, const float* c,
-                          const float* n, float scale) {
+__device__ __forceinline__ unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
+
+// stable compaction of the register list: entry k survives iff bit k of `keep`; returns the new count
+__device__ __forceinline__ int compact_list(int& id, unsigned long long keep) {
+    const int lane = lane_id();
+    int nid = -1, m = 0;
+    for (unsigned long long t = keep; t; t &= t - 1ull, m++) {
+        const int v = bcast_i(id, __ffsll((long long)t) - 1);
+        if (lane == m) nid = v;
+    }
+    id = nid;
+    return m;
+}
+
+// minimum over the lanes of `v` (lanes that do not take part pass +inf)
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v = fminf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+// PatchOptimizer::addImages (PatchOptimizer.cpp:225-258): the test one covisible view has to pass
+__device__ __forceinline__ bool add_images_test(const DevView& V, const DevOptions& o, const float* c, const float* n, float scale) {
+    float ray[3];
+    ray_to_cam(V, c, ray);
+    if (dot3f(ray, n) < o.cos_max_f) return false;
+    // Camera::getLevel (Camera.cpp:92-95) then std::round
+    const float dd[3] = {c[0] - V.center[0], c[1] - V.center[1], c[2] - V.center[2]};
+    const float fz = sqrtf(dot3f(dd, dd));
+    const float lv = (float)log2((double)(scale * V.fsum) / (2.0 * (double)fz));
+    const int il = (int)roundf(lv);
+    if (il < o.MINLEVEL || il >= o.MAXLEVEL - 2) return false;
+    float P[12];
+    for (int k = 0; k < 12; k++) P[k] = V.P0[k];
+    float u, v;
+    project0(P, c[0], c[1], c[2], u, v);
+    const float s = __int_as_float((127 - il) << 23);
+    u *= s; v *= s;
+    if (u < 0.0f || (float)(V.w[il] - 1) <= u || v < 0.0f || (float)(V.h[il] - 1) <= v) return false;
+    return true;
+}
+
+// addImages on the list at `row` (global workspace, nimg entries): the covisible views of image 0 that are not
+// attached yet and pass the test are appended in covisibility order.  Returns the new count, -1 on overflow.
+__device__ __noinline__ int coop_add_images(DevScene sc, DevOptions o, uint16_t* row, int nimg, U3 c_, U3 n_, float scale) {
     if (nimg <= 0) return 0;
-    const int ref = row[0];
+    const int lane = lane_id();
+    const float c[3] = {c_.x, c_.y, c_.z}, n[3] = {n_.x, n_.y, n_.z};
+    const int id = (lane < nimg) ? (int)row[lane] : -1;
+    const int ref = bcast_i(id, 0);
     const int existing = nimg;
     const int beg = sc.covis_off[ref], end = sc.covis_off[ref + 1];
-    for (int ci = beg; ci < end; ci++) {
-        const int cv = sc.covis[ci];
+    for (int base = beg; base < end; base += 64) {
+        const int ci = base + lane;
+        const bool valid = ci < end;
+        const int cv = valid ? sc.covis[ci] : -2;
         bool found = false;
-        for (int k = 0; k < existing; k++) found |= (row[k] == cv);
-        if (found) continue;
-        const DevView& V = sc.views[cv];
-        float ray[3];
-        ray_to_cam(V, c, ray);
-        if (dot3f(ray, n) < o.cos_max_f) continue;
-        // Camera::getLevel (Camera.cpp:92-95) then std::round
-        const float dd[3] = {c[0] - V.center[0], c[1] - V.center[1], c[2] - V.center[2]};
-        const float fz = sqrtf(dot3f(dd, dd));
-        const float lv = (float)log2((double)(scale * V.fsum) / (2.0 * (double)fz));
-        const int il = (int)roundf(lv);
-        if (il < o.MINLEVEL || il >= o.MAXLEVEL - 2) continue;
-        float P[12];
-        for (int k = 0; k < 12; k++) P[k] = V.P0[k];
-        float u, v;
-        project0(P, c[0], c[1], c[2], u, v);
-        const float s = __int_as_float((127 - il) << 23);
-        u *= s; v *= s;
-        if (u < 0.0f || (float)(V.w[il] - 1) <= u || v < 0.0f || (float)(V.h[il] - 1) <= v) continue;
-        if (nimg >= kMaxImages) return -1;
-        row[nimg++] = (uint16_t)cv;
+        for (int k = 0; k < existing; k++) found |= (bcast_i(id, k) == cv);
+        bool pass = false;
+        if (valid && !found) pass = add_images_test(sc.views[cv], o, c, n, scale);
+        const unsigned long long m = __ballot(pass);
+        const int cnt = __popcll(m);
+        if (nimg + cnt > kMaxImages) return -1;
+        if (pass) row[nimg + __popcll(m & lanes_below(lane))] = (uint16_t)cv;
+        nimg += cnt;
     }
     return nimg;
 }
 
-// PatchOptimizer::sortImages + getAngleWeightedScales (PatchOptimizer.cpp:183-223, 260-284).
-// Rewrites the row; returns the new count (the reference ignores the boolean result).
-__device__ __noinline__ int sort_images(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg, const float* c,
-                           const float* n, float scale) {
-    uint16_t idx[kMaxImages];
-    float ws[kMaxImages];
-    float rays[kMaxImages][3];
-    int m = 0;
+// PatchOptimizer::sortImages + getAngleWeightedScales (PatchOptimizer.cpp:183-223, 260-284) on the register
+// list; returns the new count (the reference ignores the boolean result).
+__device__ __forceinline__ int coop_sort_images(const DevScene& sc, const DevOptions& o, int& id, int nimg, const float* c,
+                                                const float* n, float scale) {
+    const int lane = lane_id();
+    bool cand = false;
+    float w = 0.0f, ray[3] = {0.0f, 0.0f, 0.0f};
     if (nimg > 0) {
-        const DevView& V0 = sc.views[row[0]];
+        const DevView& V0 = sc.views[bcast_i(id, 0)];
         const float dd[3] = {c[0] - V0.center[0], c[1] - V0.center[1], c[2] - V0.center[2]};
         const float fz0 = sqrtf(dot3f(dd, dd));
         int refLevel = (int)roundf((float)log2((double)(scale * V0.fsum) / (2.0 * (double)fz0)));
@@ -75,87 +123,76 @@ __device__ __noinline__ int sort_images(const DevScene& sc, const DevOptions& o,
         refLevel = refLevel > 0 ? refLevel : 0;
         float nn[3];
         normalized3f(n, nn);
-        for (int k = 0; k < nimg; k++) {
-            const DevView& V = sc.views[row[k]];
-            float ray[3];
+        if (lane < nimg) {
+            const DevView& V = sc.views[id];
             ray_to_cam(V, c, ray);
             const float cosa = dot3f(ray, nn);
             if (cosa > 0.0f) {
-                idx[m] = row[k];
-                rays[m][0] = ray[0]; rays[m][1] = ray[1]; rays[m][2] = ray[2];
+                cand = true;
                 // Camera::getScale (Camera.cpp:83-90)
                 const float e[3] = {c[0] - V.center[0], c[1] - V.center[1], c[2] - V.center[2]};
                 const float fz = sqrtf(dot3f(e, e));
                 const float sc_ = (V.fsum == 0.0f) ? 1.0f : (float)(2.0 * (double)fz * (double)(1 << refLevel) / (double)V.fsum);
-                ws[m] = sc_ / cosa;
-                m++;
+                w = sc_ / cosa;
             }
         }
     }
-    if (m < 2) return 0;  // pImages_ was cleared
-    ws[0] = 0.0f;
+    unsigned long long alive = __ballot(cand);
+    if (__popcll(alive) < 2) { id = -1; return 0; }  // pImages_ was cleared
+    if (lane == __ffsll((long long)alive) - 1) w = 0.0f;  // the first candidate keeps its place
     const float thr = o.sort_thr;
-    int out = 0;
-    while (m > 0) {
-        int best = 0;
-        for (int j = 1; j < m; j++)
-            if (ws[j] < ws[best]) best = j;
-        row[out++] = idx[best];
-        const float rb[3] = {rays[best][0], rays[best][1], rays[best][2]};
-        int q = 0;
-        for (int j = 0; j < m; j++) {
-            if (j == best) continue;
-            const float ftmp = fminf(thr, fmaxf(thr / 2.0f, 1.0f - dot3f(rb, rays[j])));
-            const float w = ws[j] * (thr / ftmp);
-            idx[q] = idx[j];
-            rays[q][0] = rays[j][0]; rays[q][1] = rays[j][1]; rays[q][2] = rays[j][2];
-            ws[q] = w;
-            q++;
+    int out = 0, nid = -1;
+    while (alive) {
+        // greedy pick: the smallest weight, the earliest entry among equals
+        const bool mine = (alive >> lane) & 1ull;
+        const float mn = wave_min_f32(mine ? w : __int_as_float(0x7f800000));
+        const int best = __ffsll((long long)__ballot(mine && w == mn)) - 1;
+        const int bid = bcast_i(id, best);
+        if (lane == out) nid = bid;
+        out++;
+        const float rb[3] = {bcast_f(ray[0], best), bcast_f(ray[1], best), bcast_f(ray[2], best)};
+        alive &= ~(1ull << best);
+        if ((alive >> lane) & 1ull) {
+            const float ftmp = fminf(thr, fmaxf(thr / 2.0f, 1.0f - dot3f(rb, ray)));
+            w = w * (thr / ftmp);
         }
-        m = q;
     }
+    id = nid;
     return out;
 }
 
 // PatchOptimizer::assureImageAngles (PatchOptimizer.cpp:105-123)
-__device__ __noinline__ bool assure_image_angles(const DevScene& sc, const DevOptions& o, const uint16_t* row, int nimg,
-                                    const float* c) {
+__device__ __forceinline__ bool coop_assure_image_angles(const DevScene& sc, const DevOptions& o, int id, int nimg, const float* c) {
+    const int lane = lane_id();
+    float rj[3] = {0.0f, 0.0f, 0.0f};
+    if (lane < nimg) ray_to_cam(sc.views[id], c, rj);
     for (int ii = 0; ii < nimg - 1; ii++) {
-        float ri[3];
-        ray_to_cam(sc.views[row[ii]], c, ri);
-        for (int jj = ii + 1; jj < nimg; jj++) {
-            float rj[3];
-            ray_to_cam(sc.views[row[jj]], c, rj);
+        const float ri[3] = {bcast_f(rj[0], ii), bcast_f(rj[1], ii), bcast_f(rj[2], ii)};
+        bool hit = false;
+        if (lane > ii && lane < nimg) {
             const float a = acosf(dot3f(ri, rj));
-            if (a < o.MAX_ANGLE && a > o.MIN_ANGLE) return true;
+            hit = a < o.MAX_ANGLE && a > o.MIN_ANGLE;
         }
+        if (__any(hit)) return true;
     }
     return false;
 }
 
 // PatchOptimizer::filterImagesByAngle (PatchOptimizer.cpp:125-136)
-__device__ __noinline__ int filter_images_by_angle(const DevScene& sc, const DevOptions& o, uint16_t* row, int nimg,
-                                      const float* c, const float* n) {
-    int m = 0;
-    for (int k = 0; k < nimg; k++) {
+__device__ __forceinline__ int coop_filter_images_by_angle(const DevScene& sc, const DevOptions& o, int& id, int nimg,
+                                                           const float* c, const float* n) {
+    bool keep = false;
+    if (lane_id() < nimg) {
         float ray[3];
-        ray_to_cam(sc.views[row[k]], c, ray);
-        if (dot3f(ray, n) > o.cos_max_f) row[m++] = row[k];
+        ray_to_cam(sc.views[id], c, ray);
+        keep = dot3f(ray, n) > o.cos_max_f;
     }
-    return m;
-}
-
-// keep image 0 and the images whose bit is set (PatchOptimizer.cpp:144-151)
-__device__ int apply_keep_mask(uint16_t* row, int nimg, unsigned long long keep) {
-    int m = 1;
-    for (int i = 1; i < nimg; i++)
-        if ((keep >> i) & 1ull) row[m++] = row[i];
-    return m;
+    return compact_list(id, __ballot(keep));
 }
 
 // Scene::getColor(const Patch3d&) (Scene.cpp:300-327): bilinear colour at the projected centre in
 // every attached image, median by norm (darkest if the median is brighter than 250).
-__device__ void colour_at(const DevView& V, const float* c, float scale, float* rgb) {
+__device__ __forceinline__ void colour_at(const DevView& V, const float* c, float scale, float* rgb) {
     const float dd[3] = {c[0] - V.center[0], c[1] - V.center[1], c[2] - V.center[2]};
     const float fz = sqrtf(dot3f(dd, dd));
     const int lvl = level_clamped(scale, V.fsum, fz, V.n_levels - 1);
@@ -179,57 +216,91 @@ __device__ void colour_at(const DevView& V, const float* c, float scale, float* 
     }
 }
 
-__device__ __noinline__ void patch_colour(const DevScene& sc, const uint16_t* row, int nimg, const float* c, float scale,
-                             float* out) {
-    float norms[kMaxImages];
-    for (int k = 0; k < nimg; k++) {
-        float rgb[3];
-        colour_at(sc.views[row[k]], c, scale, rgb);
-        norms[k] = sqrtf(dot3f(rgb, rgb));
+__device__ __forceinline__ U3 coop_patch_colour(const DevScene& sc, int id, int nimg, const float* c, float scale) {
+    const int lane = lane_id();
+    float rgb[3] = {0.0f, 0.0f, 0.0f}, norm = 0.0f;
+    if (lane < nimg) {
+        colour_at(sc.views[id], c, scale, rgb);
+        norm = sqrtf(dot3f(rgb, rgb));
     }
     // rank selection instead of std::sort: element of rank nimg/2 and the minimum
-    const int want = nimg / 2;
-    int med = 0, mn = 0;
-    for (int k = 0; k < nimg; k++) {
-        int rank = 0;
-        for (int j = 0; j < nimg; j++) rank += (norms[j] < norms[k]) || (norms[j] == norms[k] && j < k);
-        if (rank == want) med = k;
-        if (rank == 0) mn = k;
+    int rank = 0;
+    for (int j = 0; j < nimg; j++) {
+        const float nj = bcast_f(norm, j);
+        rank += (nj < norm) || (nj == norm && j < lane);
     }
-    const int pick = (norms[med] > 250.0f) ? mn : med;
-    colour_at(sc.views[row[pick]], c, scale, out);
+    const int want = nimg / 2;
+    const unsigned long long mm = __ballot(lane < nimg && rank == want), m0 = __ballot(lane < nimg && rank == 0);
+    const int med = mm ? __ffsll((long long)mm) - 1 : 0, mn = m0 ? __ffsll((long long)m0) - 1 : 0;
+    const int pick = (bcast_f(norm, med) > 250.0f) ? mn : med;
+    return U3{bcast_f(rgb[0], pick), bcast_f(rgb[1], pick), bcast_f(rgb[2], pick)};
+}
+
+// ---- the three list services between the photometric requests of runOptimization (PatchOptimizer.cpp:48-76)
+struct ListResult { int nimg; int fail; U3 rgb; };
+
+__device__ __forceinline__ void store_list(uint16_t* row, int id, int nimg) {
+    if (lane_id() < nimg) row[lane_id()] = (uint16_t)id;
+}
+
+// filterImagesNCC(alpha1)'s removal -> sortImages -> assureImageAngles (PatchOptimizer.cpp:52-56, 144-151)
+__device__ __noinline__ ListResult coop_list_f1(DevScene sc, DevOptions o, uint16_t* row, int nimg, unsigned long long keep,
+                                               U3 c_, U3 n_, float scale) {
+    const int lane = lane_id();
+    const float c[3] = {c_.x, c_.y, c_.z}, n[3] = {n_.x, n_.y, n_.z};
+    ListResult r;
+    r.fail = 0; r.rgb = U3{0.0f, 0.0f, 0.0f};
+    int id = (lane < nimg) ? (int)row[lane] : -1;
+    const unsigned long long all = nimg >= 64 ? ~0ull : ((1ull << nimg) - 1ull);
+    nimg = compact_list(id, (keep | 1ull) & all);  // image 0 always stays
+    r.nimg = nimg;
+    if (nimg < o.MIN_IMAGES_PER_PATCH) { r.fail = 2; return r; }
+    nimg = coop_sort_images(sc, o, id, nimg, c, n, scale);
+    r.nimg = nimg;
+    if (!coop_assure_image_angles(sc, o, id, nimg, c)) { r.fail = 3; return r; }
+    if (nimg < o.MIN_IMAGES_PER_PATCH) { r.fail = 4; return r; }
+    store_list(row, id, nimg);
+    return r;
+}
+
+// filterImagesNCC(alpha2)'s removal -> filterImagesByAngle -> assureImageAngles (PatchOptimizer.cpp:62-67)
+__device__ __noinline__ ListResult coop_list_f2(DevScene sc, DevOptions o, uint16_t* row, int nimg, unsigned long long keep,
+                                               U3 c_, U3 n_) {
+    const int lane = lane_id();
+    const float c[3] = {c_.x, c_.y, c_.z}, n[3] = {n_.x, n_.y, n_.z};
+    ListResult r;
+    r.fail = 0; r.rgb = U3{0.0f, 0.0f, 0.0f};
+    int id = (lane < nimg) ? (int)row[lane] : -1;
+    const unsigned long long all = nimg >= 64 ? ~0ull : ((1ull << nimg) - 1ull);
+    nimg = compact_list(id, (keep | 1ull) & all);
+    r.nimg = nimg;
+    if (nimg < o.MIN_IMAGES_PER_PATCH) { r.fail = 6; return r; }
+    nimg = coop_filter_images_by_angle(sc, o, id, nimg, c, n);
+    r.nimg = nimg;
+    if (nimg < o.MIN_IMAGES_PER_PATCH) { r.fail = 7; return r; }
+    if (!coop_assure_image_angles(sc, o, id, nimg, c)) { r.fail = 8; return r; }
+    store_list(row, id, nimg);
+    return r;
+}
+
+// the last filterImagesNCC(alpha2)'s removal (PatchOptimizer.cpp:73) and Scene::getColor(patch) (PatchOptimizer.cpp:100)
+__device__ __noinline__ ListResult coop_list_f3(DevScene sc, DevOptions o, uint16_t* row, int nimg, unsigned long long keep,
+                                               U3 c_, float scale, int max_images, int want_colour) {
+    const int lane = lane_id();
+    const float c[3] = {c_.x, c_.y, c_.z};
+    ListResult r;
+    r.fail = 0; r.rgb = U3{0.0f, 0.0f, 0.0f};
+    int id = (lane < nimg) ? (int)row[lane] : -1;
+    const unsigned long long all = nimg >= 64 ? ~0ull : ((1ull << nimg) - 1ull);
+    nimg = compact_list(id, (keep | 1ull) & all);
+    r.nimg = nimg;
+    if (nimg < o.MIN_IMAGES_PER_PATCH) { r.fail = 9; return r; }
+    if (nimg > max_images) { r.fail = 100; return r; }
+    store_list(row, id, nimg);
+    if (want_colour) r.rgb = coop_patch_colour(sc, id, nimg, c, scale);
+    return r;
 }
 
 }  // namespace
-
-// The out-of-line helpers take pointers; handing them the kernel's long-lived per-lane arrays would pin those
-// arrays in scratch memory for the whole kernel (an escaping address defeats register promotion, and every
-// later c[k] / n[k] becomes a scratch access of several hundred cycles).  Short-lived copies escape instead;
-// the same holds for the kernel arguments sc / o, which are copied per call (by-value parameters) so that the
-// kernel's own copies stay in scalar registers.
-struct F3 { float x, y, z; };
-#define HPMVS_F3(a) F3{(a)[0], (a)[1], (a)[2]}
-__device__ __forceinline__ int add_images_v(DevScene sc, DevOptions o, uint16_t* row, int nimg, F3 c, F3 n, float scale) {
-    const float cc[3] = {c.x, c.y, c.z}, nn[3] = {n.x, n.y, n.z};
-    return add_images(sc, o, row, nimg, cc, nn, scale);
-}
-__device__ __forceinline__ int sort_images_v(DevScene sc, DevOptions o, uint16_t* row, int nimg, F3 c, F3 n, float scale) {
-    const float cc[3] = {c.x, c.y, c.z}, nn[3] = {n.x, n.y, n.z};
-    return sort_images(sc, o, row, nimg, cc, nn, scale);
-}
-__device__ __forceinline__ bool assure_image_angles_v(DevScene sc, DevOptions o, const uint16_t* row, int nimg, F3 c) {
-    const float cc[3] = {c.x, c.y, c.z};
-    return assure_image_angles(sc, o, row, nimg, cc);
-}
-__device__ __forceinline__ int filter_images_by_angle_v(DevScene sc, DevOptions o, uint16_t* row, int nimg, F3 c, F3 n) {
-    const float cc[3] = {c.x, c.y, c.z}, nn[3] = {n.x, n.y, n.z};
-    return filter_images_by_angle(sc, o, row, nimg, cc, nn);
-}
-__device__ __forceinline__ F3 patch_colour_v(DevScene sc, const uint16_t* row, int nimg, F3 c, float scale) {
-    const float cc[3] = {c.x, c.y, c.z};
-    float rgb[3];
-    patch_colour(sc, row, nimg, cc, scale, rgb);
-    return F3{rgb[0], rgb[1], rgb[2]};
-}
 
 }  // namespace hpmvs
