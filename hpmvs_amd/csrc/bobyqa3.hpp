@@ -97,58 +97,64 @@ enum {
 //   the BQ_P patches a wavefront owns lives in LDS as [index][slot], so that the lanes of a wave
 //   touch consecutive 8-byte words (conflict-free ds_read_b64 / ds_write_b64) and nothing of the
 //   ~1.4 KB per patch goes through scratch / HBM.
-enum {  // float64 slots: arrays first (names as in Powell's paper / bobyqb_), then scalars
+enum {  // float64 slots: arrays first (names as in Powell's paper / bobyqb_), then scalars.
+    // 164 doubles + 13 ints = 1364 B per patch: 15 patches per wavefront x 8 wavefronts fill the 160 KB of a CU
+    // exactly.  Slots are shared where two quantities are never alive at the same time (each pair checked
+    // against every read/write site below; the self-tests against the genuine library cover all of them):
+    //   xfinal = xeval   both are x * sc of the point in hand: xeval while the run is going, xfinal once it is over
+    //   gnew   = xalt    gnew lives from trsbox to the end of label 60; xalt from altmov (label 210) to label 230
+    //   stepa, stepb, fbeg = diffa, diffb, diffc   prelim_ only / main loop only (zeroed when prelim_ ends)
+    //   adelt  = distsq  distsq is consumed by label 650 before that label sets adelt for altmov
+    // The scaled trial point `x` (bobyqa.c's X array) is a local wherever it is formed.
     O_xeval = 0,
-    O_xfinal = 3,
-    O_sc = 6,
-    O_xl = 9,
-    O_xu = 12,
-    O_x = 15,
-    O_xbase = 18,
-    O_xopt = 21,
-    O_gopt = 24,
-    O_sl = 27,
-    O_su = 30,
-    O_xnew = 33,
-    O_xalt = 36,
-    O_d = 39,
-    O_gnew = 42,
-    O_xpt = 45,
-    O_fval = 66,
-    O_pq = 73,
-    O_hq = 80,
-    O_bmat = 86,
-    O_zmat = 116,
-    O_vlag = 137,
-    O_wsuma = 147,
-    O_minf = 154,
-    O_rhobeg = 155,
-    O_rhoend = 156,
-    O_rho = 157,
-    O_delta = 158,
-    O_diffa = 159,
-    O_diffb = 160,
-    O_diffc = 161,
-    O_dsq = 162,
-    O_crvmin = 163,
-    O_dnorm = 164,
-    O_xoptsq = 165,
-    O_ratio = 166,
-    O_adelt = 167,
-    O_alpha = 168,
-    O_cauchy = 169,
-    O_beta = 170,
-    O_denom = 171,
-    O_fsave = 172,
-    O_distsq = 173,
-    O_fbeg = 174,
-    O_stepa = 175,
-    O_stepb = 176,
-    BQ_ND = 177,
+    O_xfinal = O_xeval,
+    O_sc = 3,
+    O_xl = 6,
+    O_xu = 9,
+    O_xbase = 12,
+    O_xopt = 15,
+    O_gopt = 18,
+    O_sl = 21,
+    O_su = 24,
+    O_xnew = 27,
+    O_xalt = 30,
+    O_gnew = O_xalt,
+    O_d = 33,
+    O_xpt = 36,
+    O_fval = 57,
+    O_pq = 64,
+    O_hq = 71,
+    O_bmat = 77,
+    O_zmat = 107,
+    O_vlag = 128,
+    O_wsuma = 138,
+    O_minf = 145,
+    O_rhobeg = 146,
+    O_rhoend = 147,
+    O_rho = 148,
+    O_delta = 149,
+    O_diffa = 150,
+    O_diffb = 151,
+    O_diffc = 152,
+    O_stepa = O_diffa,
+    O_stepb = O_diffb,
+    O_fbeg = O_diffc,
+    O_dsq = 153,
+    O_crvmin = 154,
+    O_dnorm = 155,
+    O_xoptsq = 156,
+    O_ratio = 157,
+    O_distsq = 158,
+    O_adelt = O_distsq,
+    O_alpha = 159,
+    O_cauchy = 160,
+    O_beta = 161,
+    O_denom = 162,
+    O_fsave = 163,
+    BQ_ND = 164,
     // rescue_ state (bobyqa.c:143-742) overlays vectors that are dead between label 190 and the next
     // trust-region / geometry step: xnew, xalt, d are recomputed by trsbox / altmov before they are read
-    // again, wsuma only lives from label 230 to the evaluation that follows it.  (15 doubles per patch
-    // = one more patch per wavefront in LDS.)
+    // again, wsuma only lives from label 230 to the evaluation that follows it.
     O_ptsaux = O_xnew,   // 6 = xnew[3] + xalt[3]
     O_ptsid = O_wsuma,   // 7
     O_fbase_r = O_d,
@@ -254,9 +260,8 @@ BQ_HD void set_x_from(BqRef B, int p_off) {  // p_off: state offset of the 3-vec
         double v = mn(mx(BQ_V(xl, i), BQ_V(xbase, i) + pi), BQ_V(xu, i));
         if (pi == BQ_V(sl, i)) v = BQ_V(xl, i);
         if (pi == BQ_V(su, i)) v = BQ_V(xu, i);
-        BQ_V(x, i) = v;
+        BQ_V(xeval, i) = v * BQ_V(sc, i);  // nlopt_unscale (util/rescale.c:55-60)
     }
-    for (int i = 0; i < 3; i++) BQA(xeval, i) = BQA(x, i) * BQA(sc, i);  // nlopt_unscale (util/rescale.c:55-60)
 }
 
 // ---------------------------------------------------------------- prelim_ (bobyqa.c:1713-1952)
@@ -1338,10 +1343,9 @@ BQ_HD_NOINLINE int step_label(BqRef B, int label) {
                 double v = mn(mx(BQ_V(xl, i), BQ_V(xbase, i) + BQ_V(xopt, i)), BQ_V(xu, i));
                 if (BQ_V(xopt, i) == BQ_V(sl, i)) v = BQ_V(xl, i);
                 if (BQ_V(xopt, i) == BQ_V(su, i)) v = BQ_V(xu, i);
-                BQ_V(x, i) = v;
+                BQ_V(xfinal, i) = v * BQ_V(sc, i);
             }
             BQS(minf) = BQ_FVAL(BQN(kopt));
-            for (int i = 0; i < 3; i++) BQA(xfinal, i) = BQA(x, i) * BQA(sc, i);
             BQN(phase) = PH_DONE;
             return LRET_DONE;
         }
@@ -1429,7 +1433,7 @@ BQ_HD_NOINLINE int after_eval(BqRef B, double f) {
         BQN(rc) = BQ_XTOL_REACHED;
         if (BQS(fsave) < BQ_FVAL(BQN(kopt))) {
             BQS(minf) = f;
-            for (int i = 0; i < 3; i++) BQA(xfinal, i) = BQA(x, i) * BQA(sc, i);
+            // xfinal = x * sc of the point just evaluated: that is what the shared xeval / xfinal slot holds
             BQN(phase) = PH_DONE;
             return LRET_DONE;
         }
@@ -1601,8 +1605,9 @@ BQ_HD_NOINLINE int bq_start(BqRef B, const double* x0, const double* lb, const d
     for (int i = 0; i < 3; i++) BQA(sc, i) = 1.0;
     if (!(dx[1] == dx[0] && dx[2] == dx[1]))
         for (int i = 1; i < 3; i++) BQA(sc, i) = dx[i] / dx[0];
+    double xs[3];  // the scaled starting point (bobyqa.c's X)
     for (int i = 0; i < 3; i++) {
-        BQA(x, i) = x0[i] / BQA(sc, i);
+        xs[i] = x0[i] / BQA(sc, i);
         BQA(xl, i) = lb[i] / BQA(sc, i);
         BQA(xu, i) = ub[i] / BQA(sc, i);
         if (BQA(xl, i) > BQA(xu, i)) { const double t = BQA(xl, i); BQA(xl, i) = BQA(xu, i); BQA(xu, i) = t; }
@@ -1612,18 +1617,18 @@ BQ_HD_NOINLINE int bq_start(BqRef B, const double* x0, const double* lb, const d
     for (int j = 0; j < 3; j++) {
         const double temp = BQA(xu, j) - BQA(xl, j);
         if (temp < BQS(rhobeg) + BQS(rhobeg)) { BQN(rc) = BQ_INVALID_ARGS; BQN(phase) = bq::PH_DONE; return BQ_DONE; }
-        BQA(sl, j) = BQA(xl, j) - BQA(x, j);
-        BQA(su, j) = BQA(xu, j) - BQA(x, j);
+        BQA(sl, j) = BQA(xl, j) - xs[j];
+        BQA(su, j) = BQA(xu, j) - xs[j];
         if (BQA(sl, j) >= -BQS(rhobeg)) {
-            if (BQA(sl, j) >= 0.0) { BQA(x, j) = BQA(xl, j); BQA(sl, j) = 0.0; BQA(su, j) = temp; }
-            else { BQA(x, j) = BQA(xl, j) + BQS(rhobeg); BQA(sl, j) = -BQS(rhobeg); BQA(su, j) = bq::mx(BQA(xu, j) - BQA(x, j), BQS(rhobeg)); }
+            if (BQA(sl, j) >= 0.0) { xs[j] = BQA(xl, j); BQA(sl, j) = 0.0; BQA(su, j) = temp; }
+            else { xs[j] = BQA(xl, j) + BQS(rhobeg); BQA(sl, j) = -BQS(rhobeg); BQA(su, j) = bq::mx(BQA(xu, j) - xs[j], BQS(rhobeg)); }
         } else if (BQA(su, j) <= BQS(rhobeg)) {
-            if (BQA(su, j) <= 0.0) { BQA(x, j) = BQA(xu, j); BQA(sl, j) = -temp; BQA(su, j) = 0.0; }
-            else { BQA(x, j) = BQA(xu, j) - BQS(rhobeg); BQA(sl, j) = bq::mn(BQA(xl, j) - BQA(x, j), -BQS(rhobeg)); BQA(su, j) = BQS(rhobeg); }
+            if (BQA(su, j) <= 0.0) { xs[j] = BQA(xu, j); BQA(sl, j) = -temp; BQA(su, j) = 0.0; }
+            else { xs[j] = BQA(xu, j) - BQS(rhobeg); BQA(sl, j) = bq::mn(BQA(xl, j) - xs[j], -BQS(rhobeg)); BQA(su, j) = BQS(rhobeg); }
         }
     }
     // prelim_ initialisation (bobyqa.c:1790-1822)
-    for (int j = 0; j < 3; j++) { BQA(xbase, j) = BQA(x, j); BQA(xopt, j) = 0; BQA(gopt, j) = 0; BQA(xnew, j) = 0; BQA(xalt, j) = 0; BQA(d, j) = 0; BQA(gnew, j) = 0; }
+    for (int j = 0; j < 3; j++) { BQA(xbase, j) = xs[j]; BQA(xopt, j) = 0; BQA(gopt, j) = 0; BQA(xnew, j) = 0; BQA(xalt, j) = 0; BQA(d, j) = 0; BQA(gnew, j) = 0; }
     for (int k = 0; k < 21; k++) { BQA(xpt, k) = 0.0; BQA(zmat, k) = 0.0; }
     for (int k = 0; k < 30; k++) BQA(bmat, k) = 0.0;
     for (int k = 0; k < 6; k++) BQA(hq, k) = 0.0;

@@ -29,9 +29,9 @@
 #include "prof.h"
 #define BQ_STATE_LDS 1
 #ifndef BQ_P
-#define BQ_P 13
+#define BQ_P 15
 #endif
-// Single-wavefront workgroups: 13 x 1468 B of optimiser state = 19.1 KB of LDS, 8 per CU; the photometric
+// Single-wavefront workgroups: 15 x 1364 B of optimiser state = 20.0 KB of LDS (exactly 1/8 of a CU), 8 per CU; the photometric
 // evaluator (wave_eval_rows) needs no LDS.  (The image lists, touched a dozen times per patch, live in a
 // global-memory workspace.  Multi-wavefront workgroups -- sharing staging buffers under a lock, or scheduling the
 // BOBYQA blocks of all their slots cooperatively -- were measured 5-25 % slower in round 1)
