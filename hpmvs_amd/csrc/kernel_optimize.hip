@@ -25,17 +25,32 @@
 //   against 13 GB of algorithmic image bytes -- profiles/r01a_scratch_state.)
 #include <hip/hip_runtime.h>
 
-// optimiser state of the kP patches a wavefront owns lives in LDS (see bobyqa3.hpp)
+// optimiser state of the kP patches a wavefront owns lives in LDS while the wavefront is in phase A (bobyqa3.hpp)
 #include "prof.h"
 #define BQ_STATE_LDS 1
+#define BQ_STATE_LDS_EXTERN 1
 #ifndef BQ_P
-#define BQ_P 15
+#define BQ_P 29
 #endif
-// Single-wavefront workgroups: 15 x 1364 B of optimiser state = 20.0 KB of LDS (exactly 1/8 of a CU), 8 per CU; the photometric
-// evaluator (wave_eval_rows) needs no LDS.  (The image lists, touched a dozen times per patch, live in a
-// global-memory workspace.  Multi-wavefront workgroups -- sharing staging buffers under a lock, or scheduling the
-// BOBYQA blocks of all their slots cooperatively -- were measured 5-25 % slower in round 1)
+// LDS TIME-SHARING.  The float64 optimiser blocks of phase A cost about the same per round whether 13 or 29 lanes
+// run them (measured: 146 k cycles at 14 lanes, 175 k at 28), so patches per wavefront is THE lever -- and the
+// 160 KB of LDS per CU, at 1364 B of optimiser state per patch, is what bounds it.  But a wavefront needs its
+// optimiser state only in phase A; in phase B (the photometric requests, no LDS) it is dead weight.  So a
+// workgroup is TWO wavefronts that share ONE state region of 29 slots (39.6 KB, four workgroups per CU): the
+// wavefront that enters phase A takes the region (LDS lock), pages its 29 states in from a per-wavefront
+// parking buffer in global memory (40 KB, coalesced 16-byte accesses, ~1 % of a round), runs phase A 29 lanes
+// wide, pages out and releases; its partner does the same while the first one is in phase B.  Twice the
+// lanes per optimiser block at the same occupancy (8 wavefronts per CU).
 #define BQ_SLOTS BQ_P
+#define HPMVS_STATE_ND 164
+#define HPMVS_STATE_NI 13
+#define HPMVS_REGION_BYTES (HPMVS_STATE_ND * 8 * BQ_P + HPMVS_STATE_NI * 4 * BQ_P)
+#define HPMVS_REGION_KIB ((HPMVS_REGION_BYTES + 1023) / 1024)  // paged in 1 KiB pieces (one LDS-DMA instruction each)
+#define HPMVS_REGION_16 (HPMVS_REGION_KIB * 64)
+__shared__ uint4 hpmvs_region[HPMVS_REGION_16];
+__shared__ int hpmvs_lock[2];  // [0]: 0 = region free, 1 + w = held by wavefront w; [1]: bit w = wavefront w has left
+#define bq_lds_d ((double*)hpmvs_region)
+#define bq_lds_i ((int*)((char*)hpmvs_region + HPMVS_STATE_ND * 8 * BQ_P))
 #include "bobyqa3.hpp"
 #include "launch.h"
 #include "photometric.hpp"
@@ -43,29 +58,73 @@
 
 namespace hpmvs {
 
+static_assert(BQ_ND == HPMVS_STATE_ND && BQ_NI == HPMVS_STATE_NI, "state region sized for another layout");
+
 namespace {
 
 constexpr int kP = BQ_P;  // patches ("slots") per wavefront: lanes 0..kP-1 own one each
 constexpr int kRow = 64;  // uint16 ids per image-list row (global workspace, one row per slot)
 constexpr size_t kCounterBytes = 1024;  // head of the launch workspace: work-queue counter (+ profiling counters)
+constexpr int kPark16 = HPMVS_REGION_16;  // 16-byte chunks of a wavefront's parking buffer
+
+#ifndef HPMVS_PARK_AUX
+#define HPMVS_PARK_AUX 0
+#endif
+// the state region <-> this wavefront's parking buffer.  In: LDS-DMA (global_load_lds_dwordx4: 1 KiB per
+// instruction straight into LDS at base + lane * 16, no staging registers, all ~39 pieces in flight at once).
+// Out: ds_read_b128 + 16-byte global stores (fire and forget).
+__device__ __forceinline__ void page_in(const uint4* __restrict__ park) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int c = 0; c < HPMVS_REGION_KIB; c++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(park + c * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(hpmvs_region + c * 64), 16, 0, HPMVS_PARK_AUX);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void page_out(uint4* __restrict__ park) {
+    const int lane = lane_id();
+#pragma unroll 13
+    for (int c = 0; c < HPMVS_REGION_KIB; c++) {
+#if HPMVS_PARK_AUX
+        { typedef unsigned int u4 __attribute__((ext_vector_type(4))); __builtin_nontemporal_store(((const u4*)hpmvs_region)[c * 64 + lane], &((u4*)park)[c * 64 + lane]); }
+#else
+        park[c * 64 + lane] = hpmvs_region[c * 64 + lane];
+#endif
+    }
+}
 
 }  // namespace
 
 #ifndef HPMVS_WAVES_PER_EU
 #define HPMVS_WAVES_PER_EU 2
 #endif
-__global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
+#ifndef HPMVS_BQ_PRIO
+#define HPMVS_BQ_PRIO 1  // s_setprio while the state region is held (C2: 308 -> 302 ms)
+#endif
+__global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
     const int lane = lane_id();
-    // this wavefront's image-list rows in the launch workspace (behind the counter block)
-    uint16_t* lists = (uint16_t*)((char*)queue + kCounterBytes) + (size_t)blockIdx.x * kP * kRow;
+    const int wv = (int)(threadIdx.x >> 6);            // which wavefront of the pair
+    const int n_wgs = (int)gridDim.x;
+    const int gw = wv * n_wgs + (int)blockIdx.x;        // wavefront index: all first wavefronts before the second ones
+    // this wavefront's image-list rows and parking buffer in the launch workspace (behind the counter block)
+    uint16_t* lists = (uint16_t*)((char*)queue + kCounterBytes) + (size_t)gw * kP * kRow;
     uint16_t* row = &lists[(lane < kP ? lane : 0) * kRow];
+    uint4* park = (uint4*)((char*)queue + kCounterBytes + (size_t)2 * n_wgs * kP * kRow * sizeof(uint16_t)) + (size_t)gw * kPark16;
 
     // ---- per-lane slot state
-    // Small batches are spread over as many wavefronts as possible (a wavefront with fewer busy slots has
-    // shorter rounds: one lone patch advances ~2.4x faster than one of ten), so only `quota` lanes pull work.
-    const int n_waves = (int)gridDim.x;
-    const int quota = (b.n + n_waves - 1) / n_waves < kP ? (b.n + n_waves - 1) / n_waves : kP;
-    int stage = (lane < quota) ? S_FETCH : S_IDLE;  // the other lanes only help in phase B
+    // Small batches are spread over as many workgroups as possible (a wavefront with fewer busy slots has shorter
+    // rounds: one lone patch advances ~2.4x faster than one of ten), and over the FIRST wavefronts of the
+    // workgroups before any second one gets work: a lone wavefront keeps the state region and never pages.
+    const int per_wg = (b.n + n_wgs - 1) / n_wgs;
+    const int quota = wv == 0 ? (per_wg < kP ? per_wg : kP) : (per_wg - kP < 0 ? 0 : (per_wg - kP < kP ? per_wg - kP : kP));
+    if (threadIdx.x == 0) { hpmvs_lock[0] = 0; hpmvs_lock[1] = 0; }
+    __syncthreads();
+    if (quota == 0) {  // nothing to do for this wavefront: tell the partner that the region is his
+        if (lane == 0) atomicOr(&hpmvs_lock[1], 1 << wv);
+        return;
+    }
+    bool held = false, solo = false;  // region held by this wavefront; partner gone (held for good, no paging)
+    int stage = (lane < quota) ? S_FETCH : S_IDLE;  // the other lanes only help in the wave-cooperative phases
     int idx = -1, nimg = 0, ii = 0, refindex = -1, ngrabs = 0, fail_stage = 0, nl_result = 0;
     float c0[3] = {0, 0, 0}, n0[3] = {0, 0, 0};  // optimize() input (kept for "patch untouched")
     float c[3] = {0, 0, 0}, n[3] = {0, 0, 1};    // pCenter_, pNormal_
@@ -103,8 +162,11 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
                 for (int k = 0; k < 3; k++) { c0[k] = b.center[4 * idx + k]; n0[k] = b.normal[4 * idx + k]; c[k] = c0[k]; n[k] = n0[k]; }
                 scale = b.scale[idx];
                 nimg = b.n_images[idx];
-                ngrabs = 0; nl_result = 0; BQN(nevals) = 0; BQS(minf) = 0.0;
-                BQA(xfinal, 0) = 0.0; BQA(xfinal, 1) = 0.0; BQA(xfinal, 2) = 0.0;
+                ngrabs = 0; nl_result = 0;
+                // optimiser diagnostics of a patch that never reaches the optimiser (overwritten when it finishes)
+                if (b.fmin) b.fmin[idx] = 0.0;
+                if (b.x) for (int k = 0; k < 3; k++) b.x[3 * idx + k] = 0.0;
+                if (b.nevals) b.nevals[idx] = 0;
                 if (nimg < 0) { fail_stage = -nimg; nimg = 0; finish_fail = true; break; }  // rejected by seed_init_kernel
                 if (nimg > kMaxImages || nimg > b.max_images) { fail_stage = 100; finish_fail = true; break; }
                 bool bad_id = false;
@@ -134,32 +196,16 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
                 nimg = res_n;
                 if (res_fail) { fail_stage = res_fail; finish_fail = true; break; }
                 set_optimization_fields(sc.views[row[0]], c, F);
-                double x0[3], dx[3];
-                parameters_from_center_norm(F, o, n, lbv, ubv, x0);
-                bq_default_step(x0, lbv, ubv, dx);
-                if (bq_start(B, x0, lbv, ubv, dx, 1.e-7, 1000) != BQ_CONTINUE) {
-                    nl_result = BQN(rc); fail_stage = 4; finish_fail = true; break;
-                }
-                { const double xe[3] = {BQA(xeval, 0), BQA(xeval, 1), BQA(xeval, 2)}; set_center_norm(F, o, xe, c, n); }
-                op = OP_OBJ;
+                op = OPQ_START;  // bq_start in the optimiser service below
                 stage = S_BQ;
                 break;
             }
-            case S_BQ: {  // objective value arrived: advance BOBYQA
-                if (bq_step(B, res_f) == BQ_CONTINUE) {
-                    const double xe[3] = {BQA(xeval, 0), BQA(xeval, 1), BQA(xeval, 2)};
-                    set_center_norm(F, o, xe, c, n);
-                    op = OP_OBJ;
-                    break;
-                }
-                nl_result = BQN(rc);
-                // SUCCESS / STOPVAL / FTOL / XTOL only (PatchOptimizer.cpp:367-368); negative codes throw
-                if (!(nl_result >= 1 && nl_result <= 4)) { fail_stage = 4; finish_fail = true; break; }
-                { const double xf[3] = {BQA(xfinal, 0), BQA(xfinal, 1), BQA(xfinal, 2)}; set_center_norm(F, o, xf, c, n); }
-                op = OPL_ADD;  // addImages
-                stage = S_ADD2;
+            case S_BQ:  // objective value arrived: advance BOBYQA (optimiser service below)
+                op = OPQ_STEP;
                 break;
-            }
+            case S_BQFAIL:  // the optimiser ended with a code that optimizePatch treats as failure
+                fail_stage = 4; finish_fail = true;
+                break;
             case S_ADD2: {
                 nimg = res_n;
                 if (nimg < 0) { fail_stage = 100; finish_fail = true; break; }
@@ -217,10 +263,7 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
                     if (b.ncc) b.ncc[idx] = 1.4f;  // PatchOptimizer.cpp:95
                 }
                 if (b.stage) b.stage[idx] = finish_ok ? 0 : fail_stage;
-                if (b.fmin) b.fmin[idx] = BQS(minf);
-                if (b.x) for (int k = 0; k < 3; k++) b.x[3 * idx + k] = BQA(xfinal, k);
                 if (b.result) b.result[idx] = nl_result;
-                if (b.nevals) b.nevals[idx] = BQN(nevals);
                 if (b.ngrabs) b.ngrabs[idx] = ngrabs;
                 stage = S_FETCH;
             }
@@ -228,7 +271,7 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
         // ================= list services: the image-list passes, one request at a time, 64 lanes wide (pipeline.hpp)
         {
             wave_lds_sync();  // the lanes' own list writes (global workspace) before the cooperative reads
-            const unsigned long long lm = __ballot(op >= OPL_ADD);
+            const unsigned long long lm = __ballot(op >= OPL_ADD && op <= OPL_F3);
             if (lm) {
                 BQ_PROF_BEGIN(tls_);
                 for (unsigned long long t = lm; t; t &= t - 1ull) {
@@ -257,6 +300,74 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
                 continue;  // the served lanes go on in phase A
             }
         }
+        // ================= optimiser service: the lanes whose patch needs bq_start / bq_step run them together,
+        // holding the workgroup's state region only for that long (see LDS TIME-SHARING above)
+        if (__any(op >= OPQ_START)) {
+            const bool mine = op >= OPQ_START;
+            double x0[3] = {0, 0, 0}, dx[3] = {1, 1, 1};
+            if (op == OPQ_START) {
+                parameters_from_center_norm(F, o, n, lbv, ubv, x0);
+                bq_default_step(x0, lbv, ubv, dx);
+            }
+            if (!held) {  // take the region and bring my patches' states in
+                BQ_PROF_BEGIN(tpg_);
+                if (lane == 0)
+                    while (atomicCAS(&hpmvs_lock[0], 0, 1 + wv) != 0) __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                BQ_PROF_END(tpg_, 25);
+                BQ_PROF_BEGIN(tpi_);
+                page_in(park);
+                BQ_PROF_END(tpi_, 27);
+                held = true;
+                solo = (hpmvs_lock[1] >> (wv ^ 1)) & 1;  // wave-uniform LDS read: the partner has left, no more hand-overs
+            }
+#if HPMVS_BQ_PRIO
+            __builtin_amdgcn_s_setprio(HPMVS_BQ_PRIO);  // the region is the contended resource: hold it as briefly as possible
+#endif
+            int ret = BQ_DONE;
+            if (op == OPQ_START) ret = bq_start(B, x0, lbv, ubv, dx, 1.e-7, 1000);
+            if (op == OPQ_STEP) ret = bq_step(B, res_f);
+            double xe[3] = {0, 0, 0};
+            if (mine) {
+                for (int k = 0; k < 3; k++) xe[k] = BQA(xeval, k);  // next point, or the final one (same slot)
+                if (ret != BQ_CONTINUE) {
+                    nl_result = BQN(rc);
+                    if (b.fmin) b.fmin[idx] = BQS(minf);
+                    if (b.x) for (int k = 0; k < 3; k++) b.x[3 * idx + k] = xe[k];
+                    if (b.nevals) b.nevals[idx] = BQN(nevals);
+                }
+            }
+            if (!solo) {  // park my states and hand the region to the partner wavefront
+                BQ_PROF_BEGIN(tpo_);
+                page_out(park);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) atomicExch(&hpmvs_lock[0], 0);
+                held = false;
+                BQ_PROF_END(tpo_, 26);
+            }
+#if HPMVS_BQ_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            if (mine) {
+                if (ret == BQ_CONTINUE) {
+                    set_center_norm(F, o, xe, c, n);
+                    op = OP_OBJ;
+                } else if (op == OPQ_START || !(nl_result >= 1 && nl_result <= 4)) {
+                    // bq_start refused the arguments, or a result other than SUCCESS / STOPVAL / FTOL / XTOL
+                    // (PatchOptimizer.cpp:367-368; negative codes throw)
+                    op = OP_NONE;
+                    stage = S_BQFAIL;
+                } else {
+                    set_center_norm(F, o, xe, c, n);
+                    op = OPL_ADD;  // addImages
+                    stage = S_ADD2;
+                }
+            }
+            // failed lanes finish in phase A; finished optimisations go on with addImages in the list services
+            if (__any((op == OP_NONE && stage != S_IDLE) || (op >= OPL_ADD && op <= OPL_F3))) continue;
+        }
         BQ_PROF_BEGIN(tax_);
         if (op != OP_NONE) {  // calculatePatchAxis (PatchOptimizer.cpp:532-548), lane-parallel
             const DevView& RV = sc.views[row[op == OP_OBJ ? 0 : req_ref]];
@@ -269,7 +380,10 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
 #ifdef HPMVS_PROFILE_PHASES
         { const long long t1 = clock64(); tA += t1 - t0; t0 = t1; nrounds++; nreq += __popcll(pending); }
 #endif
-        if (pending == 0ull) break;  // every lane idle and nothing posted: queue drained
+        if (pending == 0ull) {  // every lane idle and nothing posted: queue drained
+            if (lane == 0) atomicOr(&hpmvs_lock[1], 1 << wv);
+            break;
+        }
         {
             PackedReq q;
             q.obj_mode = (op == OP_OBJ) ? 1 : 0;
@@ -307,27 +421,31 @@ __global__ void __launch_bounds__(64, HPMVS_WAVES_PER_EU) optimize_kernel(DevSce
 }
 
 static int max_workgroups(int n_cus) {
-    // workgroups per CU: LDS (optimiser state per wavefront, one staging buffer per workgroup) and the
-    // waves-per-SIMD limit
-    int lds_per_wg = (int)(sizeof(double) * BQ_ND * kP + sizeof(int) * BQ_NI * kP) + 16;
+    // two-wavefront workgroups per CU: LDS (one state region each) and the waves-per-SIMD limit
+    int lds_per_wg = (int)(HPMVS_REGION_16 * 16 + 2 * sizeof(int));
+#ifdef HPMVS_PROFILE_PHASES
+    lds_per_wg += 64 * 8;
+#endif
     lds_per_wg = (lds_per_wg + 511) & ~511;  // LDS allocation granule
     int per_cu = (160 * 1024) / lds_per_wg;
-    if (per_cu > 4 * HPMVS_WAVES_PER_EU) per_cu = 4 * HPMVS_WAVES_PER_EU;
+    if (per_cu > 2 * HPMVS_WAVES_PER_EU) per_cu = 2 * HPMVS_WAVES_PER_EU;
     return n_cus * per_cu;
 }
 
 size_t optimize_workspace_bytes(int n_cus) {
-    return kCounterBytes + (size_t)max_workgroups(n_cus) * kP * kRow * sizeof(uint16_t);
+    // counter block + per wavefront: kP image-list rows and one parking buffer for the optimiser states
+    const size_t waves = (size_t)2 * max_workgroups(n_cus);
+    return kCounterBytes + waves * kP * kRow * sizeof(uint16_t) + waves * (size_t)kPark16 * 16;
 }
 
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus,
                      hipStream_t st) {
     if (b.n <= 0) return;
-    // persistent single-wavefront workgroups, kP patches in flight each
-    int wgs = b.n;  // up to one wavefront per patch (see `quota` in the kernel)
+    // persistent two-wavefront workgroups, up to kP patches in flight per wavefront
+    int wgs = b.n;  // up to one workgroup per patch (see `quota` in the kernel)
     const int cap = max_workgroups(n_cus);
     if (wgs > cap) wgs = cap;
-    hipLaunchKernelGGL(optimize_kernel, dim3(wgs), dim3(64), 0, st, sc, o, b, workspace);
+    hipLaunchKernelGGL(optimize_kernel, dim3(wgs), dim3(128), 0, st, sc, o, b, workspace);
 }
 
 }  // namespace hpmvs
