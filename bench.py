@@ -17,6 +17,10 @@ OpenMP loop over one seed vector) and the refined records are all-gathered, so e
 step holding the full refined set.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline_issue : the compute-side view of the same kernel (it is instruction-issue / latency bound, not HBM
+                 bound): VALU lane-cycles used / the machine's lane-cycles in the kernel's time, from the PMC
+                 pass recorded in profiles/pmc_traffic.json -- only when that record carries the build id of
+                 the library that is loaded (a kernel change without a new PMC pass prints no stale counters);
   roofline     : algorithmic image bytes of the refinement kernel (588 B per sampleTexture that
                  passed its gates, counted by the kernel itself) / kernel time from HIP events on
                  the launch stream, against the 8 TB/s HBM peak;
@@ -90,11 +94,14 @@ def c_batch(t, n, max_images):
     return b
 
 
-def pack_records(t, check=False):
-    """Fixed-size refined-patch record per patch (what one expansion round exchanges).  The id / count
-    ranges are validated in the warm-up steps (check=True costs a device sync), not in the timed ones."""
-    return dd.pack_records(t["center"], t["normal"], t["color"], t["scale"], t["fmin"], t["ok"], t["n_images"],
-                           t["images"], check=check)
+def check_record_ranges(t):
+    """The record stores counts and ids as uint16: validated once in the warm-up steps (a device sync), not in
+    the timed ones.  (dd.pack_records(check=True) is the same test followed by the torch packer.)"""
+    dd.pack_records(t["center"][:1], t["normal"][:1], t["color"][:1], t["scale"][:1], t["fmin"][:1], t["ok"][:1],
+                    t["n_images"][:1], t["images"][:1], check=False)  # layout / column-count errors raise here
+    nmax = int(t["n_images"].max())
+    if nmax > t["images"].shape[1] or nmax > dd.MAX_RECORD_IMAGES:
+        raise ValueError(f"a patch has {nmax} images but only {min(t['images'].shape[1], dd.MAX_RECORD_IMAGES)} ids can travel")
 
 
 def main():
@@ -112,6 +119,8 @@ def main():
     ap.add_argument("--cpu-timing-sample", type=int, default=262144, help="patches of the all-core CPU-baseline run")
     ap.add_argument("--cpu-sample-1core", type=int, default=16384, help="patches of the 1-core CPU run")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--check-gather", action="store_true",
+                    help="after the timed steps: compare the gathered records with the un-gathered results (tests)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -167,6 +176,8 @@ def main():
     L = api.lib()
     stream = torch.cuda.current_stream().cuda_stream
     gathered = None
+    # the round's exchange buffer: n_seeds records of 192 bytes, filled by the product's own packing kernel
+    records = torch.empty((n_seeds, RECORD_BYTES), dtype=torch.uint8, device=dev) if use_dist else None
 
     events = []
 
@@ -184,8 +195,14 @@ def main():
         if timed:
             events.append((e0, e1))
         if use_dist:
+            # the product path of INTEGRATION.md: hpmvs_pack_records (kernel) -> ONE all-gather of the records
             nonlocal gathered
-            gathered = dd.all_gather_records(pack_records(work, check=not timed), counts)  # ONE collective per round
+            if not timed:
+                check_record_ranges(work)
+            rc = L.hpmvs_pack_records(C.byref(b), C.c_void_p(records.data_ptr()), C.c_void_p(stream))
+            if rc != 0:
+                raise RuntimeError(L.hpmvs_last_error().decode())
+            gathered = dd.all_gather_records(records, counts)
 
     def fence():
         torch.cuda.synchronize()
@@ -279,96 +296,134 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "grabs_per_launch": int(ngrabs.sum())},
     }
+    if use_dist and args.check_gather and rank == 0:
+        # the gathered bytes of this rank's shard against (a) the torch packer applied to the results and (b) the
+        # result fields themselves
+        mine = gathered[lo:hi] if scaling == "strong" else gathered[:n_seeds]
+        ref = dd.pack_records(work["center"], work["normal"], work["color"], work["scale"], work["fmin"], work["ok"],
+                              work["n_images"], work["images"], check=True)
+        u = dd.unpack_records(mine)
+        okb = work["ok"].cpu().numpy().astype(bool)
+        fields = (np.array_equal(u["center"], work["center"].cpu().numpy()) and np.array_equal(u["ok"], okb) and
+                  np.array_equal(u["n_images"], work["n_images"].cpu().numpy()) and
+                  np.array_equal(u["fmin"], work["fmin"].cpu().numpy()))
+        out["gather_check"] = {"collective": f"all_gather_into_tensor over RCCL ({world} rank{'s' if world > 1 else ''})",
+                               "records": int(mine.shape[0]), "gathered_total": int(gathered.shape[0]),
+                               "bytes_equal_python_packer": bool(torch.equal(mine, ref)), "fields_equal_results": bool(fields)}
+
+    # counters of a PMC pass over this very workload (profiles/collect.sh): only if they were collected from the
+    # library build that is loaded now
+    build_id = api.build_id()
+    out["library_build_id"] = build_id
+    out["n_cus"] = int(torch.cuda.get_device_properties(dev).multi_processor_count)
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc)).get(args.workload)
-            if rec and rec.get("seeds_per_gpu") == n_seeds:
+            if rec and rec.get("seeds_per_gpu") == n_seeds and rec.get("library_build_id") == build_id:
                 out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = rec.get("source")
-                # instruction-issue view of the same kernel (it is issue bound, not HBM bound: DESIGN.md section 6)
-                for k in ("valu_lane_utilization", "valu_insts_per_patch", "kernel_commit"):
-                    if k in rec:
-                        out["roofline"][k] = rec[k]
-        except Exception:
-            pass
+                if "valu_thread_cycles" in rec and "kernel_cycles" in rec:
+                    # lane-cycles: SQ_THREAD_CYCLES_VALU counts active lanes x 4-cycle issue slots; the machine
+                    # offers CUs x 4 SIMDs x 16 lanes per cycle
+                    peak = float(rec["n_cus"]) * 4 * 16 * float(rec["kernel_cycles"])
+                    used = float(rec["valu_thread_cycles"])
+                    out["roofline_issue"] = {"bound": "valu", "lane_cycles_used": used, "lane_cycles_peak": peak,
+                                             "frac": used / peak,
+                                             "valu_insts_per_patch": rec.get("valu_insts_per_patch"),
+                                             "valu_lane_utilization": rec.get("valu_lane_utilization"),
+                                             "issue_slot_frac": rec.get("valu_issue_slot_frac"),
+                                             "source": rec.get("source")}
+            elif rec:
+                out["roofline"]["traffic_note"] = ("profiles/pmc_traffic.json holds counters of another build "
+                                                   f"({rec.get('library_build_id')}); not reported")
+        except Exception as e:  # a malformed record must not cost the line
+            out["roofline"]["traffic_note"] = f"pmc_traffic.json unreadable: {e}"
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu:
-        from oracle import oracle as orc
-        m = min(args.cpu_sample, n_seeds)
-        idx = np.arange(m)
-        osc = orc.OracleScene(scene)
-        P = orc.patches_from_seeds(seeds, idx)
-        cores = os.cpu_count() or 1
-        which = orc.best_optimizer()
-        orc.optimize_batch(osc, P, which=which, n_threads=cores)   # parity sample
-        # timing: a bigger bounded sample so that thread start-up does not dominate (a few seconds of all-core work)
-        mt = min(args.cpu_timing_sample, n_seeds)
-        Pt = orc.patches_from_seeds(seeds, np.arange(mt))
-        tc = time.perf_counter()
-        orc.optimize_batch(osc, Pt, which=which, n_threads=cores)
-        tc = time.perf_counter() - tc
-        okt = int(sum(1 for p in Pt if p.stage == 0))
-        del Pt
-        # the same loop on ONE core, smaller sample
-        m1 = min(args.cpu_sample_1core, m)
-        P1 = orc.patches_from_seeds(seeds, np.arange(m1))
-        t1 = time.perf_counter()
-        orc.optimize_batch(osc, P1, which=which, n_threads=1)
-        t1 = time.perf_counter() - t1
-        cpu_model, sockets = "unknown", 0
         try:
-            info = open("/proc/cpuinfo").read()
-            names = [l.split(":", 1)[1].strip() for l in info.splitlines() if l.startswith("model name")]
-            cpu_model = names[0] if names else "unknown"
-            sockets = len({l.split(":", 1)[1].strip() for l in info.splitlines() if l.startswith("physical id")})
-        except Exception:
-            pass
-        okc = np.array([p.stage == 0 for p in P])
-        okg = ok[:m]
-        both = np.nonzero(okc & okg)[0]
-        fmin_g = work["fmin"][:m].cpu().numpy()
-        cen_g = work["center"][:m].cpu().numpy()
-        nor_g = work["normal"][:m].cpu().numpy()
-        unrob = lambda f: f / (1.0 - 3.0 * f)
-        dncc, basin, ident = [], [], []
-        col_g = work["color"][:m].cpu().numpy()
-        nim_g = work["n_images"][:m].cpu().numpy()
-        img_g = work["images"][:m].cpu().numpy()
-        nev_g = nevals[:m]
-        for k in both:
-            p = P[k]
-            ident.append(np.array_equal(np.array(p.center[:], dtype=np.float32), cen_g[k]) and
-                         np.array_equal(np.array(p.normal[:], dtype=np.float32), nor_g[k]) and
-                         np.array_equal(np.array(p.color[:], dtype=np.float32), col_g[k]) and
-                         p.nevals == nev_g[k] and list(p.images[:p.n_images]) == list(img_g[k, :nim_g[k]]))
-            dncc.append(abs(unrob(p.fmin) - unrob(fmin_g[k])))
-            ddist = np.linalg.norm(np.array(p.center[:3]) - cen_g[k, :3]) / float(seeds.scale[k])
-            cs = float(np.clip(np.dot(np.array(p.normal[:3]), nor_g[k, :3]), -1, 1))
-            basin.append(ddist < 0.25 and np.degrees(np.arccos(cs)) < 2.0)
-        out["cpu_baseline"] = {
-            "value": mt / tc, "unit": "patches/s", "cores": cores,
-            "kind": "port",
-            "sample": f"first {mt} seeds of the same workload, OpenMP schedule(dynamic,64) over patches like "
-                      f"Scene::initPatches; photometric path = oracle/ C restatement, optimiser = "
-                      f"{'genuine NLopt 2.4.2 BOBYQA (oracle/_ref)' if which == orc.OPT_REF else 'oracle BOBYQA port'}",
-            "seconds": tc, "successes": okt,
-            "optimizer_is_reference_nlopt": bool(which == orc.OPT_REF),
-            "cpu_model": cpu_model, "sockets": sockets, "hardware_threads": cores,
-            "one_core": {"value": m1 / t1, "unit": "patches/s", "cores": 1, "sample": f"first {m1} seeds", "seconds": t1},
-        }
-        out["parity"] = {
-            "sample": m, "decision_agreement": float((okc == okg).mean()),
-            "mean_abs_ncc_delta": float(np.mean(dncc)) if dncc else None,
-            "same_basin_fraction": float(np.mean(basin)) if basin else None,
-            "bit_identical_patch_fraction": float(np.mean(ident)) if ident else None,
-            "stage_agreement": float((np.array([p.stage for p in P]) == stage[:m]).mean()),
-        }
+            cpu_leg(out, args, scene, seeds, n_seeds, work, ok, nevals, stage)
+        except Exception as e:  # the GPU line must survive a box without the checker
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+
+
+def cpu_leg(out, args, scene, seeds, n_seeds, work, ok, nevals, stage):
+    """CPU baseline + parity on a bounded sample of the same seeds (the oracle is the checker, never the product)."""
+    from oracle import oracle as orc
+    m = min(args.cpu_sample, n_seeds)
+    idx = np.arange(m)
+    osc = orc.OracleScene(scene)
+    P = orc.patches_from_seeds(seeds, idx)
+    cores = os.cpu_count() or 1
+    which = orc.best_optimizer()
+    orc.optimize_batch(osc, P, which=which, n_threads=cores)   # parity sample
+    # timing: a bigger bounded sample so that thread start-up does not dominate (a few seconds of all-core work)
+    mt = min(args.cpu_timing_sample, n_seeds)
+    Pt = orc.patches_from_seeds(seeds, np.arange(mt))
+    tc = time.perf_counter()
+    orc.optimize_batch(osc, Pt, which=which, n_threads=cores)
+    tc = time.perf_counter() - tc
+    okt = int(sum(1 for p in Pt if p.stage == 0))
+    del Pt
+    # the same loop on ONE core (SURVEY 8d), smaller sample
+    m1 = min(args.cpu_sample_1core, m)
+    P1 = orc.patches_from_seeds(seeds, np.arange(m1))
+    t1 = time.perf_counter()
+    orc.optimize_batch(osc, P1, which=which, n_threads=1)
+    t1 = time.perf_counter() - t1
+    cpu_model, sockets = "unknown", 0
+    try:
+        info = open("/proc/cpuinfo").read()
+        names = [l.split(":", 1)[1].strip() for l in info.splitlines() if l.startswith("model name")]
+        cpu_model = names[0] if names else "unknown"
+        sockets = len({l.split(":", 1)[1].strip() for l in info.splitlines() if l.startswith("physical id")})
+    except Exception:
+        pass
+    okc = np.array([p.stage == 0 for p in P])
+    okg = ok[:m]
+    both = np.nonzero(okc & okg)[0]
+    fmin_g = work["fmin"][:m].cpu().numpy()
+    cen_g = work["center"][:m].cpu().numpy()
+    nor_g = work["normal"][:m].cpu().numpy()
+    unrob = lambda f: f / (1.0 - 3.0 * f)
+    dncc, basin, ident = [], [], []
+    col_g = work["color"][:m].cpu().numpy()
+    nim_g = work["n_images"][:m].cpu().numpy()
+    img_g = work["images"][:m].cpu().numpy()
+    nev_g = nevals[:m]
+    for k in both:
+        p = P[k]
+        ident.append(np.array_equal(np.array(p.center[:], dtype=np.float32), cen_g[k]) and
+                     np.array_equal(np.array(p.normal[:], dtype=np.float32), nor_g[k]) and
+                     np.array_equal(np.array(p.color[:], dtype=np.float32), col_g[k]) and
+                     p.nevals == nev_g[k] and list(p.images[:p.n_images]) == list(img_g[k, :nim_g[k]]))
+        dncc.append(abs(unrob(p.fmin) - unrob(fmin_g[k])))
+        ddist = np.linalg.norm(np.array(p.center[:3]) - cen_g[k, :3]) / float(seeds.scale[k])
+        cs = float(np.clip(np.dot(np.array(p.normal[:3]), nor_g[k, :3]), -1, 1))
+        basin.append(ddist < 0.25 and np.degrees(np.arccos(cs)) < 2.0)
+    out["cpu_baseline"] = {
+        "value": mt / tc, "unit": "patches/s", "cores": cores,
+        "kind": "port",
+        "sample": f"first {mt} seeds of the same workload, OpenMP schedule(dynamic,64) over patches like "
+                  f"Scene::initPatches; photometric path = oracle/ C restatement, optimiser = "
+                  f"{'genuine NLopt 2.4.2 BOBYQA (oracle/_ref)' if which == orc.OPT_REF else 'oracle BOBYQA port'}",
+        "seconds": tc, "successes": okt,
+        "optimizer_is_reference_nlopt": bool(which == orc.OPT_REF),
+        "cpu_model": cpu_model, "sockets": sockets, "hardware_threads": cores,
+        "one_core": {"value": m1 / t1, "unit": "patches/s", "cores": 1, "sample": f"first {m1} seeds", "seconds": t1},
+    }
+    out["parity"] = {
+        "sample": m, "decision_agreement": float((okc == okg).mean()),
+        "mean_abs_ncc_delta": float(np.mean(dncc)) if dncc else None,
+        "same_basin_fraction": float(np.mean(basin)) if basin else None,
+        "bit_identical_patch_fraction": float(np.mean(ident)) if ident else None,
+        "stage_agreement": float((np.array([p.stage for p in P]) == stage[:m]).mean()),
+    }
 
 
 if __name__ == "__main__":

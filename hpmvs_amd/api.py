@@ -46,7 +46,7 @@ class PatchBatch(C.Structure):
 
 
 EXPORTS = [
-    "hpmvs_last_error", "hpmvs_device_count", "hpmvs_default_options", "hpmvs_camera_from_nvm",
+    "hpmvs_last_error", "hpmvs_device_count", "hpmvs_build_id", "hpmvs_default_options", "hpmvs_camera_from_nvm",
     "hpmvs_scene_create", "hpmvs_scene_set_view", "hpmvs_scene_set_covis", "hpmvs_scene_commit",
     "hpmvs_scene_destroy", "hpmvs_scene_get_level", "hpmvs_scene_bytes", "hpmvs_build_pyramid",
     "hpmvs_optimize_batch", "hpmvs_init_patches_batch", "hpmvs_objective_batch", "hpmvs_inccs_batch", "hpmvs_last_kernel_ms",
@@ -66,6 +66,7 @@ def lib():
                          "(there is no fallback implementation)")
     L = C.CDLL(LIB_PATH)
     L.hpmvs_last_error.restype = C.c_char_p
+    L.hpmvs_build_id.restype = C.c_char_p
     L.hpmvs_default_options.argtypes = [C.POINTER(Options)]
     L.hpmvs_camera_from_nvm.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int,
                                         C.c_int, C.POINTER(Camera)]
@@ -97,6 +98,11 @@ def lib():
 def _chk(rc):
     if rc != 0:
         raise HpmvsError(f"hpmvs_amd error {rc}: {lib().hpmvs_last_error().decode()}")
+
+
+def build_id() -> str:
+    """Source hash the loaded library was built from (stamped by hpmvs_amd/csrc/Makefile)."""
+    return lib().hpmvs_build_id().decode()
 
 
 def device_count() -> int:

@@ -93,6 +93,10 @@ static int release_workspace(const hpmvs_scene* s, int slot, hipStream_t st) {
 extern "C" {
 
 const char* hpmvs_last_error(void) { return g_err.c_str(); }
+#ifndef HPMVS_BUILD_ID
+#define HPMVS_BUILD_ID "unstamped"
+#endif
+const char* hpmvs_build_id(void) { return HPMVS_BUILD_ID; }
 
 int hpmvs_device_count(void) {
     int n = 0;

@@ -97,16 +97,17 @@ def unpack_records(rec: torch.Tensor) -> dict:
     return dict(center=f32(0, 16, 4), normal=f32(16, 32, 4), color=f32(32, 44, 3), scale=f32(44, 48, 1)[:, 0],
                 fmin=rec[:, 48:56].contiguous().view(torch.float64).view(n).numpy(),
                 ok=rec[:, 56].numpy().astype(bool),
-                n_images=rec[:, 58:60].contiguous().view(torch.int16).view(n).numpy().astype(np.uint16).astype(np.int32),
+                # signed like the C ABI's unpack_records_kernel: seed_init's rejection codes are negative counts
+                n_images=rec[:, 58:60].contiguous().view(torch.int16).view(n).numpy().astype(np.int32),
                 images=images)
 
 
 def all_gather_records(local: torch.Tensor, counts=None) -> torch.Tensor:
     """One collective per round.  Equal shard sizes use all_gather_into_tensor; ragged shards
     (n not divisible by the world size) are padded to the largest shard and trimmed."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return local
+    world = dist.get_world_size()  # a 1-rank group still goes through the collective (bench.py's forced-dist test)
     if counts is None or len(set(counts)) == 1:
         out = torch.empty((world * local.shape[0], RECORD_BYTES), dtype=torch.uint8, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous())

@@ -103,6 +103,9 @@ typedef struct {
 /* ---- library ---------------------------------------------------------------------------- */
 const char *hpmvs_last_error(void);
 int hpmvs_device_count(void);
+/* Identifies the build of this library: a hash of its sources taken by the Makefile.  Measurement records
+ * (profiles/pmc_traffic.json) carry it, so that counters are never reported beside another kernel's time. */
+const char *hpmvs_build_id(void);
 void hpmvs_default_options(hpmvs_options *o);
 
 /* Host-side Camera::init (reference src/hpmvs/Camera.cpp:34-81): NVM camera (focal length,

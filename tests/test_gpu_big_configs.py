@@ -109,3 +109,10 @@ def test_c1_12_views_1080p_1e5_seeds():
 
 def test_c2_50_views_4k_1e6_seeds():
     _run_config(50, 3840, 2160, 1_000_000, "c2_50v_4k_1e6")
+
+
+def test_c4_200_views_4k_2e5_seeds():
+    """BASELINE.json configs[4]'s scene at full size -- 200 x 3840x2160 views, 6.6 GB of pyramids rendered on the
+    device, covisibility lists of up to 199 views (addImages walks them in chunks of 64 lanes), 16-bit image ids
+    -- with 2e5 of its 1e7 seeds so that the test stays under a minute.  Same oracle sample and property block."""
+    _run_config(200, 3840, 2160, 200_000, "c4_200v_4k_2e5")
