@@ -595,11 +595,21 @@ static int optimize_small_host_batch(const hpmvs_scene* s, const hpmvs_options* 
     const PoolLayout L = pool_layout(n, m);
     hpmvs_scene::StageEntry& e = s->stage[s->stage_next.fetch_add(1) % hpmvs_scene::kStageEntries];
     std::lock_guard<std::mutex> use(e.mu);
-    if (!e.st) {
+    if (!e.st || !e.dev || !e.host) {
+        // all three or nothing: a failed allocation must not leave a half-initialised entry behind
         const PoolLayout cap = pool_layout((size_t)hpmvs_scene::kStageCapPatches, (size_t)HPMVS_MAX_IMAGES);
-        HIPCHK(hipStreamCreateWithFlags(&e.st, hipStreamNonBlocking));
-        HIPCHK(hipMalloc((void**)&e.dev, cap.total));
-        HIPCHK(hipHostMalloc((void**)&e.host, cap.total));
+        hipStream_t st = e.st;
+        char *dv = nullptr, *hv = nullptr;
+        bool good = st || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+        good = good && hipMalloc((void**)&dv, cap.total) == hipSuccess;
+        good = good && hipHostMalloc((void**)&hv, cap.total) == hipSuccess;
+        if (!good) {
+            if (dv) hipFree(dv);
+            if (hv) hipHostFree(hv);
+            if (st && !e.st) hipStreamDestroy(st);
+            return fail(HPMVS_ERR_HIP, "optimize_batch: cannot allocate the staging block of a small host batch");
+        }
+        e.st = st; e.dev = dv; e.host = hv;
     }
     char* h = e.host;
     memcpy(h + L.off_center, b->center, 16 * n); memcpy(h + L.off_normal, b->normal, 16 * n);

@@ -124,6 +124,7 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
         return;
     }
     bool held = false, solo = false;  // region held by this wavefront; partner gone (held for good, no paging)
+    bool parked = false;              // my states are in the parking buffer
     int stage = (lane < quota) ? S_FETCH : S_IDLE;  // the other lanes only help in the wave-cooperative phases
     int idx = -1, nimg = 0, ii = 0, refindex = -1, ngrabs = 0, fail_stage = 0, nl_result = 0;
     float c0[3] = {0, 0, 0}, n0[3] = {0, 0, 0};  // optimize() input (kept for "patch untouched")
@@ -317,7 +318,7 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
                 __builtin_amdgcn_wave_barrier();
                 BQ_PROF_END(tpg_, 25);
                 BQ_PROF_BEGIN(tpi_);
-                page_in(park);
+                if (parked) page_in(park);  // (nothing is parked before this wavefront's first release)
                 BQ_PROF_END(tpi_, 27);
                 held = true;
                 solo = (hpmvs_lock[1] >> (wv ^ 1)) & 1;  // wave-uniform LDS read: the partner has left, no more hand-overs
@@ -341,6 +342,7 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
             if (!solo) {  // park my states and hand the region to the partner wavefront
                 BQ_PROF_BEGIN(tpo_);
                 page_out(park);
+                parked = true;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 0) atomicExch(&hpmvs_lock[0], 0);

@@ -282,7 +282,19 @@ struct Combiner {
 };
 // at most this many combined launches in flight: the device runs only a few kernels of different streams at once,
 // so further callers are better off joining the next batch than queueing a launch of their own
-constexpr int kMaxCombinedLaunches = 2;
+#ifndef HPMVS_MAX_COMBINED_LAUNCHES
+#define HPMVS_MAX_COMBINED_LAUNCHES 2
+#endif
+// (measured with 6 in flight, round 3: 256 threads 20.5 k -> 14.6 k patches/s, 512 threads 34.0 k -> 24.3 k: the
+//  streams share a handful of hardware queues, so a further launch often waits for a whole earlier one)
+constexpr int kMaxCombinedLaunches = HPMVS_MAX_COMBINED_LAUNCHES;
+
+// two option sets that drive the device identically (the reference's callers hold one HpmvsOptions copy per thread)
+bool same_options(const HpmvsOptions& a, const HpmvsOptions& b) {
+    return a.MAXLEVEL == b.MAXLEVEL && a.MINLEVEL == b.MINLEVEL && a.MAX_ANGLE == b.MAX_ANGLE && a.MIN_ANGLE == b.MIN_ANGLE &&
+           a.MAX_IMAGES_PER_PATCH == b.MAX_IMAGES_PER_PATCH && a.MIN_IMAGES_PER_PATCH == b.MIN_IMAGES_PER_PATCH &&
+           a.NCC_ALPHA_1 == b.NCC_ALPHA_1 && a.NCC_ALPHA_2 == b.NCC_ALPHA_2;
+}
 }  // namespace
 
 void* Scene::combiner() const {
@@ -443,14 +455,29 @@ bool PatchOptimizer::optimize(mo3d::Patch3d& patch) {
         C.collecting = false;
         C.launches++;
         lk.unlock();
-        // one launch per distinct options object (normally one)
+        // Whatever happens in the launch (an exception from a vector allocation, an infrastructure error), the
+        // owners of the taken entries are woken and the launch slot is given back: entries that were
+        // not served keep ok = 0, i.e. "patch untouched".
+        struct Finish {
+            Combiner& C; std::vector<Combiner::Entry*>& take; std::unique_lock<std::mutex>& lk;
+            ~Finish() {
+                if (!lk.owns_lock()) lk.lock();
+                C.launches--;
+                for (Combiner::Entry* e : take) e->done = true;
+                C.cv_done.notify_all();
+                C.cv_collect.notify_one();  // a collector may be waiting for a launch slot
+            }
+        } finish{C, take, lk};
+        // one launch per distinct option SET (normally one; compared by value)
         std::vector<char> handled(take.size(), 0);
         for (size_t a = 0; a < take.size(); a++) {
             if (handled[a]) continue;
             std::vector<Patch3d*> group;
             std::vector<size_t> who;
             for (size_t k = a; k < take.size(); k++)
-                if (!handled[k] && take[k]->opt == take[a]->opt) { group.push_back(take[k]->patch); who.push_back(k); handled[k] = 1; }
+                if (!handled[k] && (take[k]->opt == take[a]->opt || same_options(*take[k]->opt, *take[a]->opt))) {
+                    group.push_back(take[k]->patch); who.push_back(k); handled[k] = 1;
+                }
             std::vector<uint8_t> okv(group.size(), 0);
             PatchOptimizer runner(*take[a]->opt, scene_p);
             runner.optimizeBatch(group.data(), group.size(), okv.data());
@@ -460,12 +487,8 @@ bool PatchOptimizer::optimize(mo3d::Patch3d& patch) {
                 take[who[k]]->evals = runner.lastEvals_.size() > k ? runner.lastEvals_[k] : 0;
             }
         }
-        lk.lock();
-        C.launches--;
-        for (Combiner::Entry* e : take) e->done = true;
-        C.cv_done.notify_all();
-        C.cv_collect.notify_one();  // a collector may be waiting for a launch slot
     }
+    if (!lk.owns_lock()) lk.lock();
     C.inside--;
     lastF_.assign(1, me.f);
     lastEvals_.assign(1, me.evals);

@@ -191,7 +191,9 @@ int hpmvs_objective_batch(const hpmvs_scene *s, const hpmvs_options *o, const hp
 int hpmvs_inccs_batch(const hpmvs_scene *s, const hpmvs_options *o, const hpmvs_patch_batch *b,
                       int ref_idx, int robust, float *out, int on_device, void *stream);
 
-/* last optimize launch: kernel time measured with HIP events on the launch stream (ms) */
+/* last optimize launch: kernel time measured with HIP events on the launch stream (ms).  Meaningful with ONE caller at a
+ * time: the scene holds a single event pair, so concurrent launches from several host threads can pair the start of one
+ * launch with the end of another. */
 int hpmvs_last_kernel_ms(const hpmvs_scene *s, float *ms);
 
 /* ---- multi-GPU: the per-round exchange of refined patches ---------------------------------------------------------

@@ -114,7 +114,7 @@ def test_unchanged_callers_64_threads_in_a_loop(tiny_scene, tmp_path):
     dump = tmp_path / "scene10k.bin"
     _dump_scene(dump, tiny_scene, seeds, n)
     rows = []
-    for threads in (64, 8, 1):
+    for threads in (512, 256, 64, 8, 1):
         r = subprocess.run([exe, str(dump), str(threads)], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout + r.stderr
         rows.append(json.loads(r.stdout.strip().splitlines()[-1]))

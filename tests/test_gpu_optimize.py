@@ -71,6 +71,20 @@ def compare(seeds, oracle_scene, gpu_scene, tag):
         fh.write(json.dumps(report) + "\n")
     assert agree.mean() == 1.0, report
     assert report["bit_identical_patch"] >= 0.99, report
+    # The optimiser variables x[3] (float64, exported by the ABI).  x[0] (depth) and x[2] (asin of a float32, the
+    # glibc algorithm restated on the device) must be identical.  x[1] starts from a float64 acos(): the device
+    # rounds it to nearest (cr_acos.hpp), glibc 2.35 does not always (its acos is < 1 ulp, not correctly rounded),
+    # and where the two differ the whole run carries an offset of a few ulp in x[1] that float32 centre / normal /
+    # f never see (tools/x_mismatch_probe.py: 7 of 2850 patches, 1-4 ulp, every other output identical).  So: at
+    # least 99 % identical, and for a patch whose outputs are bit-identical x may differ in x[1] only, by <= 16 ulp.
+    assert report["identical_x"] >= 0.99 or report["identical_x"] >= report["bit_identical_patch"] - 0.02, report
+    for k in both:
+        xc, xg = np.array(P[k].x[:]), batch.x[k]
+        same_out = (np.array_equal(np.array(P[k].center[:], dtype=np.float32), batch.center[k]) and
+                    np.array_equal(np.array(P[k].normal[:], dtype=np.float32), batch.normal[k]) and P[k].nevals == batch.nevals[k])
+        if same_out and not np.array_equal(xc, xg):
+            assert xc[0] == xg[0] and xc[2] == xg[2], (tag, k, xc, xg)
+            assert abs(xc[1] - xg[1]) <= 16 * np.spacing(abs(xc[1])), (tag, k, xc, xg)
     assert np.mean(dncc) <= 1e-5, report
     assert basin.mean() >= 0.99 and np.mean(same_imgs) >= 0.99, report
     # scale_3dx_ is returned unchanged and ncc_ is the reference's constant
