@@ -34,6 +34,13 @@ static inline float dot3(const float *a, const float *b) { return (a[0] * b[0] +
  * how far the refined patches move (the "stated float tolerance" against a real build). */
 static int g_dot4_order = 0;
 void orc_set_dot4_order(int order) { g_dot4_order = order; }
+/* A second build-dependent choice inside Eigen: `vector / scalar` (hence normalized(), `ave /= size3` in
+ * Patch2d.hpp:60 and `result /= result(2)` in Camera.h:55) is a true division per coefficient from Eigen 3.2 on,
+ * but a multiplication by the reciprocal (scalar_quotient1_op: m_other = 1 / other) in Eigen 3.0 / 3.1.
+ *   0  true division   <- what the HIP path restates      1  multiply by 1/scalar */
+static int g_vec_div_mode = 0;
+void orc_set_vec_div_mode(int mode) { g_vec_div_mode = mode; }
+static inline float vdiv(float a, float s, float inv_s) { return g_vec_div_mode ? a * inv_s : a / s; }
 static inline float sum4(float p0, float p1, float p2, float p3) {
     if (g_dot4_order == 1) return (p0 + p2) + (p1 + p3);
     if (g_dot4_order == 2) return (p0 + p1) + (p2 + p3);
@@ -50,12 +57,12 @@ static inline void cross3(const float *a, const float *b, float *r) {
 }
 static inline void normalized3(const float *a, float *r) {
     const float n2 = dot3(a, a);
-    if (n2 > 0.0f) { const float n = sqrtf(n2); r[0] = a[0] / n; r[1] = a[1] / n; r[2] = a[2] / n; }
+    if (n2 > 0.0f) { const float n = sqrtf(n2), in = 1.0f / n; r[0] = vdiv(a[0], n, in); r[1] = vdiv(a[1], n, in); r[2] = vdiv(a[2], n, in); }
     else { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
 }
 static inline void normalized4(const float *a, float *r) {
     const float n2 = dot4(a, a);
-    if (n2 > 0.0f) { const float n = sqrtf(n2); for (int i = 0; i < 4; i++) r[i] = a[i] / n; }
+    if (n2 > 0.0f) { const float n = sqrtf(n2), in = 1.0f / n; for (int i = 0; i < 4; i++) r[i] = vdiv(a[i], n, in); }
     else { for (int i = 0; i < 4; i++) r[i] = a[i]; }
 }
 static inline void sub4(const float *a, const float *b, float *r) { for (int i = 0; i < 4; i++) r[i] = a[i] - b[i]; }
@@ -209,7 +216,7 @@ static void cam_project(const orc_camera *cam, const float *X, int level, float 
         out[0] = -65535.0f; out[1] = -65535.0f; out[2] = -1.0f;
     } else {
         const float lo = (float)(INT_MIN + 3.0f), hi = (float)(INT_MAX - 3.0f);
-        r[0] = r[0] / r[2]; r[1] = r[1] / r[2]; r[2] = r[2] / r[2];
+        { const float z = r[2], iz = 1.0f / z; r[0] = vdiv(r[0], z, iz); r[1] = vdiv(r[1], z, iz); r[2] = vdiv(r[2], z, iz); }  /* Eigen: result /= result(2) */
         out[0] = fmaxf(lo, fminf(hi, r[0]));
         out[1] = fmaxf(lo, fminf(hi, r[1]));
         out[2] = r[2];
@@ -261,7 +268,7 @@ static void img_get_color(const orc_image *im, float x, float y, int level, floa
 static void tex_normalize(float *d) {
     float ave[3] = {0, 0, 0};
     for (int i = 0; i < 49; i++) { ave[0] += d[3 * i]; ave[1] += d[3 * i + 1]; ave[2] += d[3 * i + 2]; }
-    ave[0] /= 49; ave[1] /= 49; ave[2] /= 49;
+    { const float in = 1.0f / 49; ave[0] = vdiv(ave[0], 49, in); ave[1] = vdiv(ave[1], 49, in); ave[2] = vdiv(ave[2], 49, in); }  /* Eigen: ave /= size3 */
     float ave2 = 0.0f;
     for (int i = 0; i < 49; i++) {
         const float f0 = ave[0] - d[3 * i], f1 = ave[1] - d[3 * i + 1], f2 = ave[2] - d[3 * i + 2];

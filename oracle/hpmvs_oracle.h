@@ -153,6 +153,9 @@ int orc_bobyqa_minimize(int which, int n, orc_obj_fn f, void *data, double *x, c
 
 /* test-only switch: evaluation order of Eigen's 4-float reductions (0 left-to-right = default, 1 SSE2, 2 SSE3) */
 void orc_set_dot4_order(int order);
+/* Eigen's vector / scalar: 0 true division (Eigen >= 3.2, the default and what the HIP path restates), 1 multiply by the
+ * reciprocal (Eigen 3.0 / 3.1) */
+void orc_set_vec_div_mode(int mode);
 
 #ifdef __cplusplus
 }

@@ -103,6 +103,12 @@ def set_dot4_order(order: int):
     lib().orc_set_dot4_order(int(order))
 
 
+def set_vec_div_mode(mode: int):
+    """Eigen's `vector / scalar` in the oracle: 0 true division (Eigen >= 3.2), 1 multiplication by the reciprocal
+    (Eigen 3.0 / 3.1: normalized(), ave /= size3, result /= result(2))."""
+    lib().orc_set_vec_div_mode(int(mode))
+
+
 def optimizer_available(which: int) -> bool:
     return lib().orc_optimizer_available(which) == 0
 

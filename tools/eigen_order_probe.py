@@ -1,16 +1,17 @@
 """How far do refined patches move when Eigen's 4-float reductions use another evaluation order?  CPU only (oracle +
 genuine NLopt): left-to-right (what the HIP path restates) vs the SSE2 packet order and the SSE3 haddps order.
-Output committed as profiles/r02/eigen_order_sensitivity.json; DESIGN.md section 5 quotes it."""
+Round 3: also Eigen 3.0/3.1's vector / scalar = multiplication by the reciprocal.
+Output committed as profiles/r03/eigen_variant_sensitivity.json (r02: eigen_order_sensitivity.json); DESIGN.md section 5 quotes it."""
 import sys, os, json, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hpmvs_amd import synth
 from oracle import oracle as orc
-def run(scene, seeds, order):
-    orc.set_dot4_order(order)
-    osc = orc.OracleScene(scene)
+def run(scene, seeds, order, div_mode=0):
+    orc.set_dot4_order(order); orc.set_vec_div_mode(div_mode)
+    osc = orc.OracleScene(scene)   # (the camera tables are built under the same settings)
     P = orc.patches_from_seeds(seeds)
-    orc.optimize_batch(osc, P, which=orc.OPT_REF, n_threads=8)
-    orc.set_dot4_order(0)
+    orc.optimize_batch(osc, P, which=orc.best_optimizer(), n_threads=os.cpu_count() or 8)
+    orc.set_dot4_order(0); orc.set_vec_div_mode(0)
     return P
 def cmp(P0, P1, seeds):
     ok0 = np.array([p.stage==0 for p in P0]); ok1=np.array([p.stage==0 for p in P1])
@@ -27,5 +28,8 @@ def cmp(P0, P1, seeds):
 scene = synth.make_scene(12, 960, 540, n_waves=24)
 seeds = synth.make_seeds(scene, 4000, start_level=3, max_images=32)
 P0 = run(scene, seeds, 0)
-for o in (1,2):
-    print(o, json.dumps(cmp(P0, run(scene, seeds, o), seeds)))
+out = {}
+for name, o, dm in (("sse2_order", 1, 0), ("sse3_order", 2, 0), ("reciprocal_division_eigen30_31", 0, 1), ("sse2_order+reciprocal_division", 1, 1)):
+    out[name] = cmp(P0, run(scene, seeds, o, dm), seeds)
+    print(name, json.dumps(out[name]))
+json.dump(out, open(sys.argv[1] if len(sys.argv) > 1 else "/tmp/eigen_variants.json", "w"), indent=1)
