@@ -52,6 +52,8 @@ EXPORTS = [
     "hpmvs_optimize_batch", "hpmvs_init_patches_batch", "hpmvs_objective_batch", "hpmvs_inccs_batch", "hpmvs_last_kernel_ms",
     "hpmvs_expand_batch", "hpmvs_expand_directions", "hpmvs_selftest_bobyqa",
     "hpmvs_pack_records", "hpmvs_unpack_records", "hpmvs_allgather_records",
+    "hpmvs_scene_depth_reset", "hpmvs_scene_depth_set_level", "hpmvs_scene_depth_get_level",
+    "hpmvs_set_depths_batch", "hpmvs_depth_gates_batch",
 ]
 
 _lib = None
@@ -91,6 +93,13 @@ def lib():
     L.hpmvs_expand_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.POINTER(PatchBatch), C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.POINTER(PatchBatch), C.c_int, C.c_void_p]
     L.hpmvs_expand_directions.argtypes = [C.c_int, C.c_void_p]
+    L.hpmvs_scene_depth_reset.argtypes = [C.c_void_p]
+    L.hpmvs_scene_depth_set_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.hpmvs_scene_depth_get_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
+                                              C.POINTER(C.c_int)]
+    L.hpmvs_set_depths_batch.argtypes = [C.c_void_p, C.POINTER(PatchBatch), C.c_int, C.c_void_p]
+    L.hpmvs_depth_gates_batch.argtypes = [C.c_void_p, C.POINTER(PatchBatch), C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_void_p]
     _lib = L
     return L
 
@@ -295,6 +304,35 @@ def inccs_batch(scene: Scene, batch: Batch, ref_idx=0, robust=0, options: Option
     out = np.zeros((batch.n, batch.max_images), dtype=np.float32)
     _chk(lib().hpmvs_inccs_batch(scene.h, C.byref(o), C.byref(b), ref_idx, robust, out.ctypes.data, 0, None))
     return out
+
+
+def depth_reset(scene: Scene):
+    """Allocate (first call) and clear the scene's depth maps (reference Scene.cpp:74-80)."""
+    _chk(lib().hpmvs_scene_depth_reset(scene.h))
+
+
+def depth_level(scene: Scene, view: int, level: int) -> np.ndarray:
+    """One depth map in Eigen's storage order: shape (cols, rows), element [x, y]."""
+    r, c = C.c_int(), C.c_int()
+    _chk(lib().hpmvs_scene_depth_get_level(scene.h, view, level, None, 0, C.byref(r), C.byref(c)))
+    out = np.zeros((c.value, r.value), dtype=np.float32)
+    _chk(lib().hpmvs_scene_depth_get_level(scene.h, view, level, out.ctypes.data, out.size, C.byref(r), C.byref(c)))
+    return out
+
+
+def set_depths_batch(scene: Scene, batch: Batch):
+    """Scene::setDepths for every patch of the batch with ok != 0 (reference Scene.cpp:351-381)."""
+    b = batch.c_struct()
+    _chk(lib().hpmvs_set_depths_batch(scene.h, C.byref(b), 0, None))
+
+
+def depth_gates_batch(scene: Scene, batch: Batch, margin=1.0, abs_int=0):
+    """depthTests / viewBlockTest / pixelFreeTests counts per patch (reference Scene.cpp:518-644)."""
+    b = batch.c_struct()
+    v = np.zeros(batch.n, dtype=np.int32); k = np.zeros(batch.n, dtype=np.int32); f = np.zeros(batch.n, dtype=np.int32)
+    _chk(lib().hpmvs_depth_gates_batch(scene.h, C.byref(b), float(margin), int(abs_int), v.ctypes.data, k.ctypes.data,
+                                       f.ctypes.data, 0, None))
+    return v, k, f
 
 
 def build_pyramid(img: np.ndarray, device: int = 0) -> np.ndarray:

@@ -53,6 +53,11 @@ struct hpmvs_scene {
     DevView* dviews = nullptr;
     int32_t* dcovis_off = nullptr;
     int32_t* dcovis = nullptr;
+    // depth maps (hpmvs_scene_depth_reset): one pool, per view a table of level pointers
+    mutable float* depth_pool = nullptr;
+    mutable size_t depth_floats = 0;
+    mutable DevDepthView* ddepth = nullptr;
+    mutable std::vector<DevDepthView> hdepth;
     int32_t* dqueue = nullptr;          // kQueueSlots launch workspaces of ws_bytes each
     size_t ws_bytes = 0;
     mutable unsigned next_slot = 0;
@@ -291,6 +296,8 @@ int hpmvs_scene_destroy(hpmvs_scene* s) {
     if (!s) return HPMVS_OK;
     hipSetDevice(s->device);
     for (void* p : s->allocs) hipFree(p);
+    if (s->depth_pool) hipFree(s->depth_pool);
+    if (s->ddepth) hipFree(s->ddepth);
     if (s->dviews) hipFree(s->dviews);
     if (s->dcovis_off) hipFree(s->dcovis_off);
     if (s->dcovis) hipFree(s->dcovis);
@@ -860,6 +867,117 @@ int hpmvs_inccs_batch(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     return stage_out(out, dout, n * b->max_images);
+}
+
+// ---- depth maps and the acceptance gates over them (kernel_depth.hip)
+int hpmvs_scene_depth_reset(hpmvs_scene* s) {
+    if (!s || !s->committed) return fail(HPMVS_ERR_STATE, "scene_depth_reset: scene not committed");
+    HIPCHK(hipSetDevice(s->device));
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!s->depth_pool) {
+        // Scene.cpp:74-80: rows = height(level) / DEPTH_SUBSAMPLE, cols = width(level) / DEPTH_SUBSAMPLE (a double 2)
+        size_t total = 0;
+        s->hdepth.assign((size_t)s->n_views, DevDepthView{});
+        for (int v = 0; v < s->n_views; v++)
+            for (int l = 0; l < s->hviews[v].n_levels; l++) {
+                s->hdepth[v].rows[l] = (int)((double)s->hviews[v].h[l] / 2.0);
+                s->hdepth[v].cols[l] = (int)((double)s->hviews[v].w[l] / 2.0);
+                total += (size_t)s->hdepth[v].rows[l] * s->hdepth[v].cols[l];
+            }
+        if (total == 0) return fail(HPMVS_ERR_STATE, "scene_depth_reset: empty scene");
+        HIPCHK(hipMalloc((void**)&s->depth_pool, total * sizeof(float)));
+        s->depth_floats = total;
+        size_t off = 0;
+        for (int v = 0; v < s->n_views; v++)
+            for (int l = 0; l < s->hviews[v].n_levels; l++) {
+                s->hdepth[v].d[l] = s->depth_pool + off;
+                off += (size_t)s->hdepth[v].rows[l] * s->hdepth[v].cols[l];
+            }
+        HIPCHK(hipMalloc((void**)&s->ddepth, sizeof(DevDepthView) * (size_t)s->n_views));
+        HIPCHK(hipMemcpy(s->ddepth, s->hdepth.data(), sizeof(DevDepthView) * (size_t)s->n_views, hipMemcpyHostToDevice));
+    }
+    launch_depth_fill(s->depth_pool, s->depth_floats, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    return HPMVS_OK;
+}
+
+static int depth_level(const hpmvs_scene* s, int view, int level, const char* who, float** p, int* rows, int* cols) {
+    if (!s || !s->depth_pool) return fail(HPMVS_ERR_STATE, std::string(who) + ": call hpmvs_scene_depth_reset first");
+    if (view < 0 || view >= s->n_views || level < 0 || level >= s->hviews[view].n_levels)
+        return fail(HPMVS_ERR_ARG, std::string(who) + ": bad view / level");
+    *p = s->hdepth[view].d[level]; *rows = s->hdepth[view].rows[level]; *cols = s->hdepth[view].cols[level];
+    return HPMVS_OK;
+}
+int hpmvs_scene_depth_set_level(hpmvs_scene* s, int view, int level, const float* data, int rows, int cols) {
+    float* p; int r, c, rc;
+    if ((rc = depth_level(s, view, level, "scene_depth_set_level", &p, &r, &c))) return rc;
+    if (!data || rows != r || cols != c) return fail(HPMVS_ERR_ARG, "scene_depth_set_level: shape is not rows x cols of that level");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemcpy(p, data, sizeof(float) * (size_t)r * c, hipMemcpyHostToDevice));
+    return HPMVS_OK;
+}
+int hpmvs_scene_depth_get_level(const hpmvs_scene* s, int view, int level, float* data, size_t capacity, int* rows, int* cols) {
+    float* p; int r, c, rc;
+    if ((rc = depth_level(s, view, level, "scene_depth_get_level", &p, &r, &c))) return rc;
+    if (rows) *rows = r;
+    if (cols) *cols = c;
+    if (!data) return HPMVS_OK;  // shape query
+    if (capacity < (size_t)r * c) return fail(HPMVS_ERR_ARG, "scene_depth_get_level: buffer too small");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(data, p, sizeof(float) * (size_t)r * c, hipMemcpyDeviceToHost));
+    return HPMVS_OK;
+}
+
+static int check_depth_batch(const hpmvs_scene* s, const hpmvs_patch_batch* b, const char* who) {
+    if (!s || !b) return fail(HPMVS_ERR_ARG, std::string(who) + ": null scene / batch");
+    if (!s->committed || !s->depth_pool) return fail(HPMVS_ERR_STATE, std::string(who) + ": call hpmvs_scene_depth_reset first");
+    if (b->n < 0 || b->max_images < 1 || b->max_images > HPMVS_MAX_IMAGES) return fail(HPMVS_ERR_ARG, std::string(who) + ": bad n/max_images");
+    if (b->n > 0 && (!b->center || !b->normal || !b->scale || !b->n_images || !b->images))
+        return fail(HPMVS_ERR_ARG, std::string(who) + ": batch input arrays missing");
+    return HPMVS_OK;
+}
+int hpmvs_set_depths_batch(hpmvs_scene* s, const hpmvs_patch_batch* b, int on_device, void* stream) {
+    int rc = check_depth_batch(s, b, "set_depths_batch");
+    if (rc) return rc;
+    if (b->n == 0) return HPMVS_OK;
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    Staged sg;
+    if ((rc = stage_batch(sg, b, on_device != 0, false))) return rc;
+    if (!on_device && b->ok) { if ((rc = stage_in(sg, sg.d.ok, b->ok, (size_t)b->n, true))) return rc; }
+    launch_set_depths(dev_scene(s), s->ddepth, sg.d, st);
+    HIPCHK(hipGetLastError());
+    if (!on_device) HIPCHK(hipStreamSynchronize(st));
+    return HPMVS_OK;
+}
+int hpmvs_depth_gates_batch(const hpmvs_scene* s, const hpmvs_patch_batch* b, float margin, int abs_int,
+                            int32_t* n_visible, int32_t* n_blocking, int32_t* n_free, int on_device, void* stream) {
+    int rc = check_depth_batch(s, b, "depth_gates_batch");
+    if (rc) return rc;
+    if (!n_visible && !n_blocking && !n_free) return fail(HPMVS_ERR_ARG, "depth_gates_batch: no output array");
+    if (b->n == 0) return HPMVS_OK;
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    Staged sg;
+    if ((rc = stage_batch(sg, b, on_device != 0, false))) return rc;
+    if (on_device) {
+        launch_depth_gates(dev_scene(s), s->ddepth, sg.d, margin, abs_int, n_visible, n_blocking, n_free, st);
+        HIPCHK(hipGetLastError());
+        return HPMVS_OK;
+    }
+    const size_t n = (size_t)b->n;
+    int32_t *dv = nullptr, *db = nullptr, *df = nullptr;
+    if ((rc = stage_in(sg, dv, n_visible, n, false))) return rc;
+    if ((rc = stage_in(sg, db, n_blocking, n, false))) return rc;
+    if ((rc = stage_in(sg, df, n_free, n, false))) return rc;
+    launch_depth_gates(dev_scene(s), s->ddepth, sg.d, margin, abs_int, dv, db, df, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    if ((rc = stage_out(n_visible, dv, n))) return rc;
+    if ((rc = stage_out(n_blocking, db, n))) return rc;
+    return stage_out(n_free, df, n);
 }
 
 // debug: phase counters of the last optimize launch (only meaningful in -DHPMVS_PROFILE_PHASES builds)

@@ -26,6 +26,14 @@ struct alignas(16) DevView {
     int32_t pad[2];
 };
 
+// One view's depth maps (reference Scene.h:74-76, Scene.cpp:74-80): per pyramid level an Eigen::MatrixXf(rows, cols),
+// column-major (element (y, x) at y + x * rows), rows / cols = level size / DEPTH_SUBSAMPLE.
+struct DevDepthView {
+    float* d[kMaxLevels];
+    int32_t rows[kMaxLevels];
+    int32_t cols[kMaxLevels];
+};
+
 struct DevScene {
     const DevView* views;
     const int32_t* covis_off;  // n_views + 1

@@ -1,0 +1,208 @@
+// kernel_depth.hip -- per-view depth maps in HBM and the acceptance gates that read them (second half).
+//
+// The reference's expansion accepts a refined candidate only if it is consistent with the depth maps the
+// already accepted patches have written (src/hpmvs/CellProcessor.cpp:134-142):
+//     scene.depthTests(p, margin)     >= MIN_IMAGES     (src/hpmvs/Scene.cpp:518-524, 531-580)
+//     scene.viewBlockTest(p, margin)  <  MIN_IMAGES     (Scene.cpp:607-642: ALL views, 3x3 pixels, 6 pyramid levels each)
+//     scene.pixelFreeTests(p)         >= MIN_IMAGES - 1 and > 0.75 * #images   (Scene.cpp:582-605)
+// and Scene::setDepths (Scene.cpp:351-381) records an accepted patch.  On the host that is a serial walk over up to
+// 200 views per candidate; here a wavefront takes one candidate, lane v one view (chunks of 64), and the three counts
+// are ballots.  The maps keep the reference's layout (Eigen::MatrixXf(rows, cols), column-major, MAX_DEPTH = 1000,
+// rows/cols = level size / DEPTH_SUBSAMPLE) so that the scheduler's matrices can be copied in and out as they are.
+// Read-only on the gate side; setDepths is a float minimum (order-independent), done with atomicMin on the bit
+// patterns of non-negative floats.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "launch.h"
+#include "photometric.hpp"
+
+namespace hpmvs {
+
+namespace {
+
+constexpr float kMaxDepth = 1000.0f;  // Scene::MAX_DEPTH (Scene.cpp:33)
+
+// `int / DEPTH_SUBSAMPLE` with DEPTH_SUBSAMPLE a double 2 (Scene.h:78), stored to an int: truncation towards zero
+__device__ __forceinline__ int sub_index(int v) { return (int)((double)v / 2.0); }
+
+// Camera::getLevel (Camera.cpp:92-95) then std::round
+__device__ __forceinline__ int level_rounded(const DevView& V, const float* c, float scale) {
+    const float d0 = c[0] - V.center[0], d1 = c[1] - V.center[1], d2 = c[2] - V.center[2];
+    const float fz = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+    const float lv = (float)log2((double)(scale * V.fsum) / (2.0 * (double)fz));
+    return (int)roundf(lv);
+}
+// Camera::mult at `level` (Camera.h:76-78): P[level] = diag(2^-l, 2^-l, 1) * P0 exactly
+__device__ __forceinline__ void mult_level(const DevView& V, const float* c, int level, float* r) {
+    const float* P = V.P0;
+    const float s = __int_as_float((127 - level) << 23);
+    r[0] = (((P[0] * c[0] + P[1] * c[1]) + P[2] * c[2]) + P[3]) * s;
+    r[1] = (((P[4] * c[0] + P[5] * c[1]) + P[6] * c[2]) + P[7]) * s;
+    r[2] = ((P[8] * c[0] + P[9] * c[1]) + P[10] * c[2]) + P[11];
+}
+// Camera::project at `level` (Camera.h:45-62)
+__device__ __forceinline__ void project_level(const DevView& V, const float* c, int level, float* r) {
+    float P[12];
+    for (int k = 0; k < 12; k++) P[k] = V.P0[k];
+    const float z = ((P[8] * c[0] + P[9] * c[1]) + P[10] * c[2]) + P[11];
+    if (z <= 0.0f) { r[0] = -65535.0f; r[1] = -65535.0f; r[2] = -1.0f; return; }
+    float u, v;
+    project0(P, c[0], c[1], c[2], u, v);
+    const float s = __int_as_float((127 - level) << 23);
+    r[0] = u * s; r[1] = v * s; r[2] = z / z;
+}
+// Scene::getFullDepth (Scene.cpp:406-432)
+__device__ __forceinline__ float full_depth(const DevDepthView& D, int n_levels, int xx, int yy) {
+    float depth = kMaxDepth;
+    int x = sub_index(xx), y = sub_index(yy);
+    for (int level = 0; level < n_levels; level++) {
+        if (x < 0 || x >= D.cols[level] || y < 0 || y >= D.rows[level]) return depth;
+        const float v = D.d[level][y + (size_t)x * D.rows[level]];
+        depth = v < depth ? v : depth;
+        x /= 2; y /= 2;
+    }
+    return depth;
+}
+// Scene::depthTest(patch, image, margin, neighbours = true, viewBlock) (Scene.cpp:531-580)
+__device__ __forceinline__ bool depth_test(const DevView& V, const DevDepthView& D, const float* c, const float* n,
+                                           float scale, float margin, bool view_block, int abs_int) {
+    float m[3];
+    mult_level(V, c, 0, m);
+    const float depth = m[2];
+    const int ix0 = (int)((double)(m[0] / m[2]) + 0.5) - 1, iy0 = (int)((double)(m[1] / m[2]) + 0.5) - 1;
+    // patch-constant part of the pixel test
+    float ray[3];
+    const float d[3] = {c[0] - V.center[0], c[1] - V.center[1], c[2] - V.center[2]};
+    normalized3f(d, ray);
+    const float rn = dot3f(ray, n) + 0.0f;  // the 4-vector dot: ... + w * w with both w = 0
+    const float factor = 2.0f < 2.0f + rn ? 2.0f : 2.0f + rn;
+    const double thr = (double)(scale * margin * factor) * 2.0;
+    for (int yy = 0; yy < 3; yy++)
+        for (int xx = 0; xx < 3; xx++) {
+            const int ix = ix0 + xx, iy = iy0 + yy;
+            if (depth < 0 || ix < 0 || ix >= V.w[0] || iy < 0 || iy >= V.h[0]) return false;
+            const float img_depth = full_depth(D, V.n_levels, ix, iy);
+            if (img_depth >= kMaxDepth) { if (view_block) return false; continue; }
+            const float diff = img_depth - depth;
+            if (!view_block) {
+                const double a = abs_int ? (double)abs((int)diff) : (double)fabsf(diff);
+                if (!(a < thr)) return false;
+            } else if (!((double)diff > thr)) return false;
+        }
+    return true;
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(256) depth_fill_kernel(float* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = kMaxDepth;
+}
+
+// Scene::setDepths(patch, subtract = false): one thread per (patch, attached image)
+__global__ void __launch_bounds__(256) set_depths_kernel(DevScene sc, const DevDepthView* __restrict__ depths, DevBatch b) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = t / kMaxImages, k = t - p * kMaxImages;
+    if (p >= b.n) return;
+    if (b.ok && !b.ok[p]) return;
+    const int nimg = b.n_images[p];
+    if (k >= nimg || k >= b.max_images) return;
+    const int idx = b.images[(size_t)p * b.max_images + k];
+    if (idx < 0 || idx >= sc.n_views) return;
+    const DevView& V = sc.views[idx];
+    const float c[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
+    const float scale = b.scale[p];
+    const float d0 = c[0] - V.center[0], d1 = c[1] - V.center[1], d2 = c[2] - V.center[2];
+    const int level = level_clamped(scale, V.fsum, sqrtf((d0 * d0 + d1 * d1) + d2 * d2), V.n_levels - 1);
+    float m[3];
+    mult_level(V, c, level, m);
+    const int x = sub_index((int)((double)(m[0] / m[2]) + 0.5)), y = sub_index((int)((double)(m[1] / m[2]) + 0.5));
+    const DevDepthView& D = depths[idx];
+    if (x < 0 || x >= D.cols[level] || y < 0 || y >= D.rows[level]) return;
+    if (!(m[2] >= 0.0f)) return;  // (the reference CHECK-fails on a negative depth)
+    // `if (d < old) old = d` for non-negative floats = unsigned minimum of the bit patterns
+    atomicMin((unsigned int*)&D.d[level][y + (size_t)x * D.rows[level]], __float_as_uint(m[2]));
+}
+
+// depthTests / viewBlockTest / pixelFreeTests: one wavefront per patch, one lane per view
+__global__ void __launch_bounds__(256) depth_gates_kernel(DevScene sc, const DevDepthView* __restrict__ depths, DevBatch b,
+                                                          float margin, int abs_int, int32_t* __restrict__ n_visible,
+                                                          int32_t* __restrict__ n_blocking, int32_t* __restrict__ n_free) {
+    const int lane = lane_id();
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int p = wave; p < b.n; p += nwaves) {
+        const float c[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
+        const float n[3] = {b.normal[4 * p], b.normal[4 * p + 1], b.normal[4 * p + 2]};
+        const float scale = b.scale[p];
+        int nimg = b.n_images[p];
+        nimg = nimg < 0 ? 0 : (nimg > b.max_images ? b.max_images : nimg);
+        // the attached images: depthTests (similar depth) and pixelFreeTests
+        bool vis = false, fre = false;
+        if (lane < nimg) {
+            const int idx = b.images[(size_t)p * b.max_images + lane];
+            if (idx >= 0 && idx < sc.n_views) {
+                const DevView& V = sc.views[idx];
+                vis = depth_test(V, depths[idx], c, n, scale, margin, false, abs_int);
+                const int level = level_rounded(V, c, scale);
+                if (level >= 0 && level < V.n_levels) {
+                    float r[3];
+                    project_level(V, c, level, r);
+                    const int ix = (int)((double)(r[0] / r[2]) + 0.5), iy = (int)((double)(r[1] / r[2]) + 0.5);
+                    if (!(ix < 0 || ix >= V.w[level] || iy < 0 || iy >= V.h[level])) {
+                        const DevDepthView& D = depths[idx];
+                        const int x = sub_index(ix), y = sub_index(iy);
+                        float dv = kMaxDepth;
+                        if (!(x < 0 || x >= D.cols[level] || y < 0 || y >= D.rows[level])) dv = D.d[level][y + (size_t)x * D.rows[level]];
+                        fre = dv == kMaxDepth;
+                    }
+                }
+            }
+        }
+        const int nv = __popcll(__ballot(vis)), nf = __popcll(__ballot(fre));
+        // every view of the scene: does the patch lie in front of a confirmed surface there?
+        int nb = 0;
+        for (int base = 0; base < sc.n_views; base += 64) {
+            const int v = base + lane;
+            bool blk = false;
+            if (v < sc.n_views) {
+                const DevView& V = sc.views[v];
+                const int level = level_rounded(V, c, scale);
+                if (!(level < 0 || level > V.n_levels - 1)) {
+                    float r[3];
+                    project_level(V, c, level, r);
+                    if (!(r[0] < 0 || r[0] > (float)V.w[level] || r[1] < 0 || r[1] > (float)V.h[level]))
+                        blk = depth_test(V, depths[v], c, n, scale, margin, true, abs_int);
+                }
+            }
+            nb += __popcll(__ballot(blk));
+        }
+        if (lane == 0) {
+            if (n_visible) n_visible[p] = nv;
+            if (n_blocking) n_blocking[p] = nb;
+            if (n_free) n_free[p] = nf;
+        }
+    }
+}
+
+void launch_depth_fill(float* p, size_t n, hipStream_t st) {
+    if (!n) return;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(depth_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n);
+}
+void launch_set_depths(const DevScene& sc, const DevDepthView* depths, const DevBatch& b, hipStream_t st) {
+    if (b.n <= 0) return;
+    const size_t threads = (size_t)b.n * kMaxImages;
+    hipLaunchKernelGGL(set_depths_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, sc, depths, b);
+}
+void launch_depth_gates(const DevScene& sc, const DevDepthView* depths, const DevBatch& b, float margin, int abs_int,
+                        int32_t* n_visible, int32_t* n_blocking, int32_t* n_free, hipStream_t st) {
+    if (b.n <= 0) return;
+    int blocks = (b.n + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(depth_gates_kernel, dim3(blocks), dim3(256), 0, st, sc, depths, b, margin, abs_int, n_visible,
+                       n_blocking, n_free);
+}
+
+}  // namespace hpmvs

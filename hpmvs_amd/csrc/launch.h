@@ -27,6 +27,12 @@ size_t optimize_workspace_bytes(int n_cus);
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace,
                      int n_cus, hipStream_t st);
 
+// depth maps and the acceptance gates over them (kernel_depth.hip)
+void launch_depth_fill(float* p, size_t n, hipStream_t st);
+void launch_set_depths(const DevScene& sc, const DevDepthView* depths, const DevBatch& b, hipStream_t st);
+void launch_depth_gates(const DevScene& sc, const DevDepthView* depths, const DevBatch& b, float margin, int abs_int,
+                        int32_t* n_visible, int32_t* n_blocking, int32_t* n_free, hipStream_t st);
+
 // refined-patch records of the multi-GPU exchange (include/hpmvs_amd.h: hpmvs_record, 192 bytes)
 void launch_pack_records(const DevBatch& b, void* records, hipStream_t st);
 void launch_unpack_records(const void* records, int n, const DevBatch& b, hipStream_t st);

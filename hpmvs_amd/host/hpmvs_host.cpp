@@ -421,6 +421,57 @@ hpmvs_scene* Scene::deviceScene() const {
     return dev_;
 }
 
+// ---------------------------------------------------------------- depth maps + acceptance gates (batched)
+namespace {
+struct HostBatch {  // SoA copy of a patch list for the C ABI (inputs only)
+    std::vector<float> center, normal, scale;
+    std::vector<int32_t> nimg, images;
+    hpmvs_patch_batch b;
+    HostBatch(const Patch3d* const* patches, size_t n) : center(4 * n), normal(4 * n), scale(n), nimg(n), images(n * HPMVS_MAX_IMAGES, -1) {
+        for (size_t i = 0; i < n; i++) {
+            const Patch3d& p = *patches[i];
+            for (int k = 0; k < 4; k++) { center[4 * i + k] = p.center_[k]; normal[4 * i + k] = p.normal_[k]; }
+            scale[i] = p.scale_3dx_;
+            const size_t m = p.images_.size() < (size_t)HPMVS_MAX_IMAGES ? p.images_.size() : (size_t)HPMVS_MAX_IMAGES;
+            nimg[i] = (int32_t)m;
+            for (size_t k = 0; k < m; k++) images[i * HPMVS_MAX_IMAGES + k] = p.images_[k];
+        }
+        memset(&b, 0, sizeof(b));
+        b.n = (int32_t)n; b.max_images = HPMVS_MAX_IMAGES;
+        b.center = center.data(); b.normal = normal.data(); b.scale = scale.data(); b.n_images = nimg.data(); b.images = images.data();
+    }
+};
+}  // namespace
+
+bool Scene::resetDepths() const {
+    hpmvs_scene* dev = deviceScene();
+    if (!dev || hpmvs_scene_depth_reset(dev) != HPMVS_OK) { std::cerr << "hpmvs: " << hpmvs_last_error() << std::endl; return false; }
+    return true;
+}
+bool Scene::setDepths(const Patch3d* const* patches, size_t n) const {
+    hpmvs_scene* dev = deviceScene();
+    if (!dev) return false;
+    if (n == 0) return true;
+    HostBatch hb(patches, n);
+    if (hpmvs_set_depths_batch(dev, &hb.b, 0, nullptr) != HPMVS_OK) { std::cerr << "hpmvs: " << hpmvs_last_error() << std::endl; return false; }
+    return true;
+}
+bool Scene::depthGates(const Patch3d* const* patches, size_t n, float margin, std::vector<int>& nVisible,
+                       std::vector<int>& nBlocking, std::vector<int>& nFree, bool absInt) const {
+    nVisible.assign(n, 0); nBlocking.assign(n, 0); nFree.assign(n, 0);
+    hpmvs_scene* dev = deviceScene();
+    if (!dev) return false;
+    if (n == 0) return true;
+    HostBatch hb(patches, n);
+    std::vector<int32_t> v(n), k(n), f(n);
+    if (hpmvs_depth_gates_batch(dev, &hb.b, margin, absInt ? 1 : 0, v.data(), k.data(), f.data(), 0, nullptr) != HPMVS_OK) {
+        std::cerr << "hpmvs: " << hpmvs_last_error() << std::endl;
+        return false;
+    }
+    for (size_t i = 0; i < n; i++) { nVisible[i] = v[i]; nBlocking[i] = k[i]; nFree[i] = f[i]; }
+    return true;
+}
+
 // ---------------------------------------------------------------- PatchOptimizer
 PatchOptimizer::PatchOptimizer(const mo3d::HpmvsOptions& options, const mo3d::Scene* scene)
     : options_p(&options), scene_p(scene) {}

@@ -1,7 +1,8 @@
 // mo3d::Scene -- the part of the reference's Scene the refinement path reads (reference
 // include/hpmvs/Scene.h:69-71: cameras_, images_, covis_; cached by PatchOptimizer at
-// src/hpmvs/PatchOptimizer.cpp:38-41).  The octree, depth maps and the scheduler stay with the host
-// application.  The scene must be complete before the first PatchOptimizer is constructed and is
+// src/hpmvs/PatchOptimizer.cpp:38-41).  The octree and the scheduler stay with the host application; the
+// depth maps (reference Scene.h:74-76) live in HBM next to the pyramids, with batch forms of setDepths and of the
+// three acceptance tests the expansion gates its candidates on.  The scene must be complete before the first PatchOptimizer is constructed and is
 // immutable afterwards, exactly as in the reference; at that point it is uploaded to HBM once and
 // shared by every optimizer instance.
 #ifndef HPMVS_SCENE_H_
@@ -30,6 +31,15 @@ public:
     // construction, optimize(), drift gate.  Survivors are appended to `out` in point order; inserting
     // them into the octree / depth maps (Scene.cpp:183-199) stays with the host application.
     bool initPatches(const NVM_Model& model, const HpmvsOptions& options, std::vector<Ppatch3d>& out) const;
+    // ---- depth maps (src/hpmvs/Scene.cpp:74-80) and the acceptance tests over them, batched on the device.
+    // resetDepths: allocate / clear (MAX_DEPTH = 1000).  setDepths: Scene::setDepths(patch) (Scene.cpp:351-381) for
+    // every patch.  depthGates: per patch the counts of Scene::depthTests, viewBlockTest and pixelFreeTests
+    // (Scene.cpp:518-644) that CellProcessor compares with MIN_IMAGES_PER_PATCH (CellProcessor.cpp:134-142);
+    // absInt selects C's abs(int) for the unqualified abs() at Scene.cpp:571 (default: the <cmath> overload).
+    bool resetDepths() const;
+    bool setDepths(const Patch3d* const* patches, size_t n) const;
+    bool depthGates(const Patch3d* const* patches, size_t n, float margin, std::vector<int>& nVisible,
+                    std::vector<int>& nBlocking, std::vector<int>& nFree, bool absInt = false) const;
     std::map<std::string, int> dict_;
     std::vector<Camera> cameras_;
     std::vector<Image> images_;

@@ -191,6 +191,31 @@ int hpmvs_objective_batch(const hpmvs_scene *s, const hpmvs_options *o, const hp
 int hpmvs_inccs_batch(const hpmvs_scene *s, const hpmvs_options *o, const hpmvs_patch_batch *b,
                       int ref_idx, int robust, float *out, int on_device, void *stream);
 
+/* ---- depth maps and the acceptance gates of the expansion (second half) ----------------------------------
+ * The reference accepts a refined candidate only if it agrees with the depth maps written by the patches accepted
+ * so far (src/hpmvs/CellProcessor.cpp:134-142, 198-200):
+ *     Scene::depthTests(p, margin)    >= MIN_IMAGES_PER_PATCH      src/hpmvs/Scene.cpp:518-524, 531-580
+ *     Scene::viewBlockTest(p, margin) <  MIN_IMAGES_PER_PATCH      src/hpmvs/Scene.cpp:607-642 (every view of the scene)
+ *     Scene::pixelFreeTests(p)        >= MIN_IMAGES_PER_PATCH - 1 and > 0.75 * #images    src/hpmvs/Scene.cpp:582-605
+ * and records an accepted patch with Scene::setDepths (src/hpmvs/Scene.cpp:351-381).  The maps live in HBM in the
+ * reference's own layout -- per view and pyramid level an Eigen::MatrixXf(rows, cols), column-major, filled with
+ * MAX_DEPTH = 1000, rows / cols = level size / DEPTH_SUBSAMPLE (src/hpmvs/Scene.cpp:33,74-80) -- so the unchanged
+ * scheduler copies its matrices in and out as they are (matrix.data(), rows(), cols()).
+ *   hpmvs_scene_depth_reset      allocate (first call) and fill every map with MAX_DEPTH
+ *   hpmvs_scene_depth_set_level / _get_level   one map <-> host (get with data == NULL: shape query)
+ *   hpmvs_set_depths_batch       setDepths(patch, subtract = false) for every patch of the batch with ok[i] != 0
+ *                                (all patches when ok is NULL): a float minimum per cell, order-independent
+ *   hpmvs_depth_gates_batch      the three counts per patch, read-only; the caller applies the thresholds.
+ *                                abs_int selects the reading of the unqualified `abs(diff)` at Scene.cpp:571: 0 = the
+ *                                <cmath> overload (fabsf), 1 = C's abs(int), which truncates the difference first --
+ *                                which one a reference binary has depends on the headers its toolchain exports. */
+int hpmvs_scene_depth_reset(hpmvs_scene *s);
+int hpmvs_scene_depth_set_level(hpmvs_scene *s, int view, int level, const float *data, int rows, int cols);
+int hpmvs_scene_depth_get_level(const hpmvs_scene *s, int view, int level, float *data, size_t capacity, int *rows, int *cols);
+int hpmvs_set_depths_batch(hpmvs_scene *s, const hpmvs_patch_batch *b, int on_device, void *stream);
+int hpmvs_depth_gates_batch(const hpmvs_scene *s, const hpmvs_patch_batch *b, float margin, int abs_int,
+                            int32_t *n_visible, int32_t *n_blocking, int32_t *n_free, int on_device, void *stream);
+
 /* last optimize launch: kernel time measured with HIP events on the launch stream (ms).  Meaningful with ONE caller at a
  * time: the scene holds a single event pair, so concurrent launches from several host threads can pair the start of one
  * launch with the end of another. */

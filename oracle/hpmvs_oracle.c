@@ -918,3 +918,156 @@ int orc_sample_texture(const orc_scene *s, const orc_options *o, const orc_patch
     if (ok) { *level = po.last_level; memcpy(cdxdy6, po.last_cdxdy, sizeof(float) * 6); }
     return ok;
 }
+
+/* ------------------------------------------------------------------------- */
+/* Depth maps and the acceptance gates that read them (SURVEY 8f-3's second half).
+ *
+ * Storage: per view and pyramid level an Eigen::MatrixXf(rows, cols) filled with MAX_DEPTH = 1000
+ * (src/hpmvs/Scene.cpp:33,74-80), rows = height(level) / DEPTH_SUBSAMPLE, cols = width(level) / DEPTH_SUBSAMPLE
+ * with `const double DEPTH_SUBSAMPLE = 2` (include/hpmvs/Scene.h:78): an int divided by a double, truncated.
+ * Eigen's default storage is column-major: element (y, x) is data[y + x * rows]; this struct keeps that layout. */
+#define ORC_MAX_DEPTH 1000.0f
+struct orc_depths_s {
+    int n_views;
+    int n_levels;
+    int *rows, *cols;   /* [view * ORC_MAX_LEVELS + level] */
+    float **d;
+};
+static inline int sub_index(int v) { return (int)((double)v / 2.0); }  /* `int / DEPTH_SUBSAMPLE` -> int: truncation towards zero */
+
+orc_depths *orc_depths_create(const orc_scene *s) {
+    orc_depths *D = (orc_depths *)calloc(1, sizeof(orc_depths));
+    D->n_views = s->n_views;
+    D->rows = (int *)calloc((size_t)s->n_views * ORC_MAX_LEVELS, sizeof(int));
+    D->cols = (int *)calloc((size_t)s->n_views * ORC_MAX_LEVELS, sizeof(int));
+    D->d = (float **)calloc((size_t)s->n_views * ORC_MAX_LEVELS, sizeof(float *));
+    for (int v = 0; v < s->n_views; v++)
+        for (int l = 0; l < s->cams[v].n_levels; l++) {
+            const int k = v * ORC_MAX_LEVELS + l;
+            D->rows[k] = sub_index(s->imgs[v].h[l]);
+            D->cols[k] = sub_index(s->imgs[v].w[l]);
+            const size_t n = (size_t)D->rows[k] * D->cols[k];
+            D->d[k] = (float *)malloc((n ? n : 1) * sizeof(float));
+            for (size_t i = 0; i < n; i++) D->d[k][i] = ORC_MAX_DEPTH;
+        }
+    return D;
+}
+void orc_depths_destroy(orc_depths *D) {
+    if (!D) return;
+    for (int k = 0; k < D->n_views * ORC_MAX_LEVELS; k++) free(D->d[k]);
+    free(D->d); free(D->rows); free(D->cols); free(D);
+}
+float *orc_depths_level(orc_depths *D, int view, int level, int *rows, int *cols) {
+    const int k = view * ORC_MAX_LEVELS + level;
+    if (rows) *rows = D->rows[k];
+    if (cols) *cols = D->cols[k];
+    return D->d[k];
+}
+/* Camera::mult, include/hpmvs/Camera.h:76-78 */
+static void cam_mult(const orc_camera *cam, const float *X, int level, float *r) {
+    const float *P = cam->P[level];
+    for (int k = 0; k < 3; k++)
+        r[k] = sum4(P[k * 4 + 0] * X[0], P[k * 4 + 1] * X[1], P[k * 4 + 2] * X[2], P[k * 4 + 3] * X[3]);
+}
+/* Scene::setDepths(patch, subtract = false), src/hpmvs/Scene.cpp:351-381 */
+void orc_set_depths(const orc_scene *s, orc_depths *D, const orc_patch *p) {
+    for (int i = 0; i < p->n_images; i++) {
+        const int idx = p->images[i];
+        const orc_camera *cam = &s->cams[idx];
+        const int level = cam_get_leveli(cam, p->center, p->scale, cam->n_levels - 1);
+        float c[3];
+        cam_mult(cam, p->center, level, c);
+        const int x = sub_index((int)(c[0] / c[2] + 0.5));
+        const int y = sub_index((int)(c[1] / c[2] + 0.5));
+        const float d = c[2];
+        const int k = idx * ORC_MAX_LEVELS + level;
+        if (x < 0 || x >= D->cols[k] || y < 0 || y >= D->rows[k]) continue;
+        float *cell = &D->d[k][y + (size_t)x * D->rows[k]];
+        if (d < *cell) *cell = d;
+    }
+}
+/* Scene::getFullDepth, src/hpmvs/Scene.cpp:406-432 */
+static float get_full_depth(const orc_scene *s, const orc_depths *D, int img, int xx, int yy) {
+    float depth = ORC_MAX_DEPTH;
+    int x = sub_index(xx), y = sub_index(yy);
+    for (int level = 0; level < s->cams[img].n_levels; level++) {
+        const int k = img * ORC_MAX_LEVELS + level;
+        if (x < 0 || x >= D->cols[k] || y < 0 || y >= D->rows[k]) return depth;
+        const float v = D->d[k][y + (size_t)x * D->rows[k]];
+        depth = v < depth ? v : depth;  /* std::min(depth, v) */
+        x /= 2; y /= 2;
+    }
+    return depth;
+}
+/* Scene::getDetphAtLevel, src/hpmvs/Scene.cpp:383-404 */
+static float get_depth_at_level(const orc_depths *D, int img, int xx, int yy, int level) {
+    const int x = sub_index(xx), y = sub_index(yy);
+    const int k = img * ORC_MAX_LEVELS + level;
+    if (x < 0 || x >= D->cols[k] || y < 0 || y >= D->rows[k]) return ORC_MAX_DEPTH;
+    return D->d[k][y + (size_t)x * D->rows[k]];
+}
+/* Scene::depthTest(patch, ix, iy, depth, image, margin, viewBlock), src/hpmvs/Scene.cpp:552-580.
+ * abs_int: the similarity test is written `abs(diff) < ...` on a float, unqualified, inside namespace mo3d
+ * (Scene.cpp:571): with <cmath>'s overloads visible that is fabsf; with only C's abs(int) in scope the
+ * difference is truncated to an int first.  Both are "the reference"; the caller says which. */
+static int depth_test_px(const orc_scene *s, const orc_depths *D, const orc_patch *p, int ix, int iy, float depth,
+                         int image, float margin, int view_block, int abs_int) {
+    if (depth < 0 || ix < 0 || ix >= s->imgs[image].w[0] || iy < 0 || iy >= s->imgs[image].h[0]) return 0;
+    const float img_depth = get_full_depth(s, D, image, ix, iy);
+    if (img_depth >= ORC_MAX_DEPTH) return view_block ? 0 : 1;
+    float d[4], ray[4];
+    sub4(p->center, s->cams[image].center, d);
+    normalized4(d, ray);
+    const float diff = img_depth - depth;
+    const float rn = dot4(ray, p->normal);
+    const float factor = 2.0f < 2.0f + rn ? 2.0f : 2.0f + rn;  /* std::min(2.0f, 2.0f + ray.dot(normal)) */
+    const double thr = p->scale * margin * factor * 2.0;
+    if (!view_block) {
+        const double a = abs_int ? (double)abs((int)diff) : (double)fabsf(diff);
+        return a < thr;
+    }
+    return (double)diff > thr;
+}
+/* Scene::depthTest(patch, image, margin, neighbours = true, viewBlock), src/hpmvs/Scene.cpp:531-550 */
+static int depth_test(const orc_scene *s, const orc_depths *D, const orc_patch *p, int image, float margin,
+                      int view_block, int abs_int) {
+    float c[3];
+    cam_mult(&s->cams[image], p->center, 0, c);
+    int ix = (int)(c[0] / c[2] + 0.5), iy = (int)(c[1] / c[2] + 0.5);
+    ix--; iy--;
+    for (int yy = 0; yy < 3; yy++)
+        for (int xx = 0; xx < 3; xx++)
+            if (!depth_test_px(s, D, p, ix + xx, iy + yy, c[2], image, margin, view_block, abs_int)) return 0;
+    return 1;
+}
+/* Scene::pixelFreeTest, src/hpmvs/Scene.cpp:590-605 */
+static int pixel_free_test(const orc_scene *s, const orc_depths *D, const orc_patch *p, int image) {
+    const orc_camera *cam = &s->cams[image];
+    const int level = (int)roundf(cam_get_level(cam, p->center, p->scale));
+    if (level < 0 || level >= cam->n_levels) return 0;
+    float c[3];
+    cam_project(cam, p->center, level, c);
+    const int ix = (int)(c[0] / c[2] + 0.5), iy = (int)(c[1] / c[2] + 0.5);
+    if (ix < 0 || ix >= s->imgs[image].w[level] || iy < 0 || iy >= s->imgs[image].h[level]) return 0;
+    return get_depth_at_level(D, image, ix, iy, level) == ORC_MAX_DEPTH;
+}
+/* Scene::depthTests / viewBlockTest / pixelFreeTests (src/hpmvs/Scene.cpp:518-524, 607-642, 582-588): the three
+ * counts CellProcessor::extend / ::branch / ::refine gate a refined candidate on (CellProcessor.cpp:134-142). */
+void orc_depth_gates(const orc_scene *s, const orc_depths *D, const orc_patch *p, float margin, int abs_int,
+                     int *n_visible, int *n_blocking, int *n_free) {
+    int vis = 0, blk = 0, fre = 0;
+    for (int i = 0; i < p->n_images; i++) {
+        if (depth_test(s, D, p, p->images[i], margin, 0, abs_int)) vis++;
+        if (pixel_free_test(s, D, p, p->images[i])) fre++;
+    }
+    for (int img = 0; img < s->n_views; img++) {
+        const orc_camera *cam = &s->cams[img];
+        const int level = (int)roundf(cam_get_level(cam, p->center, p->scale));
+        if (level < 0 || level > cam->n_levels - 1) continue;
+        float c[3];
+        cam_project(cam, p->center, level, c);
+        if (c[0] < 0 || c[0] > s->imgs[img].w[level] || c[1] < 0 || c[1] > s->imgs[img].h[level]) continue;
+        if (depth_test(s, D, p, img, margin, 1, abs_int)) blk++;
+    }
+    *n_visible = vis; *n_blocking = blk; *n_free = fre;
+}

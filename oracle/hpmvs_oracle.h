@@ -151,6 +151,18 @@ typedef double (*orc_obj_fn)(unsigned n, const double *x, double *grad, void *da
 int orc_bobyqa_minimize(int which, int n, orc_obj_fn f, void *data, double *x, const double *lb,
                         const double *ub, double xtol_rel, int maxeval, double *minf, int *nevals);
 
+/* Depth maps (Scene.cpp:74-80: MatrixXf(rows, cols) per view and level, MAX_DEPTH = 1000, column-major) and the three
+ * acceptance counts read from them: Scene::setDepths (Scene.cpp:351-381, subtract = false), Scene::depthTests /
+ * viewBlockTest / pixelFreeTests (Scene.cpp:518-644).  abs_int selects the reading of the unqualified abs() at
+ * Scene.cpp:571 (0: fabsf, 1: C's abs(int)). */
+typedef struct orc_depths_s orc_depths;
+orc_depths *orc_depths_create(const orc_scene *s);
+void orc_depths_destroy(orc_depths *D);
+float *orc_depths_level(orc_depths *D, int view, int level, int *rows, int *cols);
+void orc_set_depths(const orc_scene *s, orc_depths *D, const orc_patch *p);
+void orc_depth_gates(const orc_scene *s, const orc_depths *D, const orc_patch *p, float margin, int abs_int,
+                     int *n_visible, int *n_blocking, int *n_free);
+
 /* test-only switch: evaluation order of Eigen's 4-float reductions (0 left-to-right = default, 1 SSE2, 2 SSE3) */
 void orc_set_dot4_order(int order);
 /* Eigen's vector / scalar: 0 true division (Eigen >= 3.2, the default and what the HIP path restates), 1 multiply by the

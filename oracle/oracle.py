@@ -85,6 +85,14 @@ def lib():
     L.orc_expand_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_int, C.POINTER(Patch), C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.POINTER(Patch), C.c_int, C.c_int]
     L.orc_expand_directions.argtypes = [C.c_int, C.c_void_p]
+    L.orc_depths_create.restype = C.c_void_p
+    L.orc_depths_create.argtypes = [C.c_void_p]
+    L.orc_depths_destroy.argtypes = [C.c_void_p]
+    L.orc_depths_level.restype = C.POINTER(C.c_float)
+    L.orc_depths_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_set_depths.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Patch)]
+    L.orc_depth_gates.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Patch), C.c_float, C.c_int, C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.orc_bobyqa_minimize.argtypes = [C.c_int, C.c_int, OBJ_FN, C.c_void_p, C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_int,
                                       C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -165,6 +173,34 @@ class OracleScene:
         w, h = C.c_int(), C.c_int()
         p = lib().orc_scene_level(self.h, i, level, C.byref(w), C.byref(h))
         return np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
+
+
+class OracleDepths:
+    """The depth maps of Scene (reference Scene.cpp:74-80) and the gates over them (Scene.cpp:351-381, 518-644)."""
+
+    def __init__(self, scene: OracleScene):
+        self.scene = scene
+        self.h = lib().orc_depths_create(scene.h)
+
+    def __del__(self):
+        try:
+            lib().orc_depths_destroy(self.h)
+        except Exception:
+            pass
+
+    def level(self, view, level) -> np.ndarray:
+        """One map as an array in Eigen's storage order: shape (cols, rows), element [x, y]."""
+        r, c = C.c_int(), C.c_int()
+        p = lib().orc_depths_level(self.h, view, level, C.byref(r), C.byref(c))
+        return np.ctypeslib.as_array(p, shape=(c.value, r.value))
+
+    def set_depths(self, patch):
+        lib().orc_set_depths(self.scene.h, self.h, C.byref(patch))
+
+    def gates(self, patch, margin=1.0, abs_int=0):
+        v, b, f = C.c_int(), C.c_int(), C.c_int()
+        lib().orc_depth_gates(self.scene.h, self.h, C.byref(patch), float(margin), int(abs_int), C.byref(v), C.byref(b), C.byref(f))
+        return v.value, b.value, f.value
 
 
 def patches_from_seeds(seeds, idx=None):

@@ -125,6 +125,17 @@ int main(int argc, char** argv) {
                    cand[t].center_[1], cand[t].center_[2], cand[t].normal_[0], cand[t].normal_[1], cand[t].normal_[2],
                    cand[t].scale_3dx_, cand[t].images_.size(), cand[t].expanded_ ? 1 : 0);
     }
+    // (4) the depth maps and the acceptance counts of the expansion, batched (Scene.cpp:351-381, 518-644)
+    {
+        std::vector<const mo3d::Patch3d*> acc;
+        for (int i = 0; i < np; i++) if (ok[i]) acc.push_back(patches[i].get());
+        std::vector<int> vis, blk, fre, vis2, blk2, fre2;
+        bool fine = scene.resetDepths() && scene.depthGates(acc.data(), acc.size(), 1.0f, vis, blk, fre);
+        fine = fine && scene.setDepths(acc.data(), acc.size()) && scene.depthGates(acc.data(), acc.size(), 1.0f, vis2, blk2, fre2);
+        for (size_t t = 0; t < acc.size() && fine; t++)
+            printf("depth %zu %d %d %d %d %d %d\n", t, vis[t], blk[t], fre[t], vis2[t], blk2[t], fre2[t]);
+        if (!fine) printf("depth failed\n");
+    }
     printf("good %zu\n", good);
     return 0;
 }

@@ -81,6 +81,17 @@ def test_cpp_patchoptimizer_equals_c_abi(tiny_scene, tiny_seeds, gpu_scene, tmp_
         if want.ok[t]:
             assert int(r[11]) == want.n_images[t]
     assert want.ok.sum() > 0
+    # Scene::resetDepths / setDepths / depthGates (C++ host layer) == the C-ABI batch entries on the same patches
+    rows = [l.split() for l in out if l.startswith("depth")]
+    assert len(rows) == len(keep) and rows[0][1] != "failed"
+    api.depth_reset(gpu_scene)
+    v0, b0, f0 = api.depth_gates_batch(gpu_scene, par, 1.0, 0)
+    par.ok[:] = 1  # (the C ABI records the patches whose ok flag is set)
+    api.set_depths_batch(gpu_scene, par)
+    v1, b1, f1 = api.depth_gates_batch(gpu_scene, par, 1.0, 0)
+    got = np.array([[int(t) for t in r[2:8]] for r in rows])
+    assert np.array_equal(got, np.stack([v0, b0, f0, v1, b1, f1], axis=1))
+    assert (f1 < f0).any() and b0.max() == 0
 
 
 def _dump_scene(path, scene, seeds, n):
