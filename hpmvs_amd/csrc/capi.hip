@@ -5,13 +5,16 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hpmvs_amd.h"
@@ -25,7 +28,8 @@ using namespace hpmvs;
 // reference runs one PatchOptimizer per OpenMP thread against one shared Scene: src/hpmvs/Scene.cpp:94-96,
 // 166-167) never share one.  16 launches in flight per scene; each of them fills the GPU.
 static constexpr int kQueueSlots = 16;
-static constexpr size_t kQueueSlotBytes = 1024;  // the counter block at the head of a workspace (zeroed per launch)
+static constexpr size_t kQueueSlotBytes = 1024;
+static constexpr int kServiceMaxPatches = 4;  // host batches up to this size go through the open batch (Service)  // the counter block at the head of a workspace (zeroed per launch)
 
 static thread_local std::string g_err;
 
@@ -53,6 +57,11 @@ struct hpmvs_scene {
     DevView* dviews = nullptr;
     int32_t* dcovis_off = nullptr;
     int32_t* dcovis = nullptr;
+    // open batches behind single-patch host calls (see Service below); two, so that one can drain while the other is open
+    struct Service;
+    mutable Service* svc[2] = {nullptr, nullptr};
+    mutable int svc_cur = 0;
+    mutable std::mutex svc_mu;
     // depth maps (hpmvs_scene_depth_reset): one pool, per view a table of level pointers
     mutable float* depth_pool = nullptr;
     mutable size_t depth_floats = 0;
@@ -77,6 +86,9 @@ struct hpmvs_scene {
     mutable StageEntry stage[kStageEntries];
     mutable std::atomic<unsigned> stage_next{0};
 };
+
+static int service_quiesce(const hpmvs_scene* s);
+static void service_free(hpmvs_scene* s);
 
 // Workspace hand-out (call with s->mu held).  Before a workspace is reused the launch that used it last must
 // have finished: more than kQueueSlots launches in flight against one scene (e.g. 256 OpenMP threads each
@@ -295,6 +307,7 @@ int hpmvs_scene_commit(hpmvs_scene* s) {
 int hpmvs_scene_destroy(hpmvs_scene* s) {
     if (!s) return HPMVS_OK;
     hipSetDevice(s->device);
+    service_free(s);  // closes and drains the open batches of single-patch calls
     for (void* p : s->allocs) hipFree(p);
     if (s->depth_pool) hipFree(s->depth_pool);
     if (s->ddepth) hipFree(s->ddepth);
@@ -597,6 +610,233 @@ PoolLayout pool_layout(size_t n, size_t m) {
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------
+// OPEN BATCH: the service behind single-patch host calls.
+//
+// The reference's callers hand over ONE patch per optimize() call from many host threads (Scene.cpp:166-167,
+// CellProcessor.cpp:129,256).  A launch per call costs a kernel start and two PCIe copies; a launch per group of
+// callers (the combiner of round 2) makes everybody wait for the slowest patch of the group (450 evaluations against a
+// mean of 88).  Here ONE long-running launch serves them all: its patch arrays live in host-mapped memory and have
+// room for kCap patches; a calling thread appends its patch, publishes the new count (ctrl[0]) and spins on its own
+// done flag, which the kernel sets as soon as that patch's results are visible to the host -- so a caller waits for
+// its own patch only.  The launch is closed (ctrl[1] = 1, the kernel drains and exits) when nobody is waiting any
+// more, when its room is used up, or when the options change; a second Service object takes over meanwhile.
+// Results are those of any other launch: patches are independent.
+// HPMVS_SERVICE_STATS=1: where the time of a call goes (printed at exit)
+static std::atomic<long long> g_svc_calls{0}, g_svc_ns_lock{0}, g_svc_ns_wait{0}, g_svc_ns_total{0}, g_svc_opens{0};
+static bool service_stats() {
+    static const bool on = [] {
+        const char* e = getenv("HPMVS_SERVICE_STATS");
+        const bool v = e && e[0] == '1';
+        if (v) atexit([] {
+            const double c = (double)std::max<long long>(1, g_svc_calls.load());
+            fprintf(stderr, "hpmvs service: %lld calls, %lld launches; per call: submit (lock + copy) %.1f us, wait for the device %.1f us, total %.1f us\n",
+                    g_svc_calls.load(), g_svc_opens.load(), g_svc_ns_lock.load() / c / 1e3, g_svc_ns_wait.load() / c / 1e3, g_svc_ns_total.load() / c / 1e3);
+        });
+        return v;
+    }();
+    return on;
+}
+
+struct hpmvs_scene::Service {
+    static constexpr int kCap = 16384;      // patches per open batch
+    static constexpr int kLanes = 4;        // patches per wavefront (few: latency first)
+    hipStream_t st = nullptr;
+    char* host = nullptr;                   // host-mapped, coherent: patch arrays + ctrl + done flags
+    int32_t* ws = nullptr;                  // launch workspace
+    size_t ws_bytes = 0;
+    int wgs = 0;
+    PoolLayout L;
+    volatile int32_t* ctrl = nullptr;
+    volatile int32_t* done = nullptr;
+    int published = 0;
+    std::atomic<int> outstanding{0};        // published patches whose owner has not picked up the results yet
+    bool open = false, running = false;
+    hpmvs_options opts;
+};
+
+static void service_close(hpmvs_scene::Service& S) {  // call with svc_mu held
+    if (S.open) {
+        std::atomic_thread_fence(std::memory_order_release);
+        S.ctrl[1] = 1;
+        S.open = false;
+    }
+}
+static int service_wait_drained(hpmvs_scene::Service& S) {
+    if (S.running) {
+        HIPCHK(hipStreamSynchronize(S.st));
+        S.running = false;
+    }
+    return HPMVS_OK;
+}
+// closes and drains every open batch of the scene (before anything that synchronises the whole device)
+static int service_quiesce(const hpmvs_scene* s) {
+    std::lock_guard<std::mutex> lk(s->svc_mu);
+    for (int k = 0; k < 2; k++)
+        if (s->svc[k]) {
+            service_close(*s->svc[k]);
+            int rc = service_wait_drained(*s->svc[k]);
+            if (rc) return rc;
+        }
+    return HPMVS_OK;
+}
+static int service_open(const hpmvs_scene* s, hpmvs_scene::Service& S, const hpmvs_options* o) {  // svc_mu held
+    using Service = hpmvs_scene::Service;
+    int rc = service_wait_drained(S);
+    if (rc) return rc;
+    // the owners of the previous generation's patches read their results from S.host: not before they are done
+    while (S.outstanding.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    if (!S.st) {
+        S.L = pool_layout((size_t)Service::kCap, (size_t)HPMVS_MAX_IMAGES);
+        S.wgs = s->n_cus;  // one workgroup per CU: batch launches keep three quarters of every CU
+        if (const char* e = getenv("HPMVS_SERVICE_WGS")) S.wgs = atoi(e) > 0 ? atoi(e) : S.wgs;  // (experiments)
+        S.ws_bytes = (optimize_workspace_bytes_for(S.wgs) + 255) & ~(size_t)255;
+        hipStream_t st = nullptr; char* hv = nullptr; int32_t* wv = nullptr;
+        const size_t hbytes = S.L.total + 256 + sizeof(int32_t) * (size_t)Service::kCap;
+        bool good = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+        good = good && hipHostMalloc((void**)&hv, hbytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+        good = good && hipMalloc((void**)&wv, S.ws_bytes) == hipSuccess;
+        if (!good) {
+            if (wv) hipFree(wv);
+            if (hv) hipHostFree(hv);
+            if (st) hipStreamDestroy(st);
+            return fail(HPMVS_ERR_HIP, "cannot allocate the open batch of single-patch calls");
+        }
+        S.st = st; S.host = hv; S.ws = wv;
+        S.ctrl = (volatile int32_t*)(hv + S.L.total);
+        S.done = (volatile int32_t*)(hv + S.L.total + 256);
+    }
+    memset(S.host + S.L.total, 0, 256 + sizeof(int32_t) * (size_t)Service::kCap);  // ctrl + done flags
+    S.opts = *o;
+    S.published = 0; S.outstanding.store(0);
+    DevBatch D;
+    memset(&D, 0, sizeof(D));
+    D.n = Service::kCap; D.max_images = HPMVS_MAX_IMAGES;
+    char* d = S.host;  // (unified addressing: the host pointer is the device pointer of mapped memory)
+    D.center = (float*)(d + S.L.off_center); D.normal = (float*)(d + S.L.off_normal); D.scale = (float*)(d + S.L.off_scale);
+    D.n_images = (int32_t*)(d + S.L.off_nimg); D.images = (int32_t*)(d + S.L.off_images);
+    D.ok = (uint8_t*)(d + S.L.off_ok); D.color = (float*)(d + S.L.off_color); D.ncc = (float*)(d + S.L.off_ncc);
+    D.fmin = (double*)(d + S.L.off_fmin); D.x = (double*)(d + S.L.off_x); D.result = (int32_t*)(d + S.L.off_result);
+    D.nevals = (int32_t*)(d + S.L.off_nevals); D.stage = (int32_t*)(d + S.L.off_stage); D.ngrabs = (int32_t*)(d + S.L.off_ngrabs);
+    D.svc_ctrl = (const int32_t*)S.ctrl; D.svc_done = (int32_t*)S.done; D.svc_lanes = Service::kLanes;
+    if (const char* e = getenv("HPMVS_SERVICE_LANES")) D.svc_lanes = atoi(e) > 0 ? atoi(e) : D.svc_lanes;  // (experiments)
+    HIPCHK(hipMemsetAsync(S.ws, 0, kQueueSlotBytes, S.st));
+    launch_optimize_service(dev_scene(s), make_dev_options(o), D, S.ws, S.wgs, S.st);
+    HIPCHK(hipGetLastError());
+    S.open = true; S.running = true;
+    g_svc_opens++;
+    return HPMVS_OK;
+}
+
+static void service_free(hpmvs_scene* s) {
+    service_quiesce(s);
+    for (int k = 0; k < 2; k++)
+        if (s->svc[k]) {
+            if (s->svc[k]->ws) hipFree(s->svc[k]->ws);
+            if (s->svc[k]->host) hipHostFree(s->svc[k]->host);
+            if (s->svc[k]->st) hipStreamDestroy(s->svc[k]->st);
+            delete s->svc[k];
+            s->svc[k] = nullptr;
+        }
+}
+
+static bool service_enabled() {
+    static const bool on = [] { const char* e = getenv("HPMVS_SERVICE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// hpmvs_optimize_batch for a handful of host-resident patches (the unchanged callers' optimize() = batch of one)
+static int optimize_through_service(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_patch_batch* b) {
+    using Service = hpmvs_scene::Service;
+    const int n = b->n, m = b->max_images;
+    const bool stats = service_stats();
+    const auto t_in = std::chrono::steady_clock::now();
+    Service* S = nullptr;
+    int k0 = 0;
+    {
+        std::lock_guard<std::mutex> lk(s->svc_mu);
+        if (!s->svc[0]) { s->svc[0] = new Service(); s->svc[1] = new Service(); }
+        Service* cur = s->svc[s->svc_cur];
+        if (!cur->open || cur->published + n > Service::kCap || memcmp(&cur->opts, o, sizeof(*o)) != 0) {
+            service_close(*cur);
+            s->svc_cur ^= 1;
+            cur = s->svc[s->svc_cur];
+            service_close(*cur);  // (can only be open if the options flipped twice)
+            const int rc = service_open(s, *cur, o);
+            if (rc) return rc;
+        }
+        S = cur;
+        k0 = S->published;
+        char* h = S->host;
+        for (int i = 0; i < n; i++) {
+            const size_t k = (size_t)(k0 + i);
+            memcpy(h + S->L.off_center + 16 * k, b->center + 4 * i, 16);
+            memcpy(h + S->L.off_normal + 16 * k, b->normal + 4 * i, 16);
+            memcpy(h + S->L.off_scale + 4 * k, b->scale + i, 4);
+            // a list longer than the caller's row cannot come back: failed like every other launch does (stage 100)
+            const int32_t ni = b->n_images[i] > m ? (int32_t)(HPMVS_MAX_IMAGES + 1) : b->n_images[i];
+            memcpy(h + S->L.off_nimg + 4 * k, &ni, 4);
+            memcpy(h + S->L.off_images + 4 * k * HPMVS_MAX_IMAGES, b->images + (size_t)i * m, 4 * (size_t)m);
+        }
+        std::atomic_thread_fence(std::memory_order_release);
+        S->ctrl[0] = k0 + n;  // published
+        S->published += n; S->outstanding.fetch_add(n);
+    }
+    const auto t_sub = std::chrono::steady_clock::now();
+    // wait for my own patches only
+    int rc = HPMVS_OK;
+    for (int i = 0; i < n && rc == HPMVS_OK; i++) {
+        const int k = k0 + i;
+        unsigned spins = 0;
+        auto t_check = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
+        while (S->done[k] == 0) {
+            if (++spins < 2000) { __builtin_ia32_pause(); continue; }
+            std::this_thread::yield();
+            if ((spins & 0xfff) == 0 && std::chrono::steady_clock::now() > t_check) {
+                // the launch must still be running while my flag is down
+                const hipError_t q = hipStreamQuery(S->st);
+                if (q != hipErrorNotReady && S->done[k] == 0) { rc = fail(HPMVS_ERR_HIP, "open batch ended without finishing a published patch"); break; }
+                t_check = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (rc) break;
+        if (stats && i == n - 1) g_svc_ns_wait += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_sub).count();
+        const char* h = S->host;
+        const size_t kk = (size_t)k;
+        uint8_t okv = *(const uint8_t*)(h + S->L.off_ok + kk);
+        int32_t nout = *(const int32_t*)(h + S->L.off_nimg + 4 * kk);
+        int32_t stg = *(const int32_t*)(h + S->L.off_stage + 4 * kk);
+        if (okv && nout > m) { okv = 0; stg = 100; }  // refined list longer than the caller's row
+        b->ok[i] = okv;
+        if (okv) {
+            memcpy(b->center + 4 * i, h + S->L.off_center + 16 * kk, 16);
+            memcpy(b->normal + 4 * i, h + S->L.off_normal + 16 * kk, 16);
+            b->n_images[i] = nout;
+            memcpy(b->images + (size_t)i * m, h + S->L.off_images + 4 * kk * HPMVS_MAX_IMAGES, 4 * (size_t)m);
+        }
+        if (b->color) memcpy(b->color + 3 * i, h + S->L.off_color + 12 * kk, 12);
+        if (b->ncc) memcpy(b->ncc + i, h + S->L.off_ncc + 4 * kk, 4);
+        if (b->fmin) memcpy(b->fmin + i, h + S->L.off_fmin + 8 * kk, 8);
+        if (b->x) memcpy(b->x + 3 * i, h + S->L.off_x + 24 * kk, 24);
+        if (b->result) memcpy(b->result + i, h + S->L.off_result + 4 * kk, 4);
+        if (b->nevals) memcpy(b->nevals + i, h + S->L.off_nevals + 4 * kk, 4);
+        if (b->stage) b->stage[i] = stg;
+        if (b->ngrabs) memcpy(b->ngrabs + i, h + S->L.off_ngrabs + 4 * kk, 4);
+    }
+    if (stats) {
+        const auto t_out = std::chrono::steady_clock::now();
+        g_svc_calls++;
+        g_svc_ns_lock += std::chrono::duration_cast<std::chrono::nanoseconds>(t_sub - t_in).count();
+        g_svc_ns_total += std::chrono::duration_cast<std::chrono::nanoseconds>(t_out - t_in).count();
+    }
+    if (S->outstanding.fetch_sub(n, std::memory_order_acq_rel) == n) {  // I was the last one waiting
+        std::lock_guard<std::mutex> lk(s->svc_mu);
+        if (S->outstanding.load() == 0) service_close(*S);  // nobody is waiting: let the launch end
+    }
+    return rc;
+}
+
 static int optimize_small_host_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_patch_batch* b) {
     const size_t n = (size_t)b->n, m = (size_t)b->max_images;
     const PoolLayout L = pool_layout(n, m);
@@ -664,6 +904,7 @@ int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_pat
     if (!b->ok) return fail(HPMVS_ERR_ARG, "optimize_batch: ok[] is required");
     if (b->n == 0) return HPMVS_OK;
     HIPCHK(hipSetDevice(s->device));
+    if (!on_device && !stream && b->n <= kServiceMaxPatches && service_enabled()) return optimize_through_service(s, o, b);
     if (!on_device && !stream && b->n <= hpmvs_scene::kStageCapPatches) return optimize_small_host_batch(s, o, b);
     hipStream_t st = (hipStream_t)stream;
     Staged sg;
@@ -898,7 +1139,7 @@ int hpmvs_scene_depth_reset(hpmvs_scene* s) {
     }
     launch_depth_fill(s->depth_pool, s->depth_floats, nullptr);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamSynchronize(nullptr));  // (not the whole device: an open batch of single-patch calls may be running)
     return HPMVS_OK;
 }
 
@@ -925,7 +1166,7 @@ int hpmvs_scene_depth_get_level(const hpmvs_scene* s, int view, int level, float
     if (!data) return HPMVS_OK;  // shape query
     if (capacity < (size_t)r * c) return fail(HPMVS_ERR_ARG, "scene_depth_get_level: buffer too small");
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamSynchronize(nullptr));
     HIPCHK(hipMemcpy(data, p, sizeof(float) * (size_t)r * c, hipMemcpyDeviceToHost));
     return HPMVS_OK;
 }
@@ -984,6 +1225,7 @@ int hpmvs_depth_gates_batch(const hpmvs_scene* s, const hpmvs_patch_batch* b, fl
 int hpmvs_debug_counters(const hpmvs_scene* s, unsigned long long* out4) {
     if (!s || !out4) return fail(HPMVS_ERR_ARG, "debug_counters: null argument");
     HIPCHK(hipSetDevice(s->device));
+    { const int rcq = service_quiesce(s); if (rcq) return rcq; }
     HIPCHK(hipDeviceSynchronize());
     if (!s->last_queue) return fail(HPMVS_ERR_STATE, "debug_counters: no launch yet");
     HIPCHK(hipMemcpy(out4, (char*)s->last_queue + 16, 544, hipMemcpyDeviceToHost));

@@ -61,6 +61,10 @@ struct DevBatch {
     int32_t* n_images; int32_t* images;
     uint8_t* ok; float* color; float* ncc;
     double* fmin; double* x; int32_t* result; int32_t* nevals; int32_t* stage; int32_t* ngrabs;
+    // open batch (single-patch callers, capi.hip: Service): the arrays above are host-mapped and have room for n
+    // patches, of which svc_ctrl[0] are published so far (the host appends while the kernel runs; svc_ctrl[1] != 0:
+    // no more will come); the kernel sets svc_done[i] once patch i's results are visible to the host
+    const int32_t* svc_ctrl; int32_t* svc_done; int32_t svc_lanes;
 };
 
 }  // namespace hpmvs

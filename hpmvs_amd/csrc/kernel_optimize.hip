@@ -95,6 +95,15 @@ __device__ __forceinline__ void page_out(uint4* __restrict__ park) {
 
 }  // namespace
 
+// patch-array accesses: plain in a batch launch; system-scope (cache-bypassing) in an open batch, whose arrays are
+// host memory that the host appends to / reads from while the kernel runs
+template <typename T> __device__ __forceinline__ T ld_batch(const T* p, bool sys) {
+    return sys ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *p;
+}
+template <typename T> __device__ __forceinline__ void st_batch(T* p, T v, bool sys) {
+    if (sys) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else *p = v;
+}
+
 #ifndef HPMVS_WAVES_PER_EU
 #define HPMVS_WAVES_PER_EU 2
 #endif
@@ -115,8 +124,16 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
     // Small batches are spread over as many workgroups as possible (a wavefront with fewer busy slots has shorter
     // rounds: one lone patch advances ~2.4x faster than one of ten), and over the FIRST wavefronts of the
     // workgroups before any second one gets work: a lone wavefront keeps the state region and never pages.
+    // OPEN BATCH (b.svc_ctrl != nullptr; the service behind single-patch host callers, capi.hip): the patch arrays
+    // are host memory, the host appends patches while this launch runs, and a lane that holds queue ticket i waits
+    // (without blocking its wavefront) until patch i has been published.  The first wavefront of workgroup 0 (the
+    // dispatcher) copies the host's progress words into the launch workspace once per round; everybody else polls
+    // that copy.  No cache maintenance anywhere in the protocol: host words, patch arrays and done flags are accessed
+    // with cache-bypassing system-scope loads / stores, the copies with relaxed agent-scope atomics.
+    const bool service = b.svc_ctrl != nullptr;
     const int per_wg = (b.n + n_wgs - 1) / n_wgs;
-    const int quota = wv == 0 ? (per_wg < kP ? per_wg : kP) : (per_wg - kP < 0 ? 0 : (per_wg - kP < kP ? per_wg - kP : kP));
+    int quota = wv == 0 ? (per_wg < kP ? per_wg : kP) : (per_wg - kP < 0 ? 0 : (per_wg - kP < kP ? per_wg - kP : kP));
+    if (service) quota = wv == 0 ? (b.svc_lanes < kP ? b.svc_lanes : kP) : 0;  // few patches per wavefront: latency first
     if (threadIdx.x == 0) { hpmvs_lock[0] = 0; hpmvs_lock[1] = 0; }
     __syncthreads();
     if (quota == 0) {  // nothing to do for this wavefront: tell the partner that the region is his
@@ -152,27 +169,59 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
     // results delivered by the list services (pipeline.hpp)
     int res_n = 0, res_fail = 0;
     float res_rgb[3] = {0, 0, 0};
+    int svc_n = 0, svc_closed = 0;  // open batch: patches published so far / no more will come
     for (;;) {
+        bool yield = false;  // open batch: my ticket's patch has not been published yet
+        if (service) {
+            if (gw == 0 && lane == 0) {  // the dispatcher: host progress words -> launch workspace
+                const int closed = __hip_atomic_load(&b.svc_ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // closed before the count: a count read after it is final
+                const int n_pub = __hip_atomic_load(&b.svc_ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&queue[32], n_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the count is out before the closed flag
+                __hip_atomic_store(&queue[33], closed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            int cl = 0, np = 0;
+            if (lane == 0) {
+                cl = __hip_atomic_load(&queue[33], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // closed is read first
+                np = __hip_atomic_load(&queue[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            svc_closed = bcast_i(cl, 0);
+            svc_n = bcast_i(np, 0);
+        }
         // ================= phase A: every lane advances its own patch until it needs the wave
-        while (op == OP_NONE && stage != S_IDLE) {
+        while (op == OP_NONE && stage != S_IDLE && !yield) {
             bool finish_fail = false, finish_ok = false;
             switch (stage) {
-            case S_FETCH: {
+            case S_FETCH:
                 idx = atomicAdd(queue, 1);
                 if (idx >= b.n) { stage = S_IDLE; break; }
-                for (int k = 0; k < 3; k++) { c0[k] = b.center[4 * idx + k]; n0[k] = b.normal[4 * idx + k]; c[k] = c0[k]; n[k] = n0[k]; }
-                scale = b.scale[idx];
-                nimg = b.n_images[idx];
+                if (service) { stage = S_WAIT; break; }
+                [[fallthrough]];
+            case S_WAIT: {
+                if (service && stage == S_WAIT) {
+                    if (idx >= svc_n) {  // not published yet (or never: the batch was closed before my ticket)
+                        if (svc_closed) stage = S_IDLE; else yield = true;
+                        break;
+                    }
+                }
+                for (int k = 0; k < 3; k++) {
+                    c0[k] = ld_batch(&b.center[4 * idx + k], service); n0[k] = ld_batch(&b.normal[4 * idx + k], service);
+                    c[k] = c0[k]; n[k] = n0[k];
+                }
+                scale = ld_batch(&b.scale[idx], service);
+                nimg = ld_batch(&b.n_images[idx], service);
                 ngrabs = 0; nl_result = 0;
                 // optimiser diagnostics of a patch that never reaches the optimiser (overwritten when it finishes)
-                if (b.fmin) b.fmin[idx] = 0.0;
-                if (b.x) for (int k = 0; k < 3; k++) b.x[3 * idx + k] = 0.0;
-                if (b.nevals) b.nevals[idx] = 0;
+                if (b.fmin) st_batch(&b.fmin[idx], 0.0, service);
+                if (b.x) for (int k = 0; k < 3; k++) st_batch(&b.x[3 * idx + k], 0.0, service);
+                if (b.nevals) st_batch(&b.nevals[idx], 0, service);
                 if (nimg < 0) { fail_stage = -nimg; nimg = 0; finish_fail = true; break; }  // rejected by seed_init_kernel
                 if (nimg > kMaxImages || nimg > b.max_images) { fail_stage = 100; finish_fail = true; break; }
                 bool bad_id = false;
                 for (int k = 0; k < nimg; k++) {
-                    const int id = b.images[(size_t)idx * b.max_images + k];
+                    const int id = ld_batch(&b.images[(size_t)idx * b.max_images + k], service);
                     bad_id |= (id < 0 || id >= sc.n_views);
                     row[k] = (uint16_t)id;
                 }
@@ -253,19 +302,24 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
             default: stage = S_IDLE; break;
             }
             if (finish_ok || finish_fail) {
-                b.ok[idx] = finish_ok ? 1 : 0;
+                st_batch(&b.ok[idx], (uint8_t)(finish_ok ? 1 : 0), service);
                 if (finish_ok) {
-                    for (int k = 0; k < 3; k++) { b.center[4 * idx + k] = c[k]; b.normal[4 * idx + k] = n[k]; }
-                    b.center[4 * idx + 3] = 1.0f;
-                    b.normal[4 * idx + 3] = 0.0f;
-                    b.n_images[idx] = nimg;
-                    for (int k = 0; k < nimg && k < b.max_images; k++) b.images[(size_t)idx * b.max_images + k] = row[k];
-                    if (b.color) { b.color[3 * idx] = res_rgb[0]; b.color[3 * idx + 1] = res_rgb[1]; b.color[3 * idx + 2] = res_rgb[2]; }
-                    if (b.ncc) b.ncc[idx] = 1.4f;  // PatchOptimizer.cpp:95
+                    for (int k = 0; k < 3; k++) { st_batch(&b.center[4 * idx + k], c[k], service); st_batch(&b.normal[4 * idx + k], n[k], service); }
+                    st_batch(&b.center[4 * idx + 3], 1.0f, service);
+                    st_batch(&b.normal[4 * idx + 3], 0.0f, service);
+                    st_batch(&b.n_images[idx], (int32_t)nimg, service);
+                    for (int k = 0; k < nimg && k < b.max_images; k++) st_batch(&b.images[(size_t)idx * b.max_images + k], (int32_t)row[k], service);
+                    if (b.color) for (int k = 0; k < 3; k++) st_batch(&b.color[3 * idx + k], res_rgb[k], service);
+                    if (b.ncc) st_batch(&b.ncc[idx], 1.4f, service);  // PatchOptimizer.cpp:95
                 }
-                if (b.stage) b.stage[idx] = finish_ok ? 0 : fail_stage;
-                if (b.result) b.result[idx] = nl_result;
-                if (b.ngrabs) b.ngrabs[idx] = ngrabs;
+                if (b.stage) st_batch(&b.stage[idx], (int32_t)(finish_ok ? 0 : fail_stage), service);
+                if (b.result) st_batch(&b.result[idx], (int32_t)nl_result, service);
+                if (b.ngrabs) st_batch(&b.ngrabs[idx], (int32_t)ngrabs, service);
+                if (service) {  // results first (host memory: done once the stores are acknowledged), then the flag the
+                                // owning host thread spins on
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&b.svc_done[idx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 stage = S_FETCH;
             }
         }
@@ -334,9 +388,9 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
                 for (int k = 0; k < 3; k++) xe[k] = BQA(xeval, k);  // next point, or the final one (same slot)
                 if (ret != BQ_CONTINUE) {
                     nl_result = BQN(rc);
-                    if (b.fmin) b.fmin[idx] = BQS(minf);
-                    if (b.x) for (int k = 0; k < 3; k++) b.x[3 * idx + k] = xe[k];
-                    if (b.nevals) b.nevals[idx] = BQN(nevals);
+                    if (b.fmin) st_batch(&b.fmin[idx], (double)BQS(minf), service);
+                    if (b.x) for (int k = 0; k < 3; k++) st_batch(&b.x[3 * idx + k], xe[k], service);
+                    if (b.nevals) st_batch(&b.nevals[idx], (int32_t)BQN(nevals), service);
                 }
             }
             if (!solo) {  // park my states and hand the region to the partner wavefront
@@ -382,8 +436,17 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
 #ifdef HPMVS_PROFILE_PHASES
         { const long long t1 = clock64(); tA += t1 - t0; t0 = t1; nrounds++; nreq += __popcll(pending); }
 #endif
-        if (pending == 0ull) {  // every lane idle and nothing posted: queue drained
-            if (lane == 0) atomicOr(&hpmvs_lock[1], 1 << wv);
+        if (pending == 0ull) {  // nothing posted
+            // open batch: lanes are waiting for their patch; and the dispatcher stays until the batch is closed
+            if (service && (__any(stage != S_IDLE) || (gw == 0 && !svc_closed))) {
+                // ~10 us between polls: a waiting wavefront must not take issue slots or cache contents from the ones
+                // that work (1024 waiting workgroups polling every microsecond made a lone patch 5x slower); the
+                // dispatcher reads the host words every ~1 us
+                if (gw == 0) __builtin_amdgcn_s_sleep(32);
+                else { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+                continue;
+            }
+            if (lane == 0) atomicOr(&hpmvs_lock[1], 1 << wv);  // every lane idle: queue drained
             break;
         }
         {
@@ -438,6 +501,15 @@ size_t optimize_workspace_bytes(int n_cus) {
     // counter block + per wavefront: kP image-list rows and one parking buffer for the optimiser states
     const size_t waves = (size_t)2 * max_workgroups(n_cus);
     return kCounterBytes + waves * kP * kRow * sizeof(uint16_t) + waves * (size_t)kPark16 * 16;
+}
+
+// open batch (b.svc_ctrl set): a fixed grid of `wgs` workgroups (one per CU leaves room for batch launches beside it)
+size_t optimize_workspace_bytes_for(int wgs) {
+    return kCounterBytes + (size_t)2 * wgs * kP * kRow * sizeof(uint16_t) + (size_t)2 * wgs * (size_t)kPark16 * 16;
+}
+void launch_optimize_service(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int wgs,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(optimize_kernel, dim3(wgs), dim3(128), 0, st, sc, o, b, workspace);
 }
 
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus,

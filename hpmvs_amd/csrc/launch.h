@@ -26,6 +26,11 @@ void launch_expand_gate(int mode, int n, const DevBatch& parents, const float* c
 size_t optimize_workspace_bytes(int n_cus);
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace,
                      int n_cus, hipStream_t st);
+// open batch (DevBatch::svc_ctrl set, arrays host-mapped): `wgs` persistent workgroups, workspace of
+// optimize_workspace_bytes_for(wgs) bytes with a zeroed first 1 KB
+size_t optimize_workspace_bytes_for(int wgs);
+void launch_optimize_service(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int wgs,
+                             hipStream_t st);
 
 // depth maps and the acceptance gates over them (kernel_depth.hip)
 void launch_depth_fill(float* p, size_t n, hipStream_t st);

@@ -28,7 +28,7 @@ enum Op { OP_NONE = 0, OP_OBJ = 1, OP_INCC = 2, OP_REFSUM = 3,
           OPL_ADD = 4, OPL_F1 = 5, OPL_F2 = 6, OPL_F3 = 7,  // list services (this file)
           OPQ_START = 8, OPQ_STEP = 9 };                    // optimiser service (kernel_optimize.hip)
 enum Stage {
-    S_FETCH = 0, S_ADD1, S_F1, S_F1B, S_BQ, S_BQFAIL, S_ADD2, S_F2, S_F2B, S_RS, S_F3, S_F3B, S_IDLE
+    S_FETCH = 0, S_WAIT, S_ADD1, S_F1, S_F1B, S_BQ, S_BQFAIL, S_ADD2, S_F2, S_F2B, S_RS, S_F3, S_F3B, S_IDLE
 };
 
 struct U3 { float x, y, z; };  // a wave-uniform 3-vector

@@ -477,6 +477,16 @@ PatchOptimizer::PatchOptimizer(const mo3d::HpmvsOptions& options, const mo3d::Sc
     : options_p(&options), scene_p(scene) {}
 
 bool PatchOptimizer::optimize(mo3d::Patch3d& patch) {
+    // Default: a batch of one through the C ABI, which serves small host batches from ONE long-running launch that all
+    // calling threads feed (capi.hip, "open batch"): a caller waits for its own patch only.  HPMVS_SERVICE=0 selects
+    // the round-2 combiner below (concurrent callers are grouped into launches and wait for the group's slowest patch).
+    static const bool use_service = [] { const char* e = getenv("HPMVS_SERVICE"); return !(e && e[0] == '0'); }();
+    if (use_service) {
+        mo3d::Patch3d* one = &patch;
+        uint8_t ok = 0;
+        optimizeBatch(&one, 1, &ok);
+        return ok != 0;
+    }
     Combiner& C = *(Combiner*)scene_p->combiner();
     Combiner::Entry me;
     me.patch = &patch; me.opt = options_p;
