@@ -15,6 +15,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <time.h>
 #include <vector>
 
 #include "../../include/hpmvs_amd.h"
@@ -623,6 +624,7 @@ PoolLayout pool_layout(size_t n, size_t m) {
 // more, when its room is used up, or when the options change; a second Service object takes over meanwhile.
 // Results are those of any other launch: patches are independent.
 // HPMVS_SERVICE_STATS=1: where the time of a call goes (printed at exit)
+static std::atomic<long long> g_svc_ns_hold{0};
 static std::atomic<long long> g_svc_calls{0}, g_svc_ns_lock{0}, g_svc_ns_wait{0}, g_svc_ns_total{0}, g_svc_opens{0};
 static bool service_stats() {
     static const bool on = [] {
@@ -630,8 +632,8 @@ static bool service_stats() {
         const bool v = e && e[0] == '1';
         if (v) atexit([] {
             const double c = (double)std::max<long long>(1, g_svc_calls.load());
-            fprintf(stderr, "hpmvs service: %lld calls, %lld launches; per call: submit (lock + copy) %.1f us, wait for the device %.1f us, total %.1f us\n",
-                    g_svc_calls.load(), g_svc_opens.load(), g_svc_ns_lock.load() / c / 1e3, g_svc_ns_wait.load() / c / 1e3, g_svc_ns_total.load() / c / 1e3);
+            fprintf(stderr, "hpmvs service: %lld calls, %lld launches; per call: submit (lock + copy) %.1f us of which the lock is held %.1f us, wait for the device %.1f us, total %.1f us\n",
+                    g_svc_calls.load(), g_svc_opens.load(), g_svc_ns_lock.load() / c / 1e3, g_svc_ns_hold.load() / c / 1e3, g_svc_ns_wait.load() / c / 1e3, g_svc_ns_total.load() / c / 1e3);
         });
         return v;
     }();
@@ -640,13 +642,14 @@ static bool service_stats() {
 
 struct hpmvs_scene::Service {
     static constexpr int kCap = 16384;      // patches per open batch
-    static constexpr int kLanes = 4;        // patches per wavefront (few: latency first)
+    static constexpr int kLanes = 2;        // patches per wavefront (few: latency first)
     hipStream_t st = nullptr;
-    char* host = nullptr;                   // host-mapped, coherent: patch arrays + ctrl + done flags
-    int32_t* ws = nullptr;                  // launch workspace
-    size_t ws_bytes = 0;
+    char* host = nullptr;                   // host-mapped, coherent: IN records, OUT records, ctrl words, done flags
+    int32_t* ws = nullptr;                  // launch workspace + the slots' staging records
+    size_t ws_bytes = 0, stage_off = 0;
     int wgs = 0;
-    PoolLayout L;
+    uint32_t* in = nullptr;                 // kCap x kSvcInDwords
+    uint32_t* out = nullptr;                // kCap x kSvcOutDwords
     volatile int32_t* ctrl = nullptr;
     volatile int32_t* done = nullptr;
     int published = 0;
@@ -686,13 +689,15 @@ static int service_open(const hpmvs_scene* s, hpmvs_scene::Service& S, const hpm
     if (rc) return rc;
     // the owners of the previous generation's patches read their results from S.host: not before they are done
     while (S.outstanding.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    const size_t in_bytes = sizeof(uint32_t) * kSvcInDwords * (size_t)Service::kCap;
+    const size_t out_bytes = sizeof(uint32_t) * kSvcOutDwords * (size_t)Service::kCap;
     if (!S.st) {
-        S.L = pool_layout((size_t)Service::kCap, (size_t)HPMVS_MAX_IMAGES);
         S.wgs = s->n_cus;  // one workgroup per CU: batch launches keep three quarters of every CU
         if (const char* e = getenv("HPMVS_SERVICE_WGS")) S.wgs = atoi(e) > 0 ? atoi(e) : S.wgs;  // (experiments)
-        S.ws_bytes = (optimize_workspace_bytes_for(S.wgs) + 255) & ~(size_t)255;
+        S.stage_off = (optimize_workspace_bytes_for(S.wgs) + 255) & ~(size_t)255;
+        S.ws_bytes = S.stage_off + optimize_stage_bytes_for(S.wgs);
         hipStream_t st = nullptr; char* hv = nullptr; int32_t* wv = nullptr;
-        const size_t hbytes = S.L.total + 256 + sizeof(int32_t) * (size_t)Service::kCap;
+        const size_t hbytes = in_bytes + out_bytes + 256 + sizeof(int32_t) * (size_t)Service::kCap;
         bool good = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
         good = good && hipHostMalloc((void**)&hv, hbytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
         good = good && hipMalloc((void**)&wv, S.ws_bytes) == hipSuccess;
@@ -703,21 +708,18 @@ static int service_open(const hpmvs_scene* s, hpmvs_scene::Service& S, const hpm
             return fail(HPMVS_ERR_HIP, "cannot allocate the open batch of single-patch calls");
         }
         S.st = st; S.host = hv; S.ws = wv;
-        S.ctrl = (volatile int32_t*)(hv + S.L.total);
-        S.done = (volatile int32_t*)(hv + S.L.total + 256);
+        S.in = (uint32_t*)hv; S.out = (uint32_t*)(hv + in_bytes);
+        S.ctrl = (volatile int32_t*)(hv + in_bytes + out_bytes);
+        S.done = (volatile int32_t*)(hv + in_bytes + out_bytes + 256);
     }
-    memset(S.host + S.L.total, 0, 256 + sizeof(int32_t) * (size_t)Service::kCap);  // ctrl + done flags
+    memset((void*)S.ctrl, 0, 256 + sizeof(int32_t) * (size_t)Service::kCap);  // ctrl + done flags
     S.opts = *o;
     S.published = 0; S.outstanding.store(0);
     DevBatch D;
     memset(&D, 0, sizeof(D));
     D.n = Service::kCap; D.max_images = HPMVS_MAX_IMAGES;
-    char* d = S.host;  // (unified addressing: the host pointer is the device pointer of mapped memory)
-    D.center = (float*)(d + S.L.off_center); D.normal = (float*)(d + S.L.off_normal); D.scale = (float*)(d + S.L.off_scale);
-    D.n_images = (int32_t*)(d + S.L.off_nimg); D.images = (int32_t*)(d + S.L.off_images);
-    D.ok = (uint8_t*)(d + S.L.off_ok); D.color = (float*)(d + S.L.off_color); D.ncc = (float*)(d + S.L.off_ncc);
-    D.fmin = (double*)(d + S.L.off_fmin); D.x = (double*)(d + S.L.off_x); D.result = (int32_t*)(d + S.L.off_result);
-    D.nevals = (int32_t*)(d + S.L.off_nevals); D.stage = (int32_t*)(d + S.L.off_stage); D.ngrabs = (int32_t*)(d + S.L.off_ngrabs);
+    // (unified addressing: the host pointer is the device pointer of mapped memory)
+    D.svc_in = (const unsigned long long*)S.in; D.svc_out = S.out; D.svc_stage = (uint32_t*)((char*)S.ws + S.stage_off);
     D.svc_ctrl = (const int32_t*)S.ctrl; D.svc_done = (int32_t*)S.done; D.svc_lanes = Service::kLanes;
     if (const char* e = getenv("HPMVS_SERVICE_LANES")) D.svc_lanes = atoi(e) > 0 ? atoi(e) : D.svc_lanes;  // (experiments)
     HIPCHK(hipMemsetAsync(S.ws, 0, kQueueSlotBytes, S.st));
@@ -754,7 +756,14 @@ static int optimize_through_service(const hpmvs_scene* s, const hpmvs_options* o
     Service* S = nullptr;
     int k0 = 0;
     {
-        std::lock_guard<std::mutex> lk(s->svc_mu);
+        // the critical section is a few microseconds; a contended futex hand-over costs far more than that (256 callers:
+        // ~1 ms per submission in the convoy), so try for a moment before queueing up
+        bool got = false;
+        for (int spin = 0; spin < 400 && !(got = s->svc_mu.try_lock()); spin++) __builtin_ia32_pause();
+        if (!got) s->svc_mu.lock();
+        std::lock_guard<std::mutex> lk(s->svc_mu, std::adopt_lock);
+        const auto t_held = std::chrono::steady_clock::now();
+        struct Hold { bool on; std::chrono::steady_clock::time_point t0; ~Hold() { if (on) g_svc_ns_hold += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } } hold{stats, t_held};
         if (!s->svc[0]) { s->svc[0] = new Service(); s->svc[1] = new Service(); }
         Service* cur = s->svc[s->svc_cur];
         if (!cur->open || cur->published + n > Service::kCap || memcmp(&cur->opts, o, sizeof(*o)) != 0) {
@@ -767,22 +776,21 @@ static int optimize_through_service(const hpmvs_scene* s, const hpmvs_options* o
         }
         S = cur;
         k0 = S->published;
-        char* h = S->host;
         for (int i = 0; i < n; i++) {
-            const size_t k = (size_t)(k0 + i);
-            memcpy(h + S->L.off_center + 16 * k, b->center + 4 * i, 16);
-            memcpy(h + S->L.off_normal + 16 * k, b->normal + 4 * i, 16);
-            memcpy(h + S->L.off_scale + 4 * k, b->scale + i, 4);
+            uint32_t* rec = S->in + (size_t)(k0 + i) * kSvcInDwords;
+            memcpy(rec + 0, b->center + 4 * i, 12); memcpy(rec + 3, b->scale + i, 4);
+            memcpy(rec + 4, b->normal + 4 * i, 12);
             // a list longer than the caller's row cannot come back: failed like every other launch does (stage 100)
             const int32_t ni = b->n_images[i] > m ? (int32_t)(HPMVS_MAX_IMAGES + 1) : b->n_images[i];
-            memcpy(h + S->L.off_nimg + 4 * k, &ni, 4);
-            memcpy(h + S->L.off_images + 4 * k * HPMVS_MAX_IMAGES, b->images + (size_t)i * m, 4 * (size_t)m);
+            memcpy(rec + 7, &ni, 4);
+            memcpy(rec + 8, b->images + (size_t)i * m, 4 * (size_t)m);
         }
         std::atomic_thread_fence(std::memory_order_release);
         S->ctrl[0] = k0 + n;  // published
         S->published += n; S->outstanding.fetch_add(n);
     }
     const auto t_sub = std::chrono::steady_clock::now();
+    static const long poll_us = [] { const char* e = getenv("HPMVS_SERVICE_POLL_US"); return e ? atol(e) : 50L; }();
     // wait for my own patches only
     int rc = HPMVS_OK;
     for (int i = 0; i < n && rc == HPMVS_OK; i++) {
@@ -790,8 +798,14 @@ static int optimize_through_service(const hpmvs_scene* s, const hpmvs_options* o
         unsigned spins = 0;
         auto t_check = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
         while (S->done[k] == 0) {
-            if (++spins < 2000) { __builtin_ia32_pause(); continue; }
-            std::this_thread::yield();
+            // Poll gently: the flags live in host memory that the GPU writes over PCIe, and hundreds of cores reading
+            // those lines back to back delay exactly those writes and the device's reads of the progress words
+            // (256 threads spinning: 6.7 k patches/s; sleeping 50 us between polls: 50 k).  A patch
+            // needs milliseconds on the device, so the sleep costs nothing.
+            ++spins;
+            if (poll_us > 0) { struct timespec ts = {0, poll_us * 1000L}; nanosleep(&ts, nullptr); }
+            else if (spins < 2000) { __builtin_ia32_pause(); continue; }
+            else std::this_thread::yield();
             if ((spins & 0xfff) == 0 && std::chrono::steady_clock::now() > t_check) {
                 // the launch must still be running while my flag is down
                 const hipError_t q = hipStreamQuery(S->st);
@@ -802,27 +816,26 @@ static int optimize_through_service(const hpmvs_scene* s, const hpmvs_options* o
         std::atomic_thread_fence(std::memory_order_acquire);
         if (rc) break;
         if (stats && i == n - 1) g_svc_ns_wait += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_sub).count();
-        const char* h = S->host;
-        const size_t kk = (size_t)k;
-        uint8_t okv = *(const uint8_t*)(h + S->L.off_ok + kk);
-        int32_t nout = *(const int32_t*)(h + S->L.off_nimg + 4 * kk);
-        int32_t stg = *(const int32_t*)(h + S->L.off_stage + 4 * kk);
+        const uint32_t* rec = S->out + (size_t)k * kSvcOutDwords;
+        uint8_t okv = rec[0] ? 1 : 0;
+        int32_t nout = (int32_t)rec[5];
+        int32_t stg = (int32_t)rec[1];
         if (okv && nout > m) { okv = 0; stg = 100; }  // refined list longer than the caller's row
         b->ok[i] = okv;
         if (okv) {
-            memcpy(b->center + 4 * i, h + S->L.off_center + 16 * kk, 16);
-            memcpy(b->normal + 4 * i, h + S->L.off_normal + 16 * kk, 16);
+            memcpy(b->center + 4 * i, rec + 8, 16);
+            memcpy(b->normal + 4 * i, rec + 12, 16);
             b->n_images[i] = nout;
-            memcpy(b->images + (size_t)i * m, h + S->L.off_images + 4 * kk * HPMVS_MAX_IMAGES, 4 * (size_t)m);
+            for (int q = 0; q < m; q++) b->images[(size_t)i * m + q] = q < nout ? (int32_t)rec[32 + q] : b->images[(size_t)i * m + q];
+            if (b->color) memcpy(b->color + 3 * i, rec + 16, 12);
+            if (b->ncc) memcpy(b->ncc + i, rec + 19, 4);
         }
-        if (b->color) memcpy(b->color + 3 * i, h + S->L.off_color + 12 * kk, 12);
-        if (b->ncc) memcpy(b->ncc + i, h + S->L.off_ncc + 4 * kk, 4);
-        if (b->fmin) memcpy(b->fmin + i, h + S->L.off_fmin + 8 * kk, 8);
-        if (b->x) memcpy(b->x + 3 * i, h + S->L.off_x + 24 * kk, 24);
-        if (b->result) memcpy(b->result + i, h + S->L.off_result + 4 * kk, 4);
-        if (b->nevals) memcpy(b->nevals + i, h + S->L.off_nevals + 4 * kk, 4);
+        if (b->fmin) memcpy(b->fmin + i, rec + 20, 8);
+        if (b->x) memcpy(b->x + 3 * i, rec + 22, 24);
+        if (b->result) b->result[i] = (int32_t)rec[2];
+        if (b->nevals) b->nevals[i] = (int32_t)rec[3];
         if (b->stage) b->stage[i] = stg;
-        if (b->ngrabs) memcpy(b->ngrabs + i, h + S->L.off_ngrabs + 4 * kk, 4);
+        if (b->ngrabs) b->ngrabs[i] = (int32_t)rec[4];
     }
     if (stats) {
         const auto t_out = std::chrono::steady_clock::now();

@@ -55,15 +55,23 @@ struct DevOptions {
 };
 
 // Batch arrays on the device (see hpmvs_patch_batch in include/hpmvs_amd.h)
+// record layouts of an open batch (dwords).  IN: 0-2 centre, 3 scale, 4-6 normal, 7 n_images, 8-71 image ids.
+// OUT: 0 ok, 1 stage, 2 nlopt result, 3 evaluations, 4 grabs, 5 n_images, 8-11 centre, 12-15 normal, 16-18 colour,
+// 19 ncc, 20-21 fmin (f64), 22-27 x (f64 x 3), 32-95 image ids.
+constexpr int kSvcInDwords = 80;
+constexpr int kSvcOutDwords = 96;
+
 struct DevBatch {
     int32_t n, max_images;
     float* center; float* normal; float* scale;
     int32_t* n_images; int32_t* images;
     uint8_t* ok; float* color; float* ncc;
     double* fmin; double* x; int32_t* result; int32_t* nevals; int32_t* stage; int32_t* ngrabs;
-    // open batch (single-patch callers, capi.hip: Service): the arrays above are host-mapped and have room for n
-    // patches, of which svc_ctrl[0] are published so far (the host appends while the kernel runs; svc_ctrl[1] != 0:
-    // no more will come); the kernel sets svc_done[i] once patch i's results are visible to the host
+    // open batch (single-patch callers, capi.hip: Service): n = room of the batch; the host appends patches while the
+    // kernel runs.  svc_in / svc_out: host-mapped records of kSvcInDwords / kSvcOutDwords dwords per patch, svc_ctrl[0]
+    // = patches published so far, svc_ctrl[1] != 0: no more will come; the kernel sets svc_done[i] once patch i's
+    // output record is visible to the host.  svc_stage: device-memory staging records, one per resident slot.
+    const unsigned long long* svc_in; uint32_t* svc_out; uint32_t* svc_stage;
     const int32_t* svc_ctrl; int32_t* svc_done; int32_t svc_lanes;
 };
 

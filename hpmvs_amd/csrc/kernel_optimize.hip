@@ -95,13 +95,10 @@ __device__ __forceinline__ void page_out(uint4* __restrict__ park) {
 
 }  // namespace
 
-// patch-array accesses: plain in a batch launch; system-scope (cache-bypassing) in an open batch, whose arrays are
-// host memory that the host appends to / reads from while the kernel runs
-template <typename T> __device__ __forceinline__ T ld_batch(const T* p, bool sys) {
-    return sys ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *p;
-}
-template <typename T> __device__ __forceinline__ void st_batch(T* p, T v, bool sys) {
-    if (sys) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else *p = v;
+// open batch: the records live in host memory that the host writes / reads while the kernel runs: cache-bypassing
+// system-scope accesses, no cache maintenance
+__device__ __forceinline__ unsigned long long ld_host64(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 #ifndef HPMVS_WAVES_PER_EU
@@ -170,6 +167,9 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
     int res_n = 0, res_fail = 0;
     float res_rgb[3] = {0, 0, 0};
     int svc_n = 0, svc_closed = 0;  // open batch: patches published so far / no more will come
+    uint32_t* srec = service ? b.svc_stage + ((size_t)gw * kP + (lane < kP ? lane : 0)) * kSvcOutDwords : nullptr;
+    int fin_idx = 0;
+    bool fin_pending = false;  // open batch: my staging record waits for the wavefront to copy it to the host
     for (;;) {
         bool yield = false;  // open batch: my ticket's patch has not been published yet
         if (service) {
@@ -177,15 +177,15 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
                 const int closed = __hip_atomic_load(&b.svc_ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // closed before the count: a count read after it is final
                 const int n_pub = __hip_atomic_load(&b.svc_ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(&queue[32], n_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&queue[200], n_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the count is out before the closed flag
-                __hip_atomic_store(&queue[33], closed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&queue[201], closed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             int cl = 0, np = 0;
             if (lane == 0) {
-                cl = __hip_atomic_load(&queue[33], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cl = __hip_atomic_load(&queue[201], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // closed is read first
-                np = __hip_atomic_load(&queue[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                np = __hip_atomic_load(&queue[200], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             svc_closed = bcast_i(cl, 0);
             svc_n = bcast_i(np, 0);
@@ -206,24 +206,43 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
                         break;
                     }
                 }
-                for (int k = 0; k < 3; k++) {
-                    c0[k] = ld_batch(&b.center[4 * idx + k], service); n0[k] = ld_batch(&b.normal[4 * idx + k], service);
-                    c[k] = c0[k]; n[k] = n0[k];
-                }
-                scale = ld_batch(&b.scale[idx], service);
-                nimg = ld_batch(&b.n_images[idx], service);
-                ngrabs = 0; nl_result = 0;
-                // optimiser diagnostics of a patch that never reaches the optimiser (overwritten when it finishes)
-                if (b.fmin) st_batch(&b.fmin[idx], 0.0, service);
-                if (b.x) for (int k = 0; k < 3; k++) st_batch(&b.x[3 * idx + k], 0.0, service);
-                if (b.nevals) st_batch(&b.nevals[idx], 0, service);
-                if (nimg < 0) { fail_stage = -nimg; nimg = 0; finish_fail = true; break; }  // rejected by seed_init_kernel
-                if (nimg > kMaxImages || nimg > b.max_images) { fail_stage = 100; finish_fail = true; break; }
                 bool bad_id = false;
-                for (int k = 0; k < nimg; k++) {
-                    const int id = ld_batch(&b.images[(size_t)idx * b.max_images + k], service);
-                    bad_id |= (id < 0 || id >= sc.n_views);
-                    row[k] = (uint16_t)id;
+                if (service) {  // my patch's input record (host memory): 4 + n_images / 2 eight-byte reads
+                    const unsigned long long* in = b.svc_in + (size_t)idx * (kSvcInDwords / 2);
+                    const unsigned long long w0 = ld_host64(in), w1 = ld_host64(in + 1), w2 = ld_host64(in + 2), w3 = ld_host64(in + 3);
+                    c0[0] = __uint_as_float((unsigned)w0); c0[1] = __uint_as_float((unsigned)(w0 >> 32));
+                    c0[2] = __uint_as_float((unsigned)w1); scale = __uint_as_float((unsigned)(w1 >> 32));
+                    n0[0] = __uint_as_float((unsigned)w2); n0[1] = __uint_as_float((unsigned)(w2 >> 32));
+                    n0[2] = __uint_as_float((unsigned)w3); nimg = (int)(unsigned)(w3 >> 32);
+                    for (int k = 0; k < 3; k++) { c[k] = c0[k]; n[k] = n0[k]; }
+                    ngrabs = 0; nl_result = 0;
+                    srec[3] = 0;                                        // evaluations
+                    for (int k = 20; k < 28; k++) srec[k] = 0;          // fmin, x
+                    if (nimg < 0) { fail_stage = -nimg; nimg = 0; finish_fail = true; break; }
+                    if (nimg > kMaxImages || nimg > b.max_images) { fail_stage = 100; finish_fail = true; break; }
+                    for (int k = 0; k < nimg; k += 2) {
+                        const unsigned long long w = ld_host64(in + 4 + k / 2);
+                        const int id0 = (int)(unsigned)w, id1 = (int)(unsigned)(w >> 32);
+                        bad_id |= (id0 < 0 || id0 >= sc.n_views);
+                        row[k] = (uint16_t)id0;
+                        if (k + 1 < nimg) { bad_id |= (id1 < 0 || id1 >= sc.n_views); row[k + 1] = (uint16_t)id1; }
+                    }
+                } else {
+                    for (int k = 0; k < 3; k++) { c0[k] = b.center[4 * idx + k]; n0[k] = b.normal[4 * idx + k]; c[k] = c0[k]; n[k] = n0[k]; }
+                    scale = b.scale[idx];
+                    nimg = b.n_images[idx];
+                    ngrabs = 0; nl_result = 0;
+                    // optimiser diagnostics of a patch that never reaches the optimiser (overwritten when it finishes)
+                    if (b.fmin) b.fmin[idx] = 0.0;
+                    if (b.x) for (int k = 0; k < 3; k++) b.x[3 * idx + k] = 0.0;
+                    if (b.nevals) b.nevals[idx] = 0;
+                    if (nimg < 0) { fail_stage = -nimg; nimg = 0; finish_fail = true; break; }  // rejected by seed_init_kernel
+                    if (nimg > kMaxImages || nimg > b.max_images) { fail_stage = 100; finish_fail = true; break; }
+                    for (int k = 0; k < nimg; k++) {
+                        const int id = b.images[(size_t)idx * b.max_images + k];
+                        bad_id |= (id < 0 || id >= sc.n_views);
+                        row[k] = (uint16_t)id;
+                    }
                 }
                 if (bad_id) { fail_stage = 101; finish_fail = true; break; }  // image id outside the scene: rejected, never dereferenced
                 op = OPL_ADD;  // addImages
@@ -302,25 +321,54 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
             default: stage = S_IDLE; break;
             }
             if (finish_ok || finish_fail) {
-                st_batch(&b.ok[idx], (uint8_t)(finish_ok ? 1 : 0), service);
-                if (finish_ok) {
-                    for (int k = 0; k < 3; k++) { st_batch(&b.center[4 * idx + k], c[k], service); st_batch(&b.normal[4 * idx + k], n[k], service); }
-                    st_batch(&b.center[4 * idx + 3], 1.0f, service);
-                    st_batch(&b.normal[4 * idx + 3], 0.0f, service);
-                    st_batch(&b.n_images[idx], (int32_t)nimg, service);
-                    for (int k = 0; k < nimg && k < b.max_images; k++) st_batch(&b.images[(size_t)idx * b.max_images + k], (int32_t)row[k], service);
-                    if (b.color) for (int k = 0; k < 3; k++) st_batch(&b.color[3 * idx + k], res_rgb[k], service);
-                    if (b.ncc) st_batch(&b.ncc[idx], 1.4f, service);  // PatchOptimizer.cpp:95
-                }
-                if (b.stage) st_batch(&b.stage[idx], (int32_t)(finish_ok ? 0 : fail_stage), service);
-                if (b.result) st_batch(&b.result[idx], (int32_t)nl_result, service);
-                if (b.ngrabs) st_batch(&b.ngrabs[idx], (int32_t)ngrabs, service);
-                if (service) {  // results first (host memory: done once the stores are acknowledged), then the flag the
-                                // owning host thread spins on
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(&b.svc_done[idx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (service) {
+                    // my slot's staging record (device memory); the wavefront copies it to the host below
+                    srec[0] = finish_ok ? 1u : 0u; srec[1] = (unsigned)(finish_ok ? 0 : fail_stage); srec[2] = (unsigned)nl_result;
+                    srec[4] = (unsigned)ngrabs; srec[5] = (unsigned)(finish_ok ? nimg : 0);
+                    if (finish_ok) {
+                        for (int k = 0; k < 3; k++) { srec[8 + k] = __float_as_uint(c[k]); srec[12 + k] = __float_as_uint(n[k]); srec[16 + k] = __float_as_uint(res_rgb[k]); }
+                        srec[11] = __float_as_uint(1.0f); srec[15] = __float_as_uint(0.0f);
+                        srec[19] = __float_as_uint(1.4f);  // PatchOptimizer.cpp:95
+                        for (int k = 0; k < nimg && k < b.max_images; k++) srec[32 + k] = row[k];
+                    }
+                    fin_idx = idx; fin_pending = true; yield = true;
+                } else {
+                    b.ok[idx] = finish_ok ? 1 : 0;
+                    if (finish_ok) {
+                        for (int k = 0; k < 3; k++) { b.center[4 * idx + k] = c[k]; b.normal[4 * idx + k] = n[k]; }
+                        b.center[4 * idx + 3] = 1.0f;
+                        b.normal[4 * idx + 3] = 0.0f;
+                        b.n_images[idx] = nimg;
+                        for (int k = 0; k < nimg && k < b.max_images; k++) b.images[(size_t)idx * b.max_images + k] = row[k];
+                        if (b.color) { b.color[3 * idx] = res_rgb[0]; b.color[3 * idx + 1] = res_rgb[1]; b.color[3 * idx + 2] = res_rgb[2]; }
+                        if (b.ncc) b.ncc[idx] = 1.4f;  // PatchOptimizer.cpp:95
+                    }
+                    if (b.stage) b.stage[idx] = finish_ok ? 0 : fail_stage;
+                    if (b.result) b.result[idx] = nl_result;
+                    if (b.ngrabs) b.ngrabs[idx] = ngrabs;
                 }
                 stage = S_FETCH;
+            }
+        }
+        // ================= open batch: finished patches go to the host, one 384-byte record each, written by the whole
+        // wavefront (two coalesced stores + one flag: host-memory transactions are what bounds the callers' rate)
+        if (service) {
+            const unsigned long long fm = __ballot(fin_pending);
+            if (fm) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the lanes' staging stores are out
+                for (unsigned long long t = fm; t; t &= t - 1ull) {
+                    const int p = __ffsll((long long)t) - 1;
+                    const int pidx = bcast_i(fin_idx, p);
+                    const uint32_t* src = b.svc_stage + ((size_t)gw * kP + p) * kSvcOutDwords;
+                    uint32_t* dst = b.svc_out + (size_t)pidx * kSvcOutDwords;
+                    const uint32_t v0 = __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t v1 = lane < kSvcOutDwords - 64 ? __hip_atomic_load(src + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    __hip_atomic_store(dst + lane, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (lane < kSvcOutDwords - 64) __hip_atomic_store(dst + 64 + lane, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // records first, then the flags the owners spin on
+                if (fin_pending) __hip_atomic_store(&b.svc_done[fin_idx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                fin_pending = false;
             }
         }
         // ================= list services: the image-list passes, one request at a time, 64 lanes wide (pipeline.hpp)
@@ -343,7 +391,7 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
                     if (kind == OPL_ADD) r.nimg = coop_add_images(sc, o, prow, pn, pc, pnrm, pscale);
                     else if (kind == OPL_F1) r = coop_list_f1(sc, o, prow, pn, pmask, pc, pnrm, pscale);
                     else if (kind == OPL_F2) r = coop_list_f2(sc, o, prow, pn, pmask, pc, pnrm);
-                    else r = coop_list_f3(sc, o, prow, pn, pmask, pc, pscale, b.max_images, b.color != nullptr);
+                    else r = coop_list_f3(sc, o, prow, pn, pmask, pc, pscale, b.max_images, service || b.color != nullptr);
                     if (lane == p) {
                         res_n = r.nimg; res_fail = r.fail;
                         res_rgb[0] = r.rgb.x; res_rgb[1] = r.rgb.y; res_rgb[2] = r.rgb.z;
@@ -388,9 +436,19 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
                 for (int k = 0; k < 3; k++) xe[k] = BQA(xeval, k);  // next point, or the final one (same slot)
                 if (ret != BQ_CONTINUE) {
                     nl_result = BQN(rc);
-                    if (b.fmin) st_batch(&b.fmin[idx], (double)BQS(minf), service);
-                    if (b.x) for (int k = 0; k < 3; k++) st_batch(&b.x[3 * idx + k], xe[k], service);
-                    if (b.nevals) st_batch(&b.nevals[idx], (int32_t)BQN(nevals), service);
+                    if (service) {
+                        const unsigned long long mf = (unsigned long long)__double_as_longlong((double)BQS(minf));
+                        srec[3] = (unsigned)BQN(nevals);
+                        srec[20] = (unsigned)mf; srec[21] = (unsigned)(mf >> 32);
+                        for (int k = 0; k < 3; k++) {
+                            const unsigned long long xv = (unsigned long long)__double_as_longlong(xe[k]);
+                            srec[22 + 2 * k] = (unsigned)xv; srec[23 + 2 * k] = (unsigned)(xv >> 32);
+                        }
+                    } else {
+                        if (b.fmin) b.fmin[idx] = BQS(minf);
+                        if (b.x) for (int k = 0; k < 3; k++) b.x[3 * idx + k] = xe[k];
+                        if (b.nevals) b.nevals[idx] = BQN(nevals);
+                    }
                 }
             }
             if (!solo) {  // park my states and hand the region to the partner wavefront
@@ -507,6 +565,7 @@ size_t optimize_workspace_bytes(int n_cus) {
 size_t optimize_workspace_bytes_for(int wgs) {
     return kCounterBytes + (size_t)2 * wgs * kP * kRow * sizeof(uint16_t) + (size_t)2 * wgs * (size_t)kPark16 * 16;
 }
+size_t optimize_stage_bytes_for(int wgs) { return (size_t)2 * wgs * kP * kSvcOutDwords * sizeof(uint32_t); }
 void launch_optimize_service(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int wgs,
                              hipStream_t st) {
     hipLaunchKernelGGL(optimize_kernel, dim3(wgs), dim3(128), 0, st, sc, o, b, workspace);

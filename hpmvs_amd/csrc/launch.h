@@ -29,6 +29,7 @@ void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b,
 // open batch (DevBatch::svc_ctrl set, arrays host-mapped): `wgs` persistent workgroups, workspace of
 // optimize_workspace_bytes_for(wgs) bytes with a zeroed first 1 KB
 size_t optimize_workspace_bytes_for(int wgs);
+size_t optimize_stage_bytes_for(int wgs);  // the slots' staging records (DevBatch::svc_stage)
 void launch_optimize_service(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int wgs,
                              hipStream_t st);
 
