@@ -107,7 +107,10 @@ __device__ __forceinline__ unsigned long long ld_host64(const unsigned long long
 #ifndef HPMVS_BQ_PRIO
 #define HPMVS_BQ_PRIO 1  // s_setprio while the state region is held (C2: 308 -> 302 ms)
 #endif
-__global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
+// SERVICE = false: a batch launch (the arrays of `b` are device memory, n patches).  SERVICE = true: an open batch (see
+// OPEN BATCH below).  Two instantiations, so that the batch kernel carries none of the open batch's code or registers.
+template <bool SERVICE>
+__device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
     const int lane = lane_id();
     const int wv = (int)(threadIdx.x >> 6);            // which wavefront of the pair
     const int n_wgs = (int)gridDim.x;
@@ -127,7 +130,7 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
     // dispatcher) copies the host's progress words into the launch workspace once per round; everybody else polls
     // that copy.  No cache maintenance anywhere in the protocol: host words, patch arrays and done flags are accessed
     // with cache-bypassing system-scope loads / stores, the copies with relaxed agent-scope atomics.
-    const bool service = b.svc_ctrl != nullptr;
+    constexpr bool service = SERVICE;
     const int per_wg = (b.n + n_wgs - 1) / n_wgs;
     int quota = wv == 0 ? (per_wg < kP ? per_wg : kP) : (per_wg - kP < 0 ? 0 : (per_wg - kP < kP ? per_wg - kP : kP));
     if (service) quota = wv == 0 ? (b.svc_lanes < kP ? b.svc_lanes : kP) : 0;  // few patches per wavefront: latency first
@@ -543,6 +546,13 @@ __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevSc
 #endif
 }
 
+__global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
+    optimize_body<false>(sc, o, b, queue);
+}
+__global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_service_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
+    optimize_body<true>(sc, o, b, queue);
+}
+
 static int max_workgroups(int n_cus) {
     // two-wavefront workgroups per CU: LDS (one state region each) and the waves-per-SIMD limit
     int lds_per_wg = (int)(HPMVS_REGION_16 * 16 + 2 * sizeof(int));
@@ -568,7 +578,7 @@ size_t optimize_workspace_bytes_for(int wgs) {
 size_t optimize_stage_bytes_for(int wgs) { return (size_t)2 * wgs * kP * kSvcOutDwords * sizeof(uint32_t); }
 void launch_optimize_service(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int wgs,
                              hipStream_t st) {
-    hipLaunchKernelGGL(optimize_kernel, dim3(wgs), dim3(128), 0, st, sc, o, b, workspace);
+    hipLaunchKernelGGL(optimize_service_kernel, dim3(wgs), dim3(128), 0, st, sc, o, b, workspace);
 }
 
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus,
