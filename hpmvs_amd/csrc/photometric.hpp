@@ -274,15 +274,19 @@ __device__ __forceinline__ float lane_prev(float v) {
 // Sequential float32 sum over a group's window in pixel order: lane yy contributes v[0..N-1] in order, lane
 // yy+1 continues from lane yy's total.  ((0 + row0.v0) + row0.v1 ...) + row1.v0 ... -- the summation order of
 // Patch2d::normalize / dot.  The total is valid on lane yy == 6 of the group.
+// (No select per stage: after stage s the value is right on the lanes with yy == s -- by induction, since such a
+//  lane read its left neighbour's value right after stage s - 1 -- and whatever the other lanes hold is never read
+//  when it matters: a lane's value is consumed by its right neighbour in the very next stage, and the final stage
+//  leaves the total on yy == 6.)
 template <int N>
-__device__ __forceinline__ float row_chain(const float (&v)[N], int yy) {
+__device__ __forceinline__ float row_chain(const float (&v)[N]) {
     float out = 0.0f;
 #pragma unroll
     for (int s = 0; s < kTex; s++) {
         float a = (s == 0) ? 0.0f : lane_prev(out);
 #pragma unroll
         for (int i = 0; i < N; i++) a += v[i];
-        out = (yy == s) ? a : out;
+        out = a;
     }
     return out;
 }
@@ -498,7 +502,7 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
                 float vr[kTex], vg[kTex], vb[kTex];
 #pragma unroll
                 for (int xx = 0; xx < kTex; xx++) { vr[xx] = t[3 * xx]; vg[xx] = t[3 * xx + 1]; vb[xx] = t[3 * xx + 2]; }
-                const float s0 = row_chain<kTex>(vr, yy), s1 = row_chain<kTex>(vg, yy), s2 = row_chain<kTex>(vb, yy);
+                const float s0 = row_chain<kTex>(vr), s1 = row_chain<kTex>(vg), s2 = row_chain<kTex>(vb);
                 a0 = div_by(shfl_f(s0, last), 1.0 / 49.0);
                 a1 = div_by(shfl_f(s1, last), 1.0 / 49.0);
                 a2 = div_by(shfl_f(s2, last), 1.0 / 49.0);
@@ -511,7 +515,7 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
                     const float f0 = a0 - t[3 * xx], f1 = a1 - t[3 * xx + 1], f2 = a2 - t[3 * xx + 2];
                     sq[xx] = f0 * f0 + f1 * f1 + f2 * f2;
                 }
-                float v2 = sqrtf(div_by(shfl_f(row_chain<kTex>(sq, yy), last), 1.0 / 147.0));
+                float v2 = sqrtf(div_by(shfl_f(row_chain<kTex>(sq), last), 1.0 / 147.0));
                 if (v2 == 0.0f) v2 = 1.0f;
                 iv = recip64(v2);
             }
@@ -534,7 +538,7 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
                 }
                 PH_T(t6);
                 PH_ADD(t5, t6, 20);
-                raw = 1.0f - div_by(shfl_f(row_chain<kRowVals>(pr, yy), last), 1.0 / 147.0);
+                raw = 1.0f - div_by(shfl_f(row_chain<kRowVals>(pr), last), 1.0 / 147.0);
                 rob = robustincc(raw);
                 PH_T(t7);
                 PH_ADD(t6, t7, 21);
