@@ -98,10 +98,11 @@ __device__ __forceinline__ void project0(const float* P, float X0, float X1, flo
     const float r0 = ((P[0] * X0 + P[1] * X1) + P[2] * X2) + P[3];
     const float r1 = ((P[4] * X0 + P[5] * X1) + P[6] * X2) + P[7];
     const float r2 = ((P[8] * X0 + P[9] * X1) + P[10] * X2) + P[11];
-    if (r2 <= 0.0f) { u = -65535.0f; v = -65535.0f; return; }
     const float lo = -2147483648.0f, hi = 2147483648.0f;  // (float)(INT_MIN+3.0f), (float)(INT_MAX-3.0f)
-    u = fmaxf(lo, fminf(hi, r0 / r2));
-    v = fmaxf(lo, fminf(hi, r1 / r2));
+    const float uu = fmaxf(lo, fminf(hi, r0 / r2)), vv = fmaxf(lo, fminf(hi, r1 / r2));
+    const bool behind = r2 <= 0.0f;
+    u = behind ? -65535.0f : uu;
+    v = behind ? -65535.0f : vv;
 }
 
 // Camera::getLeveli (Camera.cpp:92-99): clamp(round(log2(scale*fsum/(2*fz))), 0, max_level),
@@ -131,15 +132,17 @@ struct Prep {
 // pyramid level, projected window, bounding-box gate.
 __device__ __forceinline__ Prep prep_image(const DevView& V, const DevOptions& o, const float* c, float scale,
                                            const float* pxa, const float* pya, const float* zax) {
+    // Branch-free on purpose: one basic block, so that the loads and the long-latency divisions of two calls (the
+    // two job sets of the evaluator) interleave; the gates only decide `ok` at the end, exactly as sampleTexture's
+    // early returns do.
     Prep r;
-    r.ok = 0; r.tlx = r.tly = r.dxx = r.dxy = r.dyx = r.dyy = 0.0f; r.pix = nullptr; r.W = 0;
     const float d0 = V.center[0] - c[0], d1 = V.center[1] - c[1], d2 = V.center[2] - c[2];
     const float n2 = (d0 * d0 + d1 * d1) + d2 * d2;  // w components cancel (1 - 1)
     const float nn = sqrtf(n2);
-    float g;
-    if (n2 > 0.0f) g = ((d0 / nn) * zax[0] + (d1 / nn) * zax[1]) + (d2 / nn) * zax[2];
-    else g = (d0 * zax[0] + d1 * zax[1]) + d2 * zax[2];
-    if ((double)g < o.cos_max_d) return r;
+    const float g_unit = ((d0 / nn) * zax[0] + (d1 / nn) * zax[1]) + (d2 / nn) * zax[2];
+    const float g_raw = (d0 * zax[0] + d1 * zax[1]) + d2 * zax[2];
+    const float g = (n2 > 0.0f) ? g_unit : g_raw;
+    const bool angle_ok = !((double)g < o.cos_max_d);
 
     const int lvl = level_clamped(scale, V.fsum, nn, o.MAXLEVEL - 1);
     float P[12];
@@ -162,8 +165,8 @@ __device__ __forceinline__ Prep prep_image(const DevView& V, const DevOptions& o
     const float mxx = fmaxf(fmaxf(fmaxf(tlx, trx), blx), brx), mxy = fmaxf(fmaxf(fmaxf(tly, try_), bly), bry);
     const int W = V.w[lvl], H = V.h[lvl];
     const float m = 3.0f;
-    if (mnx < m || mny < m || mxx >= (float)(W - 3) || mxy >= (float)(H - 3)) return r;
-    r.ok = 1;
+    const bool box_ok = !(mnx < m || mny < m || mxx >= (float)(W - 3) || mxy >= (float)(H - 3));
+    r.ok = (angle_ok && box_ok) ? 1 : 0;
     r.tlx = tlx; r.tly = tly; r.dxx = dxx; r.dxy = dxy; r.dyx = dyx; r.dyy = dyy;
     r.pix = V.pix[lvl];
     r.W = W;
@@ -348,16 +351,15 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
             const float scale = shfl_f(q.scale, src);
             const unsigned long long lb = ((unsigned long long)(unsigned int)shfl_i(list_hi, src) << 32) |
                                           (unsigned long long)(unsigned int)shfl_i(list_lo, src);
-            Prep P;
-            P.ok = 0; P.tlx = P.tly = P.dxx = P.dxy = P.dyx = P.dyy = 0.0f; P.pix = nullptr; P.W = 0;
-            if (jp >= 0) P = prep_image(sc.views[(int)((const ListT*)lb)[ji]], o, c, scale, pxa, pya, zax);
+            int id = 0;  // (a lane without a job prepares view 0 and drops the result: no branch around prep_image)
+            if (jp >= 0) id = (int)((const ListT*)lb)[ji];
+            Prep P = prep_image(sc.views[id], o, c, scale, pxa, pya, zax);
+            P.ok = (jp >= 0) ? P.ok : 0;
             return P;
         };
-        const Prep PA = prep_job(jpA, jiA);
-        Prep PB;
-        PB.ok = 0; PB.tlx = PB.tly = PB.dxx = PB.dxy = PB.dyx = PB.dyy = 0.0f; PB.pix = nullptr; PB.W = 0;
         const bool two_sets = J > 64;
-        if (two_sets) PB = prep_job(jpB, jiB);
+        const Prep PA = prep_job(jpA, jiA);
+        const Prep PB = prep_job(jpB, jiB);  // (unconditionally: the two calls interleave; an empty set costs little)
         const unsigned long long okA = __ballot(PA.ok != 0), okB = __ballot(PB.ok != 0);
         const unsigned long long pixA = (unsigned long long)PA.pix, pixB = (unsigned long long)PB.pix;
         const int pixA_lo = (int)(pixA & 0xffffffffull), pixA_hi = (int)(pixA >> 32);
