@@ -105,7 +105,11 @@ __device__ __forceinline__ unsigned long long ld_host64(const unsigned long long
 #define HPMVS_WAVES_PER_EU 2
 #endif
 #ifndef HPMVS_BQ_PRIO
-#define HPMVS_BQ_PRIO 1  // s_setprio while the state region is held (C2: 308 -> 302 ms)
+#define HPMVS_BQ_PRIO 3  // s_setprio while the state region is held (C2: 308 -> 302 ms)
+#endif
+#ifndef HPMVS_A_PRIO
+#define HPMVS_A_PRIO 2   // ... and in the rest of phase A (serial per-lane code the whole wavefront waits for); the
+                        // photometric service runs at 0 (C2: 300 -> 296.5 ms)
 #endif
 // SERVICE = false: a batch launch (the arrays of `b` are device memory, n patches).  SERVICE = true: an open batch (see
 // OPEN BATCH below).  Two instantiations, so that the batch kernel carries none of the open batch's code or registers.
@@ -140,6 +144,7 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
         if (lane == 0) atomicOr(&hpmvs_lock[1], 1 << wv);
         return;
     }
+    __builtin_amdgcn_s_setprio(HPMVS_A_PRIO);
     bool held = false, solo = false;  // region held by this wavefront; partner gone (held for good, no paging)
     bool parked = false;              // my states are in the parking buffer
     int stage = (lane < quota) ? S_FETCH : S_IDLE;  // the other lanes only help in the wave-cooperative phases
@@ -465,7 +470,7 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
                 BQ_PROF_END(tpo_, 26);
             }
 #if HPMVS_BQ_PRIO
-            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(HPMVS_A_PRIO);
 #endif
             if (mine) {
                 if (ret == BQ_CONTINUE) {
@@ -518,7 +523,9 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
             for (int k = 0; k < 3; k++) { q.c[k] = c[k]; q.zax[k] = (op == OP_OBJ) ? az[k] : n[k]; q.px[k] = ax[k]; q.py[k] = ay[k]; }
             PackedRes r;
             r.obj = 2.0; r.keep = 0ull; r.incc_sum = 0.0f; r.ngrabs = 0;
+            __builtin_amdgcn_s_setprio(0);
             wave_eval_rows<false>(sc, o, (const uint16_t*)row, pending, q, r, nullptr);
+            __builtin_amdgcn_s_setprio(HPMVS_A_PRIO);
             if (op != OP_NONE) {
                 res_f = r.obj;
                 res_mask = r.keep;
