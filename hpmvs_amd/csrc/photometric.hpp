@@ -267,6 +267,11 @@ __device__ __forceinline__ void texel(const Taps& t, float& r, float& g, float& 
 }
 
 constexpr int kGroups = 9;               // grabs per pass: nine 7-lane groups, lane 63 is spare
+#ifndef HPMVS_JOB_SETS
+#define HPMVS_JOB_SETS 2   // measured at C2: 2 sets 297 ms, 3 sets 319 ms, 4 sets 309 ms (fewer passes, but the per-pass fetch and
+                           // the registers of the extra sets cost more than the passes they save)
+#endif
+constexpr int kJobSets = HPMVS_JOB_SETS;  // job lanes are used this many times over: up to 64 * kJobSets (request, image) pairs per batch
 constexpr int kRowVals = 3 * kTex;       // 21 float32 values (7 texels x RGB) per lane
 
 // value held by lane - 1 (lane 0 receives 0): DPP wave_shr:1, folded by the compiler into the consuming add
@@ -315,28 +320,39 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
     unsigned long long rem = pending;
     while (rem) {
         // ---- a batch of whole requests whose jobs fit two sets of 64 job lanes (at least one request)
+        // When the pending requests need several batches they are cut EVENLY: a batch's pass count is about
+        // max(longest request, grabs / 9) + 1, so a last batch with a handful of requests wastes most of its groups.
+        int j_rem = 0;
+        for (unsigned long long t = rem; t; t &= t - 1ull) j_rem += bcast_i(q.nimg, __ffsll((long long)t) - 1);
+        const int n_batches = (j_rem + 64 * kJobSets - 1) / (64 * kJobSets);
+        const int j_target = n_batches > 1 ? (j_rem + n_batches - 1) / n_batches : 64 * kJobSets;
         unsigned long long batch = 0ull;
         int J = 0;
         for (unsigned long long t = rem; t; t &= t - 1ull) {
             const int p = __ffsll((long long)t) - 1;
             const int np = bcast_i(q.nimg, p);
-            if (batch && J + np > 128) break;
+            if (batch && (J + np > 64 * kJobSets || J >= j_target)) break;
             batch |= 1ull << p;
             J += np;
         }
         rem &= ~batch;
         PH_T(t1);
-        // ---- jobs of this lane: job `lane` of set A and job 64 + `lane` of set B -> (request, image index)
+        // ---- jobs of this lane: job 64 * k + lane of set k -> (request, image index)
         int myoff = 0;  // requesting lanes: index of my request's first job
-        int jpA = -1, jiA = 0, jpB = -1, jiB = 0;
+        int jp[kJobSets], ji[kJobSets];
+#pragma unroll
+        for (int k = 0; k < kJobSets; k++) { jp[k] = -1; ji[k] = 0; }
         {
             int off = 0;
             for (unsigned long long t = batch; t; t &= t - 1ull) {
                 const int p = __ffsll((long long)t) - 1;
                 const int np = bcast_i(q.nimg, p);
                 if (lane == p) myoff = off;
-                if (lane >= off && lane < off + np) { jpA = p; jiA = lane - off; }
-                if (lane + 64 >= off && lane + 64 < off + np) { jpB = p; jiB = lane + 64 - off; }
+#pragma unroll
+                for (int k = 0; k < kJobSets; k++) {
+                    const int j = lane + 64 * k;
+                    if (j >= off && j < off + np) { jp[k] = p; ji[k] = j - off; }
+                }
                 off += np;
             }
         }
@@ -357,26 +373,52 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
             P.ok = (jp >= 0) ? P.ok : 0;
             return P;
         };
-        const bool two_sets = J > 64;
-        const Prep PA = prep_job(jpA, jiA);
-        const Prep PB = prep_job(jpB, jiB);  // (unconditionally: the two calls interleave; an empty set costs little)
-        const unsigned long long okA = __ballot(PA.ok != 0), okB = __ballot(PB.ok != 0);
-        const unsigned long long pixA = (unsigned long long)PA.pix, pixB = (unsigned long long)PB.pix;
-        const int pixA_lo = (int)(pixA & 0xffffffffull), pixA_hi = (int)(pixA >> 32);
-        const int pixB_lo = (int)(pixB & 0xffffffffull), pixB_hi = (int)(pixB >> 32);
+        // (a set without jobs is skipped; the calls of the sets in use interleave: prep_image is one basic block)
+        Prep PS[kJobSets];
+        unsigned long long okS[kJobSets];
+        int pix_lo[kJobSets], pix_hi[kJobSets];
+#pragma unroll
+        for (int k = 0; k < kJobSets; k++) {
+            PS[k].ok = 0; PS[k].tlx = PS[k].tly = PS[k].dxx = PS[k].dxy = PS[k].dyx = PS[k].dyy = 0.0f; PS[k].pix = nullptr; PS[k].W = 0;
+            if (J > 64 * k) PS[k] = prep_job(jp[k], ji[k]);
+            okS[k] = __ballot(PS[k].ok != 0);
+            const unsigned long long pb = (unsigned long long)PS[k].pix;
+            pix_lo[k] = (int)(pb & 0xffffffffull); pix_hi[k] = (int)(pb >> 32);
+        }
 
-        // ---- per request, on its requesting lane: which images are usable (bits myoff .. myoff+nimg-1 of okB:okA)
+        // ---- per request, on its requesting lane: which images are usable
         const bool inbatch = (batch >> lane) & 1ull;
         unsigned long long myok = 0ull;
         if (inbatch) {
-            unsigned long long lo;
-            if (myoff < 64) { lo = okA >> myoff; if (myoff > 0) lo |= okB << (64 - myoff); }
-            else lo = okB >> (myoff - 64);
+            // bits myoff .. myoff + nimg - 1 of the concatenated ok masks of the sets
+            unsigned long long lo = 0ull;
+            const int w = myoff >> 6, sh = myoff & 63;
+#pragma unroll
+            for (int k = 0; k < kJobSets; k++) {
+                if (k == w) lo |= okS[k] >> sh;
+                if (k == w + 1 && sh > 0) lo |= okS[k] << (64 - sh);
+            }
             myok = (q.nimg >= 64) ? lo : (lo & ((1ull << q.nimg) - 1ull));
         }
         const bool refok = inbatch && q.nimg > 0 && ((myok >> q_refsel) & 1ull);
         unsigned long long todo = __ballot(refok);
         const int mylen = __popcll(myok);  // grabs of my request
+        const unsigned long long len6 = __ballot(mylen >= 6), len4 = __ballot(mylen >= 4);
+#if defined(HPMVS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+        {   // pass-count statistics of this batch: longest request, ideal pass count, long non-OBJ requests
+            int mx = 0, tot = 0, longreq = 0;
+            for (unsigned long long t = todo; t; t &= t - 1ull) {
+                const int pp = __ffsll((long long)t) - 1;
+                const int l = bcast_i(mylen, pp);
+                mx = l > mx ? l : mx; tot += l;
+                longreq += (l > 8 && !bcast_i(q.obj_mode, pp)) ? 1 : 0;
+            }
+            if (lane == 0) {
+                atomicAdd(&s_prof[60], (unsigned long long)mx); atomicAdd(&s_prof[61], (unsigned long long)((tot + kGroups - 1) / kGroups));
+                atomicAdd(&s_prof[62], 1ull); atomicAdd(&s_prof[63], (unsigned long long)longreq);
+            }
+        }
+#endif
         if (inbatch && !refok) {  // sampleTexture false for the reference image: plateau value / all 2.0
             if (q.obj_mode) out.obj = 2.0;
             else {
@@ -409,13 +451,9 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
             {
                 unsigned long long idle = __ballot(glane && yy == 0 && g_req < 0);
                 while (todo && idle) {
-                    // longest request first (fewest idle group-passes at the end of the round); scalar loop
-                    int p = 0, pl = -1;
-                    for (unsigned long long t = todo; t; t &= t - 1ull) {
-                        const int pp = __ffsll((long long)t) - 1;
-                        const int l = bcast_i(mylen, pp);
-                        if (l > pl) { pl = l; p = pp; }
-                    }
+                    // long requests first (fewest idle group-passes at the end of the round): three length classes
+                    const unsigned long long c6 = todo & len6, c4 = todo & len4;
+                    const int p = __ffsll((long long)(c6 ? c6 : (c4 ? c4 : todo))) - 1;
                     todo &= ~(1ull << p);
                     const int gl = __ffsll((long long)idle) - 1;  // first lane of the group
                     idle &= idle - 1ull;
@@ -440,19 +478,22 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
             int W;
             {
                 const int j = g_off + g_cur;
-                const int src = j & 63;
-                tlx = shfl_f(PA.tlx, src); tly = shfl_f(PA.tly, src);
-                dxx = shfl_f(PA.dxx, src); dxy = shfl_f(PA.dxy, src);
-                dyx = shfl_f(PA.dyx, src); dyy = shfl_f(PA.dyy, src);
-                W = shfl_i(PA.W, src);
-                int plo = shfl_i(pixA_lo, src), phi = shfl_i(pixA_hi, src);
-                if (two_sets) {
-                    const bool sb = j >= 64;
-                    const float b0 = shfl_f(PB.tlx, src), b1 = shfl_f(PB.tly, src), b2 = shfl_f(PB.dxx, src),
-                                b3 = shfl_f(PB.dxy, src), b4 = shfl_f(PB.dyx, src), b5 = shfl_f(PB.dyy, src);
-                    const int b6 = shfl_i(PB.W, src), b7 = shfl_i(pixB_lo, src), b8 = shfl_i(pixB_hi, src);
-                    tlx = sb ? b0 : tlx; tly = sb ? b1 : tly; dxx = sb ? b2 : dxx; dxy = sb ? b3 : dxy;
-                    dyx = sb ? b4 : dyx; dyy = sb ? b5 : dyy; W = sb ? b6 : W; plo = sb ? b7 : plo; phi = sb ? b8 : phi;
+                const int src = j & 63, set = j >> 6;
+                tlx = shfl_f(PS[0].tlx, src); tly = shfl_f(PS[0].tly, src);
+                dxx = shfl_f(PS[0].dxx, src); dxy = shfl_f(PS[0].dxy, src);
+                dyx = shfl_f(PS[0].dyx, src); dyy = shfl_f(PS[0].dyy, src);
+                W = shfl_i(PS[0].W, src);
+                int plo = shfl_i(pix_lo[0], src), phi = shfl_i(pix_hi[0], src);
+#pragma unroll
+                for (int k = 1; k < kJobSets; k++) {
+                    if (J > 64 * k) {  // (wave-uniform)
+                        const bool sb = set == k;
+                        const float b0 = shfl_f(PS[k].tlx, src), b1 = shfl_f(PS[k].tly, src), b2 = shfl_f(PS[k].dxx, src),
+                                    b3 = shfl_f(PS[k].dxy, src), b4 = shfl_f(PS[k].dyx, src), b5 = shfl_f(PS[k].dyy, src);
+                        const int b6 = shfl_i(PS[k].W, src), b7 = shfl_i(pix_lo[k], src), b8 = shfl_i(pix_hi[k], src);
+                        tlx = sb ? b0 : tlx; tly = sb ? b1 : tly; dxx = sb ? b2 : dxx; dxy = sb ? b3 : dxy;
+                        dyx = sb ? b4 : dyx; dyy = sb ? b5 : dyy; W = sb ? b6 : W; plo = sb ? b7 : plo; phi = sb ? b8 : phi;
+                    }
                 }
                 pix = (const uint8_t*)(((unsigned long long)(unsigned int)phi << 32) | (unsigned long long)(unsigned int)plo);
             }
