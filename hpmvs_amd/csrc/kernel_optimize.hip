@@ -74,11 +74,22 @@ constexpr int kPark16 = HPMVS_REGION_16;  // 16-byte chunks of a wavefront's par
 // instruction straight into LDS at base + lane * 16, no staging registers, all ~39 pieces in flight at once).
 // Out: ds_read_b128 + 16-byte global stores (fire and forget).
 __device__ __forceinline__ void page_in(const uint4* __restrict__ park) {
-    const int lane = lane_id();
+    // One running per-lane pointer, four pieces per step through the instruction's immediate offset (which moves the
+    // global AND the LDS address).  (With one precomputed address per piece the compiler hoisted all 39 out of the
+    // kernel's main loop, spilled them, and reloaded each from scratch behind an s_waitcnt vmcnt(0) -- which also
+    // waits for the previous piece: 39 serialised memory latencies, 27 k cycles per page-in.)
+    const char* g = (const char*)(park + lane_id());
 #pragma unroll
-    for (int c = 0; c < HPMVS_REGION_KIB; c++)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(park + c * 64 + lane),
-                                         (__attribute__((address_space(3))) void*)(hpmvs_region + c * 64), 16, 0, HPMVS_PARK_AUX);
+    for (int c4 = 0; c4 < HPMVS_REGION_KIB; c4 += 4) {
+        asm volatile("" : "+v"(g));  // keep it a loop-carried value
+        auto lds = (__attribute__((address_space(3))) void*)(hpmvs_region + c4 * 64);
+        auto src = (const __attribute__((address_space(1))) void*)g;
+        __builtin_amdgcn_global_load_lds(src, lds, 16, 0, HPMVS_PARK_AUX);
+        if (c4 + 1 < HPMVS_REGION_KIB) __builtin_amdgcn_global_load_lds(src, lds, 16, 1024, HPMVS_PARK_AUX);
+        if (c4 + 2 < HPMVS_REGION_KIB) __builtin_amdgcn_global_load_lds(src, lds, 16, 2048, HPMVS_PARK_AUX);
+        if (c4 + 3 < HPMVS_REGION_KIB) __builtin_amdgcn_global_load_lds(src, lds, 16, 3072, HPMVS_PARK_AUX);
+        g += 4096;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 __device__ __forceinline__ void page_out(uint4* __restrict__ park) {
