@@ -14,7 +14,7 @@
 //
 // Reference functions restated here (file:line relative to the reference root):
 //   calc_patch_axes        <- PatchOptimizer::calculatePatchAxis   src/hpmvs/PatchOptimizer.cpp:532-548
-//   prep_image, issue_taps,
+//   load_view, prep_from_view,
 //   texel                  <- PatchOptimizer::sampleTexture        src/hpmvs/PatchOptimizer.cpp:476-529
 //                             Camera::project / getLeveli          include/hpmvs/Camera.h:45-62, src/hpmvs/Camera.cpp:92-99
 //                             Image::getColor                      include/hpmvs/Image.h:89-115
@@ -128,30 +128,38 @@ struct Prep {
     int W;                 // level-l width
 };
 
-// The per-image, patch-uniform part of sampleTexture (PatchOptimizer.cpp:476-508): angle gate,
-// pyramid level, projected window, bounding-box gate.
-__device__ __forceinline__ Prep prep_image(const DevView& V, const DevOptions& o, const float* c, float scale,
-                                           const float* pxa, const float* pya, const float* zax) {
-    // Branch-free on purpose: one basic block, so that the loads and the long-latency divisions of two calls (the
-    // two job sets of the evaluator) interleave; the gates only decide `ok` at the end, exactly as sampleTexture's
-    // early returns do.
+// The per-image, patch-uniform part of sampleTexture (PatchOptimizer.cpp:476-508): angle gate, pyramid level, projected
+// window, bounding-box gate -- in two steps, so that the evaluator can have the loads of ALL its job sets in flight
+// before it computes any of them: load_view issues the view's table loads, prep_from_view does the arithmetic
+// (branch-free: the gates only decide `ok` at the end, exactly as sampleTexture's early returns do;
+//  level sizes as w0 >> l: the pyramid halves with integer division, Image.cpp:55-63).  The pointer of the chosen
+// level is the one dependent load left.
+struct ViewRegs { float P[12]; float cx, cy, cz, fsum; int w0, h0; const DevView* vp; };
+__device__ __forceinline__ ViewRegs load_view(const DevView& V) {
+    ViewRegs r;
+#pragma unroll
+    for (int k = 0; k < 12; k++) r.P[k] = V.P0[k];
+    r.cx = V.center[0]; r.cy = V.center[1]; r.cz = V.center[2];
+    r.fsum = V.fsum; r.w0 = V.w[0]; r.h0 = V.h[0];
+    r.vp = &V;
+    return r;
+}
+__device__ __forceinline__ Prep prep_from_view(const ViewRegs& V, const DevOptions& o, const float* c, float scale,
+                                               const float* pxa, const float* pya, const float* zax) {
     Prep r;
-    const float d0 = V.center[0] - c[0], d1 = V.center[1] - c[1], d2 = V.center[2] - c[2];
+    const float d0 = V.cx - c[0], d1 = V.cy - c[1], d2 = V.cz - c[2];
     const float n2 = (d0 * d0 + d1 * d1) + d2 * d2;  // w components cancel (1 - 1)
     const float nn = sqrtf(n2);
     const float g_unit = ((d0 / nn) * zax[0] + (d1 / nn) * zax[1]) + (d2 / nn) * zax[2];
     const float g_raw = (d0 * zax[0] + d1 * zax[1]) + d2 * zax[2];
     const float g = (n2 > 0.0f) ? g_unit : g_raw;
     const bool angle_ok = !((double)g < o.cos_max_d);
-
     const int lvl = level_clamped(scale, V.fsum, nn, o.MAXLEVEL - 1);
-    float P[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) P[k] = V.P0[k];
+    r.pix = V.vp->pix[lvl];
     float cu, cv, xu, xv, yu, yv;
-    project0(P, c[0], c[1], c[2], cu, cv);
-    project0(P, c[0] + pxa[0], c[1] + pxa[1], c[2] + pxa[2], xu, xv);
-    project0(P, c[0] + pya[0], c[1] + pya[1], c[2] + pya[2], yu, yv);
+    project0(V.P, c[0], c[1], c[2], cu, cv);
+    project0(V.P, c[0] + pxa[0], c[1] + pxa[1], c[2] + pxa[2], xu, xv);
+    project0(V.P, c[0] + pya[0], c[1] + pya[1], c[2] + pya[2], yu, yv);
     const float s = __int_as_float((127 - lvl) << 23);  // 2^-lvl, exact
     cu *= s; cv *= s;
     const float dxx = xu * s - cu, dxy = xv * s - cv;
@@ -163,12 +171,11 @@ __device__ __forceinline__ Prep prep_image(const DevView& V, const DevOptions& o
     const float brx = (cu + hs * dxx) + hs * dyx, bry = (cv + hs * dxy) + hs * dyy;
     const float mnx = fminf(fminf(fminf(tlx, trx), blx), brx), mny = fminf(fminf(fminf(tly, try_), bly), bry);
     const float mxx = fmaxf(fmaxf(fmaxf(tlx, trx), blx), brx), mxy = fmaxf(fmaxf(fmaxf(tly, try_), bly), bry);
-    const int W = V.w[lvl], H = V.h[lvl];
+    const int W = V.w0 >> lvl, H = V.h0 >> lvl;
     const float m = 3.0f;
     const bool box_ok = !(mnx < m || mny < m || mxx >= (float)(W - 3) || mxy >= (float)(H - 3));
     r.ok = (angle_ok && box_ok) ? 1 : 0;
     r.tlx = tlx; r.tly = tly; r.dxx = dxx; r.dxy = dxy; r.dyx = dyx; r.dyy = dyy;
-    r.pix = V.pix[lvl];
     r.W = W;
     return r;
 }
@@ -220,7 +227,7 @@ __device__ __forceinline__ float robustincc(float rhs) { return rhs / (1 + 3 * r
 // Per grab ~120 issued instructions, no LDS, no barrier; the optimiser state gets the whole 160 KB.
 //
 // Before the passes every (request, image) pair is a "job" of its own lane (up to two sets of 64 jobs): the
-// job lane runs prep_image (gates, level, projected window) with the request's data fetched from the
+// job lane runs prep_from_view (gates, level, projected window) with the request's data fetched from the
 // requesting lane by ds_bpermute; the groups fetch the geometry of their current grab from the job lane.
 struct PackedReq {   // registers of the requesting lane (valid where its `pending` bit is set)
     int obj_mode;    // 1: objective_fn (reference image = list[0]); 0: setINCCs against list[ref]
@@ -356,34 +363,43 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
                 off += np;
             }
         }
-        auto prep_job = [&](int jp, int ji) {
-            const int src = jp >= 0 ? jp : 0;
-            float c[3], zax[3], pxa[3], pya[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                c[k] = shfl_f(q.c[k], src); zax[k] = shfl_f(q.zax[k], src);
-                pxa[k] = shfl_f(q.px[k], src); pya[k] = shfl_f(q.py[k], src);
-            }
-            const float scale = shfl_f(q.scale, src);
-            const unsigned long long lb = ((unsigned long long)(unsigned int)shfl_i(list_hi, src) << 32) |
-                                          (unsigned long long)(unsigned int)shfl_i(list_lo, src);
-            int id = 0;  // (a lane without a job prepares view 0 and drops the result: no branch around prep_image)
-            if (jp >= 0) id = (int)((const ListT*)lb)[ji];
-            Prep P = prep_image(sc.views[id], o, c, scale, pxa, pya, zax);
-            P.ok = (jp >= 0) ? P.ok : 0;
-            return P;
-        };
-        // (a set without jobs is skipped; the calls of the sets in use interleave: prep_image is one basic block)
+        // Staged over all job sets in use, so that the loads of one set hide behind those of the others: request data
+        // from the requesting lanes (ds_bpermute), image ids, the views' tables, then the arithmetic.
         Prep PS[kJobSets];
         unsigned long long okS[kJobSets];
         int pix_lo[kJobSets], pix_hi[kJobSets];
+        {
+            float jc[kJobSets][3], jz[kJobSets][3], jx[kJobSets][3], jy[kJobSets][3], jscale[kJobSets];
+            int jid[kJobSets];
 #pragma unroll
-        for (int k = 0; k < kJobSets; k++) {
-            PS[k].ok = 0; PS[k].tlx = PS[k].tly = PS[k].dxx = PS[k].dxy = PS[k].dyx = PS[k].dyy = 0.0f; PS[k].pix = nullptr; PS[k].W = 0;
-            if (J > 64 * k) PS[k] = prep_job(jp[k], ji[k]);
-            okS[k] = __ballot(PS[k].ok != 0);
-            const unsigned long long pb = (unsigned long long)PS[k].pix;
-            pix_lo[k] = (int)(pb & 0xffffffffull); pix_hi[k] = (int)(pb >> 32);
+            for (int k = 0; k < kJobSets; k++) {
+                jid[k] = 0; jscale[k] = 1.0f;
+                for (int a3 = 0; a3 < 3; a3++) { jc[k][a3] = 0.0f; jz[k][a3] = 0.0f; jx[k][a3] = 0.0f; jy[k][a3] = 0.0f; }
+                if (J > 64 * k) {  // (wave-uniform)
+                    const int src = jp[k] >= 0 ? jp[k] : 0;
+#pragma unroll
+                    for (int a3 = 0; a3 < 3; a3++) {
+                        jc[k][a3] = shfl_f(q.c[a3], src); jz[k][a3] = shfl_f(q.zax[a3], src);
+                        jx[k][a3] = shfl_f(q.px[a3], src); jy[k][a3] = shfl_f(q.py[a3], src);
+                    }
+                    jscale[k] = shfl_f(q.scale, src);
+                    const unsigned long long lb = ((unsigned long long)(unsigned int)shfl_i(list_hi, src) << 32) |
+                                                  (unsigned long long)(unsigned int)shfl_i(list_lo, src);
+                    // (a lane without a job prepares view 0 and drops the result: no branch around the arithmetic)
+                    if (jp[k] >= 0) jid[k] = (int)((const ListT*)lb)[ji[k]];
+                }
+            }
+            ViewRegs VR[kJobSets];
+#pragma unroll
+            for (int k = 0; k < kJobSets; k++) VR[k] = load_view(sc.views[jid[k]]);
+#pragma unroll
+            for (int k = 0; k < kJobSets; k++) {
+                PS[k] = prep_from_view(VR[k], o, jc[k], jscale[k], jx[k], jy[k], jz[k]);
+                PS[k].ok = (J > 64 * k && jp[k] >= 0) ? PS[k].ok : 0;
+                okS[k] = __ballot(PS[k].ok != 0);
+                const unsigned long long pb = (unsigned long long)PS[k].pix;
+                pix_lo[k] = (int)(pb & 0xffffffffull); pix_hi[k] = (int)(pb >> 32);
+            }
         }
 
         // ---- per request, on its requesting lane: which images are usable
