@@ -63,9 +63,14 @@
 // the big routines are real calls on the GPU: their register demand stays out of the caller's
 // wave-cooperative sampling loop (occupancy), and the code is shared by the call sites
 #define BQ_HD_NOINLINE static __host__ __device__ __attribute__((noinline))  // static: two kernels (TUs) include this header
+// the blocks of the main loop are all inlined into ONE real function (bq_step_): a block that needs more than the
+// 144 caller-saved VGPRs saves and restores callee-saved ones through scratch memory on every call (measured: ~27
+// cycles per saved register and call), one function pays that once per optimiser step instead of once per block
+#define BQ_HD_BLOCK static __host__ __device__ __attribute__((always_inline)) inline
 #else
 #define BQ_HD inline
 #define BQ_HD_NOINLINE inline
+#define BQ_HD_BLOCK inline
 #endif
 #include <math.h>
 
@@ -79,6 +84,15 @@
 #define BQ_PROF_COUNT(i, n) do { } while (0)
 #define BQ_PROF_BEGIN(v) do { } while (0)
 #define BQ_PROF_END(v, i) do { } while (0)
+#endif
+
+// Loads placed after BQ_STAGE() stay after it: the blocks below read their arrays in stages, and a stage's registers
+// are meant to be free again before the next stage's loads are issued (a block that needs more than the 144
+// caller-saved VGPRs has to save and restore callee-saved ones through scratch memory on every call).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BQ_STAGE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define BQ_STAGE() do { } while (0)
 #endif
 
 namespace hpmvs {
@@ -378,13 +392,16 @@ struct Vec3Regs {
     BQ_HD void set(int i, double x) { if (i == 0) v0 = x; else if (i == 1) v1 = x; else v2 = x; }
 };
 
-BQ_HD_NOINLINE void trsbox(BqRef B) {
+BQ_HD_BLOCK void trsbox(BqRef B) {
     Vec3Regs xbdi;  // +-1 for variables fixed at a bound, else 0
     double s[3] = {0, 0, 0}, hs[3], hred[3] = {0, 0, 0};
     // read-only model data and the working vectors are held in registers for the whole call
     // (one batch of LDS reads at entry, one write-back of d / gnew / xnew at exit)
-    double xopt_[3], sl_[3], su_[3], d_[3], gnew_[3];
+    double xopt_[3], sl_[3], su_[3], d_[3], gnew_[3], hq_[6], pq_[7], xpt_[21];
     for (int i = 0; i < 3; i++) { xopt_[i] = BQA(xopt, i); sl_[i] = BQA(sl, i); su_[i] = BQA(su, i); }
+    for (int i = 0; i < 6; i++) hq_[i] = BQA(hq, i);
+    for (int i = 0; i < 7; i++) pq_[i] = BQA(pq, i);
+    for (int i = 0; i < 21; i++) xpt_[i] = BQA(xpt, i);
     int iterc = 0, nact = 0, itermax = 0, iact = 0, itcsav = 0, isav, iu;
     double delsq, qred = 0.0, crvmin = -1.0, beta = 0.0, stepsq, gredsq = 0.0, resid, ds, shs, temp, blen, stplen,
                   sdec, ggsav = 0.0, dredsq = 0.0, dredg = 0.0, sredg = 0.0, angbd = 0.0, xsav = 0.0, ssq, tempa,
@@ -428,7 +445,7 @@ BQ_HD_NOINLINE void trsbox(BqRef B) {
             if (stepsq == 0.0) { st = FINISH; continue; }
             if (beta == 0.0) { gredsq = stepsq; itermax = iterc + 3 - nact; }
             if (gredsq * delsq <= qred * 1e-4 * qred) { st = FINISH; continue; }
-            hess_mul(B, s, hs);
+            hess_mul_local(hq_, pq_, xpt_, s, hs);
             BQ_PROF_COUNT(56, 1);
             resid = delsq; ds = 0.0; shs = 0.0;
             for (int i = 0; i < 3; i++)
@@ -500,7 +517,7 @@ BQ_HD_NOINLINE void trsbox(BqRef B) {
                 } else s[i] = 0.0;
             }
             itcsav = iterc;
-            hess_mul(B, s, hs);
+            hess_mul_local(hq_, pq_, xpt_, s, hs);
             for (int i = 0; i < 3; i++) hred[i] = hs[i];
             st = ALT_ITER;
         }
@@ -537,7 +554,7 @@ BQ_HD_NOINLINE void trsbox(BqRef B) {
                 }
             }
             if (refix) { st = ALT_SETUP; continue; }
-            hess_mul(B, s, hs);
+            hess_mul_local(hq_, pq_, xpt_, s, hs);
             shs = 0.0; dhs = 0.0; dhd = 0.0;
             for (int i = 0; i < 3; i++)
                 if (xbdi.get(i) == 0.0) { shs += s[i] * hs[i]; dhs += d_[i] * hs[i]; dhd += d_[i] * hred[i]; }
@@ -614,28 +631,36 @@ BQ_HD_NOINLINE void trsbox(BqRef B) {
 // ---------------------------------------------------------------- altmov_ (bobyqa.c:744-1160)
 // Geometry-improving step for interpolation point knew: B.xnew (line through xopt and another
 // point), B.xalt (constrained Cauchy step), BQS(alpha), BQS(cauchy).
-BQ_HD_NOINLINE void altmov(BqRef B) {
+BQ_HD_BLOCK void altmov(BqRef B) {
     const double cst = 1.0 + sqrt(2.);
     double glag[3], hcol[7], w[3], wsave[3] = {0, 0, 0};
     const int knew = BQN(knew), kopt = BQN(kopt);
     const double adelt = BQS(adelt);
-    for (int k = 1; k <= 7; k++) hcol[k - 1] = 0.0;
-    for (int j = 1; j <= 3; j++) {
-        const double temp = BQ_ZMAT(knew, j);
-        for (int k = 1; k <= 7; k++) hcol[k - 1] += temp * BQ_ZMAT(k, j);
-    }
-    {   // = hcol[knew-1] (same operations in the same order), without a per-lane index into a local array
+    // the model data this block reads, in registers for the whole call (nothing of it is written here)
+    double xp_[7][3], xo_[3], sl_[3], su_[3];
+    double ha;
+    {
+        double z[7][3], zk[3];
+        for (int k = 0; k < 7; k++)
+            for (int j = 0; j < 3; j++) { z[k][j] = BQ_ZMAT(k + 1, j + 1); xp_[k][j] = BQ_XPT(k + 1, j + 1); }
+        for (int j = 0; j < 3; j++) { zk[j] = BQ_ZMAT(knew, j + 1); glag[j] = BQ_BMAT(knew, j + 1); }
+        for (int j = 0; j < 3; j++) { xo_[j] = BQ_V(xopt, j + 1); sl_[j] = BQ_V(sl, j + 1); su_[j] = BQ_V(su, j + 1); }
+        for (int k = 1; k <= 7; k++) hcol[k - 1] = 0.0;
+        for (int j = 1; j <= 3; j++) {
+            const double temp = zk[j - 1];
+            for (int k = 1; k <= 7; k++) hcol[k - 1] += temp * z[k - 1][j - 1];
+        }
+        // = hcol[knew-1] (same operations in the same order), without a per-lane index into a local array
         double al = 0.0;
-        for (int j = 1; j <= 3; j++) al += BQ_ZMAT(knew, j) * BQ_ZMAT(knew, j);
+        for (int j = 1; j <= 3; j++) al += zk[j - 1] * zk[j - 1];
         BQS(alpha) = al;
+        ha = 0.5 * al;
     }
-    const double ha = 0.5 * BQS(alpha);
-    for (int i = 1; i <= 3; i++) glag[i - 1] = BQ_BMAT(knew, i);
     for (int k = 1; k <= 7; k++) {
         double temp = 0.0;
-        for (int j = 1; j <= 3; j++) temp += BQ_XPT(k, j) * BQ_V(xopt, j);
+        for (int j = 1; j <= 3; j++) temp += xp_[k - 1][j - 1] * xo_[j - 1];
         temp = hcol[k - 1] * temp;
-        for (int i = 1; i <= 3; i++) glag[i - 1] += temp * BQ_XPT(k, i);
+        for (int i = 1; i <= 3; i++) glag[i - 1] += temp * xp_[k - 1][i - 1];
     }
     double presav = 0.0, step = 0.0, stpsav = 0.0, vlag, temp, tempa, tempb, tempd, diff;
     int ksav = kopt, ibdsav = 0, isbd;
@@ -643,7 +668,7 @@ BQ_HD_NOINLINE void altmov(BqRef B) {
         if (k == kopt) continue;
         double dderiv = 0.0, distsq = 0.0;
         for (int i = 1; i <= 3; i++) {
-            temp = BQ_XPT(k, i) - BQ_V(xopt, i);
+            temp = xp_[k - 1][i - 1] - xo_[i - 1];
             dderiv += glag[i - 1] * temp;
             distsq += temp * temp;
         }
@@ -652,13 +677,13 @@ BQ_HD_NOINLINE void altmov(BqRef B) {
         int ilbd = 0, iubd = 0;
         const double sumin = mn(1.0, subd);
         for (int i = 1; i <= 3; i++) {
-            temp = BQ_XPT(k, i) - BQ_V(xopt, i);
+            temp = xp_[k - 1][i - 1] - xo_[i - 1];
             if (temp > 0.0) {
-                if (slbd * temp < BQ_V(sl, i) - BQ_V(xopt, i)) { slbd = (BQ_V(sl, i) - BQ_V(xopt, i)) / temp; ilbd = -i; }
-                if (subd * temp > BQ_V(su, i) - BQ_V(xopt, i)) { subd = mx(sumin, (BQ_V(su, i) - BQ_V(xopt, i)) / temp); iubd = i; }
+                if (slbd * temp < sl_[i - 1] - xo_[i - 1]) { slbd = (sl_[i - 1] - xo_[i - 1]) / temp; ilbd = -i; }
+                if (subd * temp > su_[i - 1] - xo_[i - 1]) { subd = mx(sumin, (su_[i - 1] - xo_[i - 1]) / temp); iubd = i; }
             } else if (temp < 0.0) {
-                if (slbd * temp > BQ_V(su, i) - BQ_V(xopt, i)) { slbd = (BQ_V(su, i) - BQ_V(xopt, i)) / temp; ilbd = i; }
-                if (subd * temp < BQ_V(sl, i) - BQ_V(xopt, i)) { subd = mx(sumin, (BQ_V(sl, i) - BQ_V(xopt, i)) / temp); iubd = -i; }
+                if (slbd * temp > su_[i - 1] - xo_[i - 1]) { slbd = (su_[i - 1] - xo_[i - 1]) / temp; ilbd = i; }
+                if (subd * temp < sl_[i - 1] - xo_[i - 1]) { subd = mx(sumin, (sl_[i - 1] - xo_[i - 1]) / temp); iubd = -i; }
             }
         }
         if (k == knew) {
@@ -691,23 +716,29 @@ BQ_HD_NOINLINE void altmov(BqRef B) {
         if (predsq > presav) { presav = predsq; ksav = k; stpsav = step; ibdsav = isbd; }
     }
     for (int i = 1; i <= 3; i++) {
-        temp = BQ_V(xopt, i) + stpsav * (BQ_XPT(ksav, i) - BQ_V(xopt, i));
-        BQ_V(xnew, i) = mx(BQ_V(sl, i), mn(BQ_V(su, i), temp));
+        temp = xo_[i - 1] + stpsav * (BQ_XPT(ksav, i) - xo_[i - 1]);
+        BQ_V(xnew, i) = mx(sl_[i - 1], mn(su_[i - 1], temp));
     }
     if (ibdsav < 0) BQ_V(xnew, -ibdsav) = BQ_V(sl, -ibdsav);
     if (ibdsav > 0) BQ_V(xnew, ibdsav) = BQ_V(su, ibdsav);
 
     const double bigstp = adelt + adelt;
     double csave = 0.0, wfixsq, ggfree, wsqsav, gw, curv, scale;
+    double xalt_[3] = {0, 0, 0}, cauchy = 0.0;  // written to the state once, at the end
     for (int iflag = 0; iflag <= 1; iflag++) {
         wfixsq = 0.0; ggfree = 0.0;
         for (int i = 1; i <= 3; i++) {
             w[i - 1] = 0.0;
-            tempa = mn(BQ_V(xopt, i) - BQ_V(sl, i), glag[i - 1]);
-            tempb = mx(BQ_V(xopt, i) - BQ_V(su, i), glag[i - 1]);
+            tempa = mn(xo_[i - 1] - sl_[i - 1], glag[i - 1]);
+            tempb = mx(xo_[i - 1] - su_[i - 1], glag[i - 1]);
             if (tempa > 0.0 || tempb < 0.0) { w[i - 1] = bigstp; ggfree += glag[i - 1] * glag[i - 1]; }
         }
-        if (ggfree == 0.0) { BQS(cauchy) = 0.0; return; }
+        if (ggfree == 0.0) {
+            // (bobyqa.c returns here with xalt as the first pass left it, or untouched)
+            if (iflag == 1) for (int i = 0; i < 3; i++) BQA(xalt, i) = xalt_[i];
+            BQS(cauchy) = 0.0;
+            return;
+        }
         for (;;) {
             temp = adelt * adelt - wfixsq;
             if (!(temp > 0.0)) break;
@@ -716,9 +747,9 @@ BQ_HD_NOINLINE void altmov(BqRef B) {
             ggfree = 0.0;
             for (int i = 1; i <= 3; i++) {
                 if (w[i - 1] == bigstp) {
-                    temp = BQ_V(xopt, i) - step * glag[i - 1];
-                    if (temp <= BQ_V(sl, i)) { w[i - 1] = BQ_V(sl, i) - BQ_V(xopt, i); wfixsq += w[i - 1] * w[i - 1]; }
-                    else if (temp >= BQ_V(su, i)) { w[i - 1] = BQ_V(su, i) - BQ_V(xopt, i); wfixsq += w[i - 1] * w[i - 1]; }
+                    temp = xo_[i - 1] - step * glag[i - 1];
+                    if (temp <= sl_[i - 1]) { w[i - 1] = sl_[i - 1] - xo_[i - 1]; wfixsq += w[i - 1] * w[i - 1]; }
+                    else if (temp >= su_[i - 1]) { w[i - 1] = su_[i - 1] - xo_[i - 1]; wfixsq += w[i - 1] * w[i - 1]; }
                     else ggfree += glag[i - 1] * glag[i - 1];
                 }
             }
@@ -728,104 +759,148 @@ BQ_HD_NOINLINE void altmov(BqRef B) {
         for (int i = 1; i <= 3; i++) {
             if (w[i - 1] == bigstp) {
                 w[i - 1] = -step * glag[i - 1];
-                BQ_V(xalt, i) = mx(BQ_V(sl, i), mn(BQ_V(su, i), BQ_V(xopt, i) + w[i - 1]));
-            } else if (w[i - 1] == 0.0) BQ_V(xalt, i) = BQ_V(xopt, i);
-            else if (glag[i - 1] > 0.0) BQ_V(xalt, i) = BQ_V(sl, i);
-            else BQ_V(xalt, i) = BQ_V(su, i);
+                xalt_[i - 1] = mx(sl_[i - 1], mn(su_[i - 1], xo_[i - 1] + w[i - 1]));
+            } else if (w[i - 1] == 0.0) xalt_[i - 1] = xo_[i - 1];
+            else if (glag[i - 1] > 0.0) xalt_[i - 1] = sl_[i - 1];
+            else xalt_[i - 1] = su_[i - 1];
             gw += glag[i - 1] * w[i - 1];
         }
         curv = 0.0;
         for (int k = 1; k <= 7; k++) {
             temp = 0.0;
-            for (int j = 1; j <= 3; j++) temp += BQ_XPT(k, j) * w[j - 1];
+            for (int j = 1; j <= 3; j++) temp += xp_[k - 1][j - 1] * w[j - 1];
             curv += hcol[k - 1] * temp * temp;
         }
         if (iflag == 1) curv = -curv;
         if (curv > -gw && curv < -cst * gw) {
             scale = -gw / curv;
             for (int i = 1; i <= 3; i++) {
-                temp = BQ_V(xopt, i) + scale * w[i - 1];
-                BQ_V(xalt, i) = mx(BQ_V(sl, i), mn(BQ_V(su, i), temp));
+                temp = xo_[i - 1] + scale * w[i - 1];
+                xalt_[i - 1] = mx(sl_[i - 1], mn(su_[i - 1], temp));
             }
-            BQS(cauchy) = (0.5 * gw * scale) * (0.5 * gw * scale);
+            cauchy = (0.5 * gw * scale) * (0.5 * gw * scale);
         } else {
-            BQS(cauchy) = (gw + 0.5 * curv) * (gw + 0.5 * curv);
+            cauchy = (gw + 0.5 * curv) * (gw + 0.5 * curv);
         }
         if (iflag == 0) {
-            for (int i = 0; i < 3; i++) { glag[i] = -glag[i]; wsave[i] = BQA(xalt, i); }
-            csave = BQS(cauchy);
+            for (int i = 0; i < 3; i++) { glag[i] = -glag[i]; wsave[i] = xalt_[i]; }
+            csave = cauchy;
         }
     }
-    if (csave > BQS(cauchy)) {
-        for (int i = 0; i < 3; i++) BQA(xalt, i) = wsave[i];
-        BQS(cauchy) = csave;
+    if (csave > cauchy) {
+        for (int i = 0; i < 3; i++) xalt_[i] = wsave[i];
+        cauchy = csave;
     }
+    for (int i = 0; i < 3; i++) BQA(xalt, i) = xalt_[i];
+    BQS(cauchy) = cauchy;
 }
 
 // ---------------------------------------------------------------- update_ (bobyqa.c:18-141)
 // Update BMAT and ZMAT for the move of interpolation point knew (uses vlag, beta, denom).
-BQ_HD_NOINLINE void update(BqRef B) {
+BQ_HD_BLOCK void update(BqRef B) {
+    // Memory traffic (here and in the other blocks of the main loop): every array the block needs is read from the
+    // state ONCE, in one batch at the top, worked on in registers and written back once at the end.  The state lives
+    // in LDS; read-modify-write through it costs a ~100-cycle round trip per dependent access and a wavefront in
+    // here has nothing else to issue.  Rows selected by a per-lane index (knew) are read separately and carried
+    // along: the operations applied to the copy are the ones the loop applies to that row.  The arithmetic and its
+    // order are bobyqa.c's.
     const int knew = BQN(knew);
+    double z[7][3], vl[10], bm[10][3], zk[3], bk[3];
+    for (int k = 0; k < 7; k++)
+        for (int j = 0; j < 3; j++) z[k][j] = BQ_ZMAT(k + 1, j + 1);
+    for (int j = 0; j < 3; j++) { zk[j] = BQ_ZMAT(knew, j + 1); bk[j] = BQ_BMAT(knew, j + 1); }
+    for (int i = 0; i < 10; i++) vl[i] = BQ_V(vlag, i + 1);
+    for (int i = 0; i < 10; i++)
+        for (int j = 0; j < 3; j++) bm[i][j] = BQ_BMAT(i + 1, j + 1);
+    const double tau = BQ_V(vlag, knew);
+    const double denom = BQS(denom), beta = BQS(beta);
     double w[10];
     double ztest = 0.0;
     for (int k = 1; k <= 7; k++)
-        for (int j = 1; j <= 3; j++) ztest = mx(ztest, fabs(BQ_ZMAT(k, j)));
+        for (int j = 1; j <= 3; j++) ztest = mx(ztest, fabs(z[k - 1][j - 1]));
     ztest *= 1e-20;
     for (int j = 2; j <= 3; j++) {
-        if (fabs(BQ_ZMAT(knew, j)) > ztest) {
-            double temp = sqrt(BQ_ZMAT(knew, 1) * BQ_ZMAT(knew, 1) + BQ_ZMAT(knew, j) * BQ_ZMAT(knew, j));
-            const double tempa = BQ_ZMAT(knew, 1) / temp;
-            const double tempb = BQ_ZMAT(knew, j) / temp;
+        if (fabs(zk[j - 1]) > ztest) {
+            double temp = sqrt(zk[0] * zk[0] + zk[j - 1] * zk[j - 1]);
+            const double tempa = zk[0] / temp;
+            const double tempb = zk[j - 1] / temp;
             for (int i = 1; i <= 7; i++) {
-                temp = tempa * BQ_ZMAT(i, 1) + tempb * BQ_ZMAT(i, j);
-                BQ_ZMAT(i, j) = tempa * BQ_ZMAT(i, j) - tempb * BQ_ZMAT(i, 1);
-                BQ_ZMAT(i, 1) = temp;
+                temp = tempa * z[i - 1][0] + tempb * z[i - 1][j - 1];
+                z[i - 1][j - 1] = tempa * z[i - 1][j - 1] - tempb * z[i - 1][0];
+                z[i - 1][0] = temp;
             }
+            temp = tempa * zk[0] + tempb * zk[j - 1];  // row knew of the loop above
+            zk[0] = temp;
         }
-        BQ_ZMAT(knew, j) = 0.0;
+        zk[j - 1] = 0.0;
+        for (int i = 1; i <= 7; i++) if (i == knew) z[i - 1][j - 1] = 0.0;
     }
-    for (int i = 1; i <= 7; i++) w[i - 1] = BQ_ZMAT(knew, 1) * BQ_ZMAT(i, 1);
-    const double alpha = BQ_ZMAT(knew, 1) * BQ_ZMAT(knew, 1);  // = w[knew-1], without a per-lane index into a local array
-    const double tau = BQ_V(vlag, knew);
-    BQ_V(vlag, knew) -= 1.0;
-    double temp = sqrt(BQS(denom));
-    double tempb = BQ_ZMAT(knew, 1) / temp;
+    for (int i = 1; i <= 7; i++) w[i - 1] = zk[0] * z[i - 1][0];
+    const double alpha = zk[0] * zk[0];  // = w[knew-1], without a per-lane index into a local array
+    for (int i = 1; i <= 7; i++) if (i == knew) vl[i - 1] = tau - 1.0;
+    double temp = sqrt(denom);
+    double tempb = zk[0] / temp;
     double tempa = tau / temp;
-    for (int i = 1; i <= 7; i++) BQ_ZMAT(i, 1) = tempa * BQ_ZMAT(i, 1) - tempb * BQ_V(vlag, i);
+    for (int i = 1; i <= 7; i++) z[i - 1][0] = tempa * z[i - 1][0] - tempb * vl[i - 1];
     for (int j = 1; j <= 3; j++) {
         const int jp = 7 + j;
-        w[jp - 1] = BQ_BMAT(knew, j);
-        tempa = (alpha * BQ_V(vlag, jp) - tau * w[jp - 1]) / BQS(denom);
-        tempb = (-BQS(beta) * w[jp - 1] - tau * BQ_V(vlag, jp)) / BQS(denom);
+        w[jp - 1] = bk[j - 1];
+        tempa = (alpha * vl[jp - 1] - tau * w[jp - 1]) / denom;
+        tempb = (-beta * w[jp - 1] - tau * vl[jp - 1]) / denom;
         for (int i = 1; i <= jp; i++) {
-            BQ_BMAT(i, j) = BQ_BMAT(i, j) + tempa * BQ_V(vlag, i) + tempb * w[i - 1];
-            if (i > 7) BQ_BMAT(jp, i - 7) = BQ_BMAT(i, j);
+            bm[i - 1][j - 1] = bm[i - 1][j - 1] + tempa * vl[i - 1] + tempb * w[i - 1];
+            if (i > 7) bm[jp - 1][i - 7 - 1] = bm[i - 1][j - 1];
         }
     }
+    for (int k = 0; k < 7; k++)
+        for (int j = 0; j < 3; j++) BQ_ZMAT(k + 1, j + 1) = z[k][j];
+    for (int i = 0; i < 10; i++)
+        for (int j = 0; j < 3; j++) BQ_BMAT(i + 1, j + 1) = bm[i][j];
+    BQ_V(vlag, knew) = tau - 1.0;
+}
+
+// pick_knew on per-point quantities the caller formed from its register copies: hdiag[k] = sum_j zmat(k,j)^2 and
+// distsq[k] = |xpt(k) - from|^2 (each accumulated in j order, as the loop of bobyqa.c does); knew and denom are
+// written to the state once, at the end
+BQ_HD void pick_knew_core(BqRef B, const double* hdiag, const double* distsq, const double* vl, double beta,
+                          bool skip_kopt, double& scaden, double& biglsq) {
+    const double delta = BQS(delta);
+    const double delsq = delta * delta;
+    const int kopt = BQN(kopt);
+    scaden = 0.0; biglsq = 0.0;
+    int knew = 0;
+    double denom = 0.0;
+    for (int k = 1; k <= 7; k++) {
+        if (skip_kopt && k == kopt) continue;
+        const double den = beta * hdiag[k - 1] + vl[k - 1] * vl[k - 1];
+        const double q = distsq[k - 1] / delsq;
+        const double temp = mx(1.0, q * q);
+        if (temp * den > scaden) { scaden = temp * den; knew = k; denom = den; }
+        biglsq = mx(biglsq, temp * (vl[k - 1] * vl[k - 1]));
+    }
+    BQN(knew) = knew;
+    if (knew > 0) BQS(denom) = denom;
 }
 
 // Select the interpolation point to drop for a trust-region step (bobyqa.c:2497-2545, 2648-2690):
 // maximise max(1, (dist/delta)^4) * |denominator|.  `from` is xopt before the evaluation and
 // xnew after an improving one.
 BQ_HD void pick_knew(BqRef B, int from_off, bool skip_kopt, double& scaden, double& biglsq) {
-    const double delsq = BQS(delta) * BQS(delta);
-    scaden = 0.0; biglsq = 0.0;
-    BQN(knew) = 0;
-    for (int k = 1; k <= 7; k++) {
-        if (skip_kopt && k == BQN(kopt)) continue;
-        double hdiag = 0.0;
-        for (int jj = 1; jj <= 3; jj++) hdiag += BQ_ZMAT(k, jj) * BQ_ZMAT(k, jj);
-        const double den = BQS(beta) * hdiag + BQ_V(vlag, k) * BQ_V(vlag, k);
-        double distsq = 0.0;
-        for (int j = 1; j <= 3; j++) {
-            const double t = BQ_XPT(k, j) - BQ_D(from_off + j - 1);
-            distsq += t * t;
+    double hdiag[7], distsq[7], vl[7];
+    {
+        double z[7][3], xp[7][3], from[3];
+        for (int k = 0; k < 7; k++)
+            for (int j = 0; j < 3; j++) { z[k][j] = BQ_ZMAT(k + 1, j + 1); xp[k][j] = BQ_XPT(k + 1, j + 1); }
+        for (int k = 0; k < 7; k++) vl[k] = BQ_V(vlag, k + 1);
+        for (int j = 0; j < 3; j++) from[j] = BQ_D(from_off + j);
+        for (int k = 0; k < 7; k++) {
+            double h = 0.0, ds = 0.0;
+            for (int j = 0; j < 3; j++) h += z[k][j] * z[k][j];
+            for (int j = 0; j < 3; j++) { const double t = xp[k][j] - from[j]; ds += t * t; }
+            hdiag[k] = h; distsq[k] = ds;
         }
-        const double q = distsq / delsq;
-        const double temp = mx(1.0, q * q);
-        if (temp * den > scaden) { scaden = temp * den; BQN(knew) = k; BQS(denom) = den; }
-        biglsq = mx(biglsq, temp * (BQ_V(vlag, k) * BQ_V(vlag, k)));
     }
+    pick_knew_core(B, hdiag, distsq, vl, BQS(beta), skip_kopt, scaden, biglsq);
 }
 
 // ---------------------------------------------------------------- rescue_ (bobyqa.c:143-742)
@@ -1102,30 +1177,220 @@ BQ_HD_NOINLINE int rescue_begin(BqRef B) {
     return rescue_finish(B, BQ_SUCCESS);
 }
 
+// label 90: shift xbase to xopt when the step is small relative to |xopt| (bobyqa.c:2246-2322)
+BQ_HD_BLOCK int label90(BqRef B) {
+    const double xoptsq = BQS(xoptsq);
+    if (BQS(dsq) <= xoptsq * .001) {
+        const double fracsq = xoptsq * .25;
+        double sumpq = 0.0;
+        double w[3], wn[7], vl[7], xo[3], pq[7], xp[7][3], bm[10][3];
+        for (int j = 0; j < 3; j++) xo[j] = BQ_V(xopt, j + 1);
+        for (int k = 0; k < 7; k++) {
+            pq[k] = BQ_PQ(k + 1);
+            for (int j = 0; j < 3; j++) xp[k][j] = BQ_XPT(k + 1, j + 1);
+        }
+        for (int i = 0; i < 10; i++)
+            for (int j = 0; j < 3; j++) bm[i][j] = BQ_BMAT(i + 1, j + 1);
+        for (int k = 1; k <= 7; k++) {
+            sumpq += pq[k - 1];
+            double sum = -0.5 * xoptsq;
+            for (int i = 1; i <= 3; i++) sum += xp[k - 1][i - 1] * xo[i - 1];
+            wn[k - 1] = sum;
+            const double temp = fracsq - 0.5 * sum;
+            for (int i = 1; i <= 3; i++) {
+                w[i - 1] = bm[k - 1][i - 1];
+                vl[i - 1] = sum * xp[k - 1][i - 1] + temp * xo[i - 1];
+                const int ip = 7 + i;
+                for (int j = 1; j <= i; j++)
+                    bm[ip - 1][j - 1] = bm[ip - 1][j - 1] + w[i - 1] * vl[j - 1] + vl[i - 1] * w[j - 1];
+            }
+        }
+        BQ_STAGE();
+        {
+            double z[7][3];
+            for (int k = 0; k < 7; k++)
+                for (int j = 0; j < 3; j++) z[k][j] = BQ_ZMAT(k + 1, j + 1);
+            for (int jj = 1; jj <= 3; jj++) {
+                double sumz = 0.0, sumw = 0.0;
+                for (int k = 1; k <= 7; k++) {
+                    sumz += z[k - 1][jj - 1];
+                    vl[k - 1] = wn[k - 1] * z[k - 1][jj - 1];
+                    sumw += vl[k - 1];
+                }
+                for (int j = 1; j <= 3; j++) {
+                    double sum = (fracsq * sumz - 0.5 * sumw) * xo[j - 1];
+                    for (int k = 1; k <= 7; k++) sum += vl[k - 1] * xp[k - 1][j - 1];
+                    w[j - 1] = sum;
+                    for (int k = 1; k <= 7; k++) bm[k - 1][j - 1] += sum * z[k - 1][jj - 1];
+                }
+                for (int i = 1; i <= 3; i++) {
+                    const int ip = i + 7;
+                    const double temp = w[i - 1];
+                    for (int j = 1; j <= i; j++) bm[ip - 1][j - 1] += temp * w[j - 1];
+                }
+            }
+        }
+        BQ_STAGE();
+        {
+            double hq[6];
+            for (int i = 0; i < 6; i++) hq[i] = BQ_HQ(i + 1);
+            int ih = 0;
+            for (int j = 1; j <= 3; j++) {
+                w[j - 1] = -0.5 * sumpq * xo[j - 1];
+                for (int k = 1; k <= 7; k++) {
+                    w[j - 1] += pq[k - 1] * xp[k - 1][j - 1];
+                    xp[k - 1][j - 1] -= xo[j - 1];
+                }
+                for (int i = 1; i <= j; i++) {
+                    ++ih;
+                    hq[ih - 1] = hq[ih - 1] + w[i - 1] * xo[j - 1] + xo[i - 1] * w[j - 1];
+                    bm[7 + i - 1][j - 1] = bm[7 + j - 1][i - 1];
+                }
+            }
+            for (int i = 0; i < 6; i++) BQ_HQ(i + 1) = hq[i];
+        }
+        for (int k = 0; k < 7; k++)
+            for (int j = 0; j < 3; j++) BQ_XPT(k + 1, j + 1) = xp[k][j];
+        for (int i = 0; i < 10; i++)
+            for (int j = 0; j < 3; j++) BQ_BMAT(i + 1, j + 1) = bm[i][j];
+        for (int i = 1; i <= 3; i++) {
+            BQ_V(xbase, i) += xo[i - 1];
+            BQ_V(xnew, i) -= xo[i - 1];
+            BQ_V(sl, i) -= xo[i - 1];
+            BQ_V(su, i) -= xo[i - 1];
+            BQ_V(xopt, i) = 0.0;
+        }
+        BQS(xoptsq) = 0.0;
+    }
+    return (BQN(ntrits) == 0) ? L210 : L230;
+}
+
+// label 230: vlag, beta for the step d (bobyqa.c:2390-2440), then knew / denominators (bobyqa.c:2441-2556)
+BQ_HD_BLOCK int label230(BqRef B) {
+    double w[7], vl[10], dd[3], xo[3], hdiag[7], distsq[7];
+    for (int j = 0; j < 3; j++) { dd[j] = BQ_V(d, j + 1); xo[j] = BQ_V(xopt, j + 1); }
+    const double xoptsq = BQS(xoptsq);
+    const int ntrits = BQN(ntrits), kopt = BQN(kopt), knew0 = BQN(knew);
+    const double alpha = BQS(alpha), cauchy = BQS(cauchy);
+    double bm[10][3];
+    for (int i = 0; i < 10; i++)
+        for (int j = 0; j < 3; j++) bm[i][j] = BQ_BMAT(i + 1, j + 1);
+    {
+        double xp[7][3];
+        for (int k = 0; k < 7; k++)
+            for (int j = 0; j < 3; j++) xp[k][j] = BQ_XPT(k + 1, j + 1);
+        for (int k = 1; k <= 7; k++) {
+            double suma = 0.0, sumb = 0.0, sum = 0.0;
+            for (int j = 1; j <= 3; j++) {
+                suma += xp[k - 1][j - 1] * dd[j - 1];
+                sumb += xp[k - 1][j - 1] * xo[j - 1];
+                sum += bm[k - 1][j - 1] * dd[j - 1];
+            }
+            w[k - 1] = suma * (0.5 * suma + sumb);
+            vl[k - 1] = sum;
+            BQA(wsuma, k - 1) = suma;
+            double ds = 0.0;  // pick_knew's distance of point k from xopt
+            for (int j = 1; j <= 3; j++) { const double t = xp[k - 1][j - 1] - xo[j - 1]; ds += t * t; }
+            distsq[k - 1] = ds;
+        }
+    }
+    BQ_STAGE();
+    double beta = 0.0;
+    {
+        double z[7][3];
+        for (int k = 0; k < 7; k++)
+            for (int j = 0; j < 3; j++) z[k][j] = BQ_ZMAT(k + 1, j + 1);
+        for (int jj = 1; jj <= 3; jj++) {
+            double sum = 0.0;
+            for (int k = 1; k <= 7; k++) sum += z[k - 1][jj - 1] * w[k - 1];
+            beta -= sum * sum;
+            for (int k = 1; k <= 7; k++) vl[k - 1] += sum * z[k - 1][jj - 1];
+        }
+        for (int k = 0; k < 7; k++) {
+            double h = 0.0;
+            for (int j = 0; j < 3; j++) h += z[k][j] * z[k][j];
+            hdiag[k] = h;
+        }
+    }
+    double dsq = 0.0;
+    double bsum = 0.0, dx = 0.0;
+    for (int j = 1; j <= 3; j++) {
+        dsq += dd[j - 1] * dd[j - 1];
+        double sum = 0.0;
+        for (int k = 1; k <= 7; k++) sum += w[k - 1] * bm[k - 1][j - 1];
+        bsum += sum * dd[j - 1];
+        const int jp = 7 + j;
+        for (int i = 1; i <= 3; i++) sum += bm[jp - 1][i - 1] * dd[i - 1];
+        vl[jp - 1] = sum;
+        bsum += sum * dd[j - 1];
+        dx += dd[j - 1] * xo[j - 1];
+    }
+    beta = dx * dx + dsq * (xoptsq + dx + dx + 0.5 * dsq) + beta - bsum;
+    for (int k = 1; k <= 7; k++) if (k == kopt) vl[k - 1] += 1.0;
+    for (int i = 0; i < 10; i++) BQ_V(vlag, i + 1) = vl[i];
+    BQS(beta) = beta;
+    BQS(dsq) = dsq;
+    if (ntrits == 0) {
+        double vk = 0.0;
+        for (int k = 1; k <= 7; k++) if (k == knew0) vk = vl[k - 1];
+        const double denom = vk * vk + alpha * beta;
+        BQS(denom) = denom;
+        if (denom < cauchy && cauchy > 0.0) {
+            for (int i = 0; i < 3; i++) { const double xa = BQA(xalt, i); BQA(xnew, i) = xa; BQA(d, i) = xa - xo[i]; }
+            BQS(cauchy) = 0.0;
+            return L230;
+        }
+        if (denom <= 0.5 * (vk * vk)) {
+            if (BQN(nevals) > BQN(nresc)) return L190;
+            BQN(rc) = BQ_ROUNDOFF_LIMITED;
+            return L720;
+        }
+    } else {
+        double scaden, biglsq;
+        pick_knew_core(B, hdiag, distsq, vl, beta, true, scaden, biglsq);
+        if (scaden <= 0.5 * biglsq) {
+            if (BQN(nevals) > BQN(nresc)) return L190;
+            BQN(rc) = BQ_ROUNDOFF_LIMITED;
+            return L720;
+        }
+    }
+    return L360;
+}
+
 // ---------------------------------------------------------------- bobyqb_ main loop (bobyqa.c:2143-3055)
 // Runs from `label` until the next objective evaluation is needed (returns BQ_CONTINUE with
 // B.xeval set) or the run ends (BQ_DONE).
-BQ_HD_NOINLINE int step_label(BqRef B, int label) {
+BQ_HD_BLOCK int step_label(BqRef B, int label) {
     double w[14];
     {
         switch (label) {
         case L20: {  // model gradient at xopt when kopt moved away from kbase (bobyqa.c:2149-2182)
             if (BQN(kopt) != BQN(kbase)) {
+                double go[3], xo[3], hq[6];
+                const int nevals = BQN(nevals);
+                for (int j = 0; j < 3; j++) { go[j] = BQ_V(gopt, j + 1); xo[j] = BQ_V(xopt, j + 1); }
+                for (int i = 0; i < 6; i++) hq[i] = BQ_HQ(i + 1);
                 int ih = 0;
                 for (int j = 1; j <= 3; j++)
                     for (int i = 1; i <= j; i++) {
                         ++ih;
-                        if (i < j) BQ_V(gopt, j) += BQ_HQ(ih) * BQ_V(xopt, i);
-                        BQ_V(gopt, i) += BQ_HQ(ih) * BQ_V(xopt, j);
+                        if (i < j) go[j - 1] += hq[ih - 1] * xo[i - 1];
+                        go[i - 1] += hq[ih - 1] * xo[j - 1];
                     }
-                if (BQN(nevals) > 7) {
+                if (nevals > 7) {
+                    double pq[7], xp[7][3];
+                    for (int k = 0; k < 7; k++) {
+                        pq[k] = BQ_PQ(k + 1);
+                        for (int j = 0; j < 3; j++) xp[k][j] = BQ_XPT(k + 1, j + 1);
+                    }
                     for (int k = 1; k <= 7; k++) {
                         double temp = 0.0;
-                        for (int j = 1; j <= 3; j++) temp += BQ_XPT(k, j) * BQ_V(xopt, j);
-                        temp = BQ_PQ(k) * temp;
-                        for (int i = 1; i <= 3; i++) BQ_V(gopt, i) += temp * BQ_XPT(k, i);
+                        for (int j = 1; j <= 3; j++) temp += xp[k - 1][j - 1] * xo[j - 1];
+                        temp = pq[k - 1] * temp;
+                        for (int i = 1; i <= 3; i++) go[i - 1] += temp * xp[k - 1][i - 1];
                     }
                 }
+                for (int j = 0; j < 3; j++) BQ_V(gopt, j + 1) = go[j];
             }
             return L60;
         }
@@ -1133,15 +1398,19 @@ BQ_HD_NOINLINE int step_label(BqRef B, int label) {
             BQ_PROF_BEGIN(t_);
             trsbox(B);
             BQ_PROF_END(t_, 0);
-            BQS(dnorm) = mn(BQS(delta), sqrt(BQS(dsq)));
-            if (BQS(dnorm) < 0.5 * BQS(rho)) {
+            const double delta = BQS(delta), rho = BQS(rho);
+            const double dnorm = mn(delta, sqrt(BQS(dsq)));
+            BQS(dnorm) = dnorm;
+            if (dnorm < 0.5 * rho) {
+                const int nevals = BQN(nevals), nfsav = BQN(nfsav);
+                const double diffa = BQS(diffa), diffb = BQS(diffb), diffc = BQS(diffc), crvmin = BQS(crvmin);
                 BQN(ntrits) = -1;
-                BQS(distsq) = (10.0 * BQS(rho)) * (10.0 * BQS(rho));
-                if (BQN(nevals) <= BQN(nfsav) + 2) { return L650; }
-                const double errbig = mx(mx(BQS(diffa), BQS(diffb)), BQS(diffc));
-                const double frhosq = BQS(rho) * .125 * BQS(rho);
-                if (BQS(crvmin) > 0.0 && errbig > frhosq * BQS(crvmin)) { return L650; }
-                const double bdtol = errbig / BQS(rho);
+                BQS(distsq) = (10.0 * rho) * (10.0 * rho);
+                if (nevals <= nfsav + 2) { return L650; }
+                const double errbig = mx(mx(diffa, diffb), diffc);
+                const double frhosq = rho * .125 * rho;
+                if (crvmin > 0.0 && errbig > frhosq * crvmin) { return L650; }
+                const double bdtol = errbig / rho;
                 bool to650 = false;
                 for (int j = 1; j <= 3; j++) {
                     double bdtest = bdtol;
@@ -1150,7 +1419,7 @@ BQ_HD_NOINLINE int step_label(BqRef B, int label) {
                     if (bdtest < bdtol) {
                         double curv = BQ_HQ((j + j * j) / 2);
                         for (int k = 1; k <= 7; k++) curv += BQ_PQ(k) * (BQ_XPT(k, j) * BQ_XPT(k, j));
-                        bdtest += 0.5 * curv * BQS(rho);
+                        bdtest += 0.5 * curv * rho;
                         if (bdtest < bdtol) { to650 = true; break; }
                     }
                 }
@@ -1159,69 +1428,7 @@ BQ_HD_NOINLINE int step_label(BqRef B, int label) {
             ++BQN(ntrits);
             return L90;
         }
-        case L90: {  // shift xbase to xopt when the step is small relative to |xopt| (bobyqa.c:2246-2322)
-            if (BQS(dsq) <= BQS(xoptsq) * .001) {
-                const double fracsq = BQS(xoptsq) * .25;
-                double sumpq = 0.0;
-                double wn[7];  // w(npt+k)
-                double vl[7];
-                for (int k = 1; k <= 7; k++) {
-                    sumpq += BQ_PQ(k);
-                    double sum = -0.5 * BQS(xoptsq);
-                    for (int i = 1; i <= 3; i++) sum += BQ_XPT(k, i) * BQ_V(xopt, i);
-                    wn[k - 1] = sum;
-                    const double temp = fracsq - 0.5 * sum;
-                    for (int i = 1; i <= 3; i++) {
-                        w[i - 1] = BQ_BMAT(k, i);
-                        vl[i - 1] = sum * BQ_XPT(k, i) + temp * BQ_V(xopt, i);
-                        const int ip = 7 + i;
-                        for (int j = 1; j <= i; j++)
-                            BQ_BMAT(ip, j) = BQ_BMAT(ip, j) + w[i - 1] * vl[j - 1] + vl[i - 1] * w[j - 1];
-                    }
-                }
-                for (int jj = 1; jj <= 3; jj++) {
-                    double sumz = 0.0, sumw = 0.0;
-                    for (int k = 1; k <= 7; k++) {
-                        sumz += BQ_ZMAT(k, jj);
-                        vl[k - 1] = wn[k - 1] * BQ_ZMAT(k, jj);
-                        sumw += vl[k - 1];
-                    }
-                    for (int j = 1; j <= 3; j++) {
-                        double sum = (fracsq * sumz - 0.5 * sumw) * BQ_V(xopt, j);
-                        for (int k = 1; k <= 7; k++) sum += vl[k - 1] * BQ_XPT(k, j);
-                        w[j - 1] = sum;
-                        for (int k = 1; k <= 7; k++) BQ_BMAT(k, j) += sum * BQ_ZMAT(k, jj);
-                    }
-                    for (int i = 1; i <= 3; i++) {
-                        const int ip = i + 7;
-                        const double temp = w[i - 1];
-                        for (int j = 1; j <= i; j++) BQ_BMAT(ip, j) += temp * w[j - 1];
-                    }
-                }
-                int ih = 0;
-                for (int j = 1; j <= 3; j++) {
-                    w[j - 1] = -0.5 * sumpq * BQ_V(xopt, j);
-                    for (int k = 1; k <= 7; k++) {
-                        w[j - 1] += BQ_PQ(k) * BQ_XPT(k, j);
-                        BQ_XPT(k, j) -= BQ_V(xopt, j);
-                    }
-                    for (int i = 1; i <= j; i++) {
-                        ++ih;
-                        BQ_HQ(ih) = BQ_HQ(ih) + w[i - 1] * BQ_V(xopt, j) + BQ_V(xopt, i) * w[j - 1];
-                        BQ_BMAT(7 + i, j) = BQ_BMAT(7 + j, i);
-                    }
-                }
-                for (int i = 1; i <= 3; i++) {
-                    BQ_V(xbase, i) += BQ_V(xopt, i);
-                    BQ_V(xnew, i) -= BQ_V(xopt, i);
-                    BQ_V(sl, i) -= BQ_V(xopt, i);
-                    BQ_V(su, i) -= BQ_V(xopt, i);
-                    BQ_V(xopt, i) = 0.0;
-                }
-                BQS(xoptsq) = 0.0;
-            }
-            return (BQN(ntrits) == 0) ? L210 : L230;
-        }
+        case L90: return label90(B);
         case L210: {  // geometry step (bobyqa.c:2376-2384)
             BQ_PROF_BEGIN(t_);
             altmov(B);
@@ -1229,64 +1436,7 @@ BQ_HD_NOINLINE int step_label(BqRef B, int label) {
             for (int i = 0; i < 3; i++) BQA(d, i) = BQA(xnew, i) - BQA(xopt, i);
             return L230;
         }
-        case L230: {  // vlag, beta for the step d (bobyqa.c:2390-2440), then knew / denominators
-            for (int k = 1; k <= 7; k++) {
-                double suma = 0.0, sumb = 0.0, sum = 0.0;
-                for (int j = 1; j <= 3; j++) {
-                    suma += BQ_XPT(k, j) * BQ_V(d, j);
-                    sumb += BQ_XPT(k, j) * BQ_V(xopt, j);
-                    sum += BQ_BMAT(k, j) * BQ_V(d, j);
-                }
-                w[k - 1] = suma * (0.5 * suma + sumb);
-                BQ_V(vlag, k) = sum;
-                BQA(wsuma, k - 1) = suma;
-            }
-            BQS(beta) = 0.0;
-            for (int jj = 1; jj <= 3; jj++) {
-                double sum = 0.0;
-                for (int k = 1; k <= 7; k++) sum += BQ_ZMAT(k, jj) * w[k - 1];
-                BQS(beta) -= sum * sum;
-                for (int k = 1; k <= 7; k++) BQ_V(vlag, k) += sum * BQ_ZMAT(k, jj);
-            }
-            BQS(dsq) = 0.0;
-            double bsum = 0.0, dx = 0.0;
-            for (int j = 1; j <= 3; j++) {
-                BQS(dsq) += BQ_V(d, j) * BQ_V(d, j);
-                double sum = 0.0;
-                for (int k = 1; k <= 7; k++) sum += w[k - 1] * BQ_BMAT(k, j);
-                bsum += sum * BQ_V(d, j);
-                const int jp = 7 + j;
-                for (int i = 1; i <= 3; i++) sum += BQ_BMAT(jp, i) * BQ_V(d, i);
-                BQ_V(vlag, jp) = sum;
-                bsum += sum * BQ_V(d, j);
-                dx += BQ_V(d, j) * BQ_V(xopt, j);
-            }
-            BQS(beta) = dx * dx + BQS(dsq) * (BQS(xoptsq) + dx + dx + 0.5 * BQS(dsq)) + BQS(beta) - bsum;
-            BQ_V(vlag, BQN(kopt)) += 1.0;
-            if (BQN(ntrits) == 0) {
-                const double vk = BQ_V(vlag, BQN(knew));
-                BQS(denom) = vk * vk + BQS(alpha) * BQS(beta);
-                if (BQS(denom) < BQS(cauchy) && BQS(cauchy) > 0.0) {
-                    for (int i = 0; i < 3; i++) { BQA(xnew, i) = BQA(xalt, i); BQA(d, i) = BQA(xnew, i) - BQA(xopt, i); }
-                    BQS(cauchy) = 0.0;
-                    return L230;
-                }
-                if (BQS(denom) <= 0.5 * (vk * vk)) {
-                    if (BQN(nevals) > BQN(nresc)) return L190;
-                    BQN(rc) = BQ_ROUNDOFF_LIMITED;
-                    return L720;
-                }
-            } else {
-                double scaden, biglsq;
-                pick_knew(B, O_xopt, true, scaden, biglsq);
-                if (scaden <= 0.5 * biglsq) {
-                    if (BQN(nevals) > BQN(nresc)) return L190;
-                    BQN(rc) = BQ_ROUNDOFF_LIMITED;
-                    return L720;
-                }
-            }
-            return L360;
-        }
+        case L230: return label230(B);
         case L360: {  // next objective evaluation (bobyqa.c:2560-2583)
             if (BQN(maxeval) > 0 && BQN(nevals) >= BQN(maxeval)) { BQN(rc) = BQ_MAXEVAL_REACHED; return L720; }
             set_x_from(B, O_xnew);
@@ -1295,29 +1445,41 @@ BQ_HD_NOINLINE int step_label(BqRef B, int label) {
             return LRET_CONT;
         }
         case L650: {  // is some interpolation point too far from xopt? (bobyqa.c:2972-3013)
-            BQN(knew) = 0;
+            double xp[7][3], xo[3];
+            for (int k = 0; k < 7; k++)
+                for (int j = 0; j < 3; j++) xp[k][j] = BQ_XPT(k + 1, j + 1);
+            for (int j = 0; j < 3; j++) xo[j] = BQ_V(xopt, j + 1);
+            double distsq = BQS(distsq);
+            const int ntrits = BQN(ntrits);
+            const double delta0 = BQS(delta), rho = BQS(rho), ratio = BQS(ratio), dnorm = BQS(dnorm);
+            int knew = 0;
             for (int k = 1; k <= 7; k++) {
                 double sum = 0.0;
                 for (int j = 1; j <= 3; j++) {
-                    const double t = BQ_XPT(k, j) - BQ_V(xopt, j);
+                    const double t = xp[k - 1][j - 1] - xo[j - 1];
                     sum += t * t;
                 }
-                if (sum > BQS(distsq)) { BQN(knew) = k; BQS(distsq) = sum; }
+                if (sum > distsq) { knew = k; distsq = sum; }
             }
-            if (BQN(knew) > 0) {
-                const double dist = sqrt(BQS(distsq));
-                if (BQN(ntrits) == -1) {
-                    BQS(delta) = mn(0.1 * BQS(delta), 0.5 * dist);
-                    if (BQS(delta) <= BQS(rho) * 1.5) BQS(delta) = BQS(rho);
+            BQN(knew) = knew;
+            if (knew > 0) {
+                BQS(distsq) = distsq;
+                const double dist = sqrt(distsq);
+                double delta = delta0;
+                if (ntrits == -1) {
+                    delta = mn(0.1 * delta, 0.5 * dist);
+                    if (delta <= rho * 1.5) delta = rho;
+                    BQS(delta) = delta;
                 }
                 BQN(ntrits) = 0;
-                BQS(adelt) = mx(mn(0.1 * dist, BQS(delta)), BQS(rho));
-                BQS(dsq) = BQS(adelt) * BQS(adelt);
+                const double adelt = mx(mn(0.1 * dist, delta), rho);
+                BQS(adelt) = adelt;
+                BQS(dsq) = adelt * adelt;
                 return L90;
             }
-            if (BQN(ntrits) == -1) { return L680; }
-            if (BQS(ratio) > 0.0) { return L60; }
-            if (mx(BQS(delta), BQS(dnorm)) > BQS(rho)) { return L60; }
+            if (ntrits == -1) { return L680; }
+            if (ratio > 0.0) { return L60; }
+            if (mx(delta0, dnorm) > rho) { return L60; }
             return L680;
         }
         case L680: {  // reduce rho, or finish (bobyqa.c:3019-3041)
@@ -1426,7 +1588,7 @@ BQ_HD int l90_next(BqRef B) { return (BQN(ntrits) == 0) ? L210 : L230; }
 
 // Code after an evaluation at xbase + xnew in the main loop (bobyqa.c:2583-2970)
 // returns the label to continue at (or LRET_DONE)
-BQ_HD_NOINLINE int after_eval(BqRef B, double f) {
+BQ_HD_BLOCK int after_eval(BqRef B, double f) {
     double w[10];
     if (BQN(ntrits) == -1) {
         BQS(fsave) = f;
@@ -1439,32 +1601,46 @@ BQ_HD_NOINLINE int after_eval(BqRef B, double f) {
         }
         return L720;
     }
+    const int ntrits = BQN(ntrits);
     const double fopt = BQ_FVAL(BQN(kopt));
     double vquad = 0.0;
-    int ih = 0;
-    for (int j = 1; j <= 3; j++) {
-        vquad += BQ_V(d, j) * BQ_V(gopt, j);
-        for (int i = 1; i <= j; i++) {
-            ++ih;
-            double temp = BQ_V(d, i) * BQ_V(d, j);
-            if (i == j) temp = 0.5 * temp;
-            vquad += BQ_HQ(ih) * temp;
+    {
+        double dd[3], go[3], hq[6], pq[7], ws[7];
+        for (int j = 0; j < 3; j++) { dd[j] = BQ_V(d, j + 1); go[j] = BQ_V(gopt, j + 1); }
+        for (int i = 0; i < 6; i++) hq[i] = BQ_HQ(i + 1);
+        for (int k = 0; k < 7; k++) { pq[k] = BQ_PQ(k + 1); ws[k] = BQA(wsuma, k); }
+        int ih = 0;
+        for (int j = 1; j <= 3; j++) {
+            vquad += dd[j - 1] * go[j - 1];
+            for (int i = 1; i <= j; i++) {
+                ++ih;
+                double temp = dd[i - 1] * dd[j - 1];
+                if (i == j) temp = 0.5 * temp;
+                vquad += hq[ih - 1] * temp;
+            }
         }
+        for (int k = 1; k <= 7; k++) vquad += 0.5 * pq[k - 1] * (ws[k - 1] * ws[k - 1]);
     }
-    for (int k = 1; k <= 7; k++) vquad += 0.5 * BQ_PQ(k) * (BQA(wsuma, k - 1) * BQA(wsuma, k - 1));
     const double diff = f - fopt - vquad;
-    BQS(diffc) = BQS(diffb);
-    BQS(diffb) = BQS(diffa);
-    BQS(diffa) = fabs(diff);
-    if (BQS(dnorm) > BQS(rho)) BQN(nfsav) = BQN(nevals);
+    {
+        const double diffa = BQS(diffa), diffb = BQS(diffb);
+        BQS(diffc) = diffb;
+        BQS(diffb) = diffa;
+        BQS(diffa) = fabs(diff);
+    }
+    const double dnorm = BQS(dnorm), rho = BQS(rho);
+    if (dnorm > rho) BQN(nfsav) = BQN(nevals);
 
-    if (BQN(ntrits) > 0) {
+    if (ntrits > 0) {
         if (vquad >= 0.0) { BQN(rc) = BQ_ROUNDOFF_LIMITED; return L720; }
-        BQS(ratio) = (f - fopt) / vquad;
-        if (BQS(ratio) <= 0.1) BQS(delta) = mn(0.5 * BQS(delta), BQS(dnorm));
-        else if (BQS(ratio) <= .7) BQS(delta) = mx(0.5 * BQS(delta), BQS(dnorm));
-        else BQS(delta) = mx(0.5 * BQS(delta), BQS(dnorm) + BQS(dnorm));
-        if (BQS(delta) <= BQS(rho) * 1.5) BQS(delta) = BQS(rho);
+        const double ratio = (f - fopt) / vquad;
+        BQS(ratio) = ratio;
+        double delta = BQS(delta);
+        if (ratio <= 0.1) delta = mn(0.5 * delta, dnorm);
+        else if (ratio <= .7) delta = mx(0.5 * delta, dnorm);
+        else delta = mx(0.5 * delta, dnorm + dnorm);
+        if (delta <= rho * 1.5) delta = rho;
+        BQS(delta) = delta;
         if (f < fopt) {
             const int ksav = BQN(knew);
             const double densav = BQS(denom);
@@ -1475,100 +1651,128 @@ BQ_HD_NOINLINE int after_eval(BqRef B, double f) {
     }
     { BQ_PROF_BEGIN(t_); update(B); BQ_PROF_END(t_, 2); }
     const int knew = BQN(knew);
-    ih = 0;
-    const double pqold = BQ_PQ(knew);
-    BQ_PQ(knew) = 0.0;
-    for (int i = 1; i <= 3; i++) {
-        const double temp = pqold * BQ_XPT(knew, i);
-        for (int j = 1; j <= i; j++) { ++ih; BQ_HQ(ih) += temp * BQ_XPT(knew, j); }
-    }
-    for (int jj = 1; jj <= 3; jj++) {
-        const double temp = diff * BQ_ZMAT(knew, jj);
-        for (int k = 1; k <= 7; k++) BQ_PQ(k) += temp * BQ_ZMAT(k, jj);
-    }
-    BQ_FVAL(knew) = f;
-    for (int i = 1; i <= 3; i++) { BQ_XPT(knew, i) = BQ_V(xnew, i); w[i - 1] = BQ_BMAT(knew, i); }
-    for (int k = 1; k <= 7; k++) {
-        double suma = 0.0;
-        for (int jj = 1; jj <= 3; jj++) suma += BQ_ZMAT(knew, jj) * BQ_ZMAT(k, jj);
-        if (is_inf(suma)) { BQN(rc) = BQ_ROUNDOFF_LIMITED; return L720; }
-        double sumb = 0.0;
-        for (int j = 1; j <= 3; j++) sumb += BQ_XPT(k, j) * BQ_V(xopt, j);
-        const double temp = suma * sumb;
-        for (int i = 1; i <= 3; i++) w[i - 1] += temp * BQ_XPT(k, i);
-    }
-    for (int i = 1; i <= 3; i++) BQ_V(gopt, i) += diff * w[i - 1];
+    double z[7][3], xp[7][3], xn[3], xo[3], go[3];
+    {   // model update for the replaced point: hq with the OLD xpt(knew), pq through zmat (bobyqa.c:2720-2760)
+        double pq[7], hq[6], zk[3], xk[3];
+        for (int k = 0; k < 7; k++) {
+            pq[k] = BQ_PQ(k + 1);
+            for (int j = 0; j < 3; j++) { z[k][j] = BQ_ZMAT(k + 1, j + 1); xp[k][j] = BQ_XPT(k + 1, j + 1); }
+        }
+        for (int i = 0; i < 6; i++) hq[i] = BQ_HQ(i + 1);
+        for (int j = 0; j < 3; j++) { zk[j] = BQ_ZMAT(knew, j + 1); xk[j] = BQ_XPT(knew, j + 1); w[j] = BQ_BMAT(knew, j + 1); }
+        for (int j = 0; j < 3; j++) { xn[j] = BQ_V(xnew, j + 1); xo[j] = BQ_V(xopt, j + 1); go[j] = BQ_V(gopt, j + 1); }
+        const double pqold = BQ_PQ(knew);
+        for (int k = 1; k <= 7; k++) if (k == knew) pq[k - 1] = 0.0;
+        int ih = 0;
+        for (int i = 1; i <= 3; i++) {
+            const double temp = pqold * xk[i - 1];
+            for (int j = 1; j <= i; j++) { ++ih; hq[ih - 1] += temp * xk[j - 1]; }
+        }
+        for (int jj = 1; jj <= 3; jj++) {
+            const double temp = diff * zk[jj - 1];
+            for (int k = 1; k <= 7; k++) pq[k - 1] += temp * z[k - 1][jj - 1];
+        }
+        for (int k = 0; k < 7; k++) BQ_PQ(k + 1) = pq[k];
+        for (int i = 0; i < 6; i++) BQ_HQ(i + 1) = hq[i];
+        BQ_FVAL(knew) = f;
+        for (int i = 1; i <= 3; i++) {
+            BQ_XPT(knew, i) = xn[i - 1];
+            for (int k = 1; k <= 7; k++) if (k == knew) xp[k - 1][i - 1] = xn[i - 1];
+        }
+        for (int k = 1; k <= 7; k++) {
+            double suma = 0.0;
+            for (int jj = 1; jj <= 3; jj++) suma += zk[jj - 1] * z[k - 1][jj - 1];
+            if (is_inf(suma)) { BQN(rc) = BQ_ROUNDOFF_LIMITED; return L720; }
+            double sumb = 0.0;
+            for (int j = 1; j <= 3; j++) sumb += xp[k - 1][j - 1] * xo[j - 1];
+            const double temp = suma * sumb;
+            for (int i = 1; i <= 3; i++) w[i - 1] += temp * xp[k - 1][i - 1];
+        }
+        for (int i = 1; i <= 3; i++) go[i - 1] += diff * w[i - 1];
 
-    if (f < fopt) {
-        BQN(kopt) = knew;
-        BQS(xoptsq) = 0.0;
-        ih = 0;
-        for (int j = 1; j <= 3; j++) {
-            BQ_V(xopt, j) = BQ_V(xnew, j);
-            BQS(xoptsq) += BQ_V(xopt, j) * BQ_V(xopt, j);
-            for (int i = 1; i <= j; i++) {
-                ++ih;
-                if (i < j) BQ_V(gopt, j) += BQ_HQ(ih) * BQ_V(d, i);
-                BQ_V(gopt, i) += BQ_HQ(ih) * BQ_V(d, j);
+        if (f < fopt) {
+            double dd[3];
+            for (int j = 0; j < 3; j++) dd[j] = BQ_V(d, j + 1);
+            BQN(kopt) = knew;
+            double xoptsq = 0.0;
+            ih = 0;
+            for (int j = 1; j <= 3; j++) {
+                xo[j - 1] = xn[j - 1];
+                xoptsq += xo[j - 1] * xo[j - 1];
+                for (int i = 1; i <= j; i++) {
+                    ++ih;
+                    if (i < j) go[j - 1] += hq[ih - 1] * dd[i - 1];
+                    go[i - 1] += hq[ih - 1] * dd[j - 1];
+                }
             }
+            for (int k = 1; k <= 7; k++) {
+                double temp = 0.0;
+                for (int j = 1; j <= 3; j++) temp += xp[k - 1][j - 1] * dd[j - 1];
+                temp = pq[k - 1] * temp;
+                for (int i = 1; i <= 3; i++) go[i - 1] += temp * xp[k - 1][i - 1];
+            }
+            for (int j = 0; j < 3; j++) BQ_V(xopt, j + 1) = xo[j];
+            BQS(xoptsq) = xoptsq;
+            // nlopt_stop_ftol with ftol_rel = ftol_abs = 0 (PatchOptimizer.cpp sets only xtol_rel) never fires
         }
-        for (int k = 1; k <= 7; k++) {
-            double temp = 0.0;
-            for (int j = 1; j <= 3; j++) temp += BQ_XPT(k, j) * BQ_V(d, j);
-            temp = BQ_PQ(k) * temp;
-            for (int i = 1; i <= 3; i++) BQ_V(gopt, i) += temp * BQ_XPT(k, i);
-        }
-        // nlopt_stop_ftol with ftol_rel = ftol_abs = 0 (PatchOptimizer.cpp sets only xtol_rel) never fires
+        for (int j = 0; j < 3; j++) BQ_V(gopt, j + 1) = go[j];
     }
 
-    if (BQN(ntrits) > 0) {  // least-Frobenius-norm interpolant test (bobyqa.c:2845-2944)
-        double vl[10], wk[14];
-        for (int k = 1; k <= 7; k++) { vl[k - 1] = BQ_FVAL(k) - BQ_FVAL(BQN(kopt)); wk[k - 1] = 0.0; }
+    if (ntrits > 0) {  // least-Frobenius-norm interpolant test (bobyqa.c:2845-2944)
+        double vl[10], wk[14], fv[7], bmr[7][3], sl_[3], su_[3];
+        for (int k = 0; k < 7; k++) {
+            fv[k] = BQ_FVAL(k + 1);
+            for (int j = 0; j < 3; j++) bmr[k][j] = BQ_BMAT(k + 1, j + 1);
+        }
+        for (int j = 0; j < 3; j++) { sl_[j] = BQ_V(sl, j + 1); su_[j] = BQ_V(su, j + 1); }
+        const double fko = BQ_FVAL(BQN(kopt));
+        for (int k = 1; k <= 7; k++) { vl[k - 1] = fv[k - 1] - fko; wk[k - 1] = 0.0; }
         for (int j = 1; j <= 3; j++) {
             double sum = 0.0;
-            for (int k = 1; k <= 7; k++) sum += BQ_ZMAT(k, j) * vl[k - 1];
-            for (int k = 1; k <= 7; k++) wk[k - 1] += sum * BQ_ZMAT(k, j);
+            for (int k = 1; k <= 7; k++) sum += z[k - 1][j - 1] * vl[k - 1];
+            for (int k = 1; k <= 7; k++) wk[k - 1] += sum * z[k - 1][j - 1];
         }
         for (int k = 1; k <= 7; k++) {
             double sum = 0.0;
-            for (int j = 1; j <= 3; j++) sum += BQ_XPT(k, j) * BQ_V(xopt, j);
+            for (int j = 1; j <= 3; j++) sum += xp[k - 1][j - 1] * xo[j - 1];
             wk[k + 7 - 1] = wk[k - 1];
             wk[k - 1] = sum * wk[k - 1];
         }
         double gqsq = 0.0, gisq = 0.0;
         for (int i = 1; i <= 3; i++) {
             double sum = 0.0;
-            for (int k = 1; k <= 7; k++) sum = sum + BQ_BMAT(k, i) * vl[k - 1] + BQ_XPT(k, i) * wk[k - 1];
-            if (BQ_V(xopt, i) == BQ_V(sl, i)) {
-                const double t1 = mn(0.0, BQ_V(gopt, i));
+            for (int k = 1; k <= 7; k++) sum = sum + bmr[k - 1][i - 1] * vl[k - 1] + xp[k - 1][i - 1] * wk[k - 1];
+            if (xo[i - 1] == sl_[i - 1]) {
+                const double t1 = mn(0.0, go[i - 1]);
                 gqsq += t1 * t1;
                 const double t2 = mn(0.0, sum);
                 gisq += t2 * t2;
-            } else if (BQ_V(xopt, i) == BQ_V(su, i)) {
-                const double t1 = mx(0.0, BQ_V(gopt, i));
+            } else if (xo[i - 1] == su_[i - 1]) {
+                const double t1 = mx(0.0, go[i - 1]);
                 gqsq += t1 * t1;
                 const double t2 = mx(0.0, sum);
                 gisq += t2 * t2;
             } else {
-                gqsq += BQ_V(gopt, i) * BQ_V(gopt, i);
+                gqsq += go[i - 1] * go[i - 1];
                 gisq += sum * sum;
             }
             vl[7 + i - 1] = sum;
         }
-        ++BQN(itest);
-        if (gqsq < 10.0 * gisq) BQN(itest) = 0;
-        if (BQN(itest) >= 3) {
+        int itest = BQN(itest) + 1;
+        if (gqsq < 10.0 * gisq) itest = 0;
+        if (itest >= 3) {
             for (int i = 1; i <= 7; i++) {  // max(npt, nh) = 7
                 if (i <= 3) BQ_V(gopt, i) = vl[7 + i - 1];
                 if (i <= 7) BQ_PQ(i) = wk[7 + i - 1];
                 if (i <= 6) BQ_HQ(i) = 0.0;
-                BQN(itest) = 0;
             }
+            itest = 0;
         }
+        BQN(itest) = itest;
     }
-    if (BQN(ntrits) == 0) return L60;
+    if (ntrits == 0) return L60;
     if (f <= fopt + 0.1 * vquad) return L60;
-    const double a = 2.0 * BQS(delta), b = 10.0 * BQS(rho);
+    const double a = 2.0 * BQS(delta), b = 10.0 * rho;
     BQS(distsq) = mx(a * a, b * b);
     return L650;
 }
@@ -1650,9 +1854,9 @@ BQ_HD int bq_step(BqRef B, double f) {
     return r;
 }
 // everything bq_step does before the label loop: consumes f, returns the label to continue at
-BQ_HD_NOINLINE int bq_step_entry(BqRef B, double f);
+BQ_HD_BLOCK int bq_step_entry(BqRef B, double f);
 BQ_HD_NOINLINE int bq_step_(BqRef B, double f) { return bq::run(B, bq_step_entry(B, f)); }
-BQ_HD_NOINLINE int bq_step_entry(BqRef B, double f) {
+BQ_HD_BLOCK int bq_step_entry(BqRef B, double f) {
     int label = bq::LRET_DONE;
     if (BQN(phase) == bq::PH_PRELIM) {
         bq::prelim_consume(B, f);

@@ -532,11 +532,19 @@ static nccl_allgather_fn find_allgather() {
     static nccl_allgather_fn fn = nullptr;
     static std::once_flag once;
     std::call_once(once, [] {
-        void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");  // the RCCL already in the process (the communicator's own)
-        if (!sym) {
-            void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-            if (h) sym = dlsym(h, "ncclAllGather");
+        // HPMVS_RCCL_LIBRARY names the library to take ncclAllGather from (an application that links its own build of
+        // RCCL under another name); otherwise the RCCL already in the process (the communicator's own), then the
+        // system's librccl
+        void* sym = nullptr;
+        if (const char* named = getenv("HPMVS_RCCL_LIBRARY")) {
+            if (void* h = dlopen(named, RTLD_NOW | RTLD_GLOBAL)) sym = dlsym(h, "ncclAllGather");
+        } else {
+            sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+            if (!sym) {
+                void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+                if (h) sym = dlsym(h, "ncclAllGather");
+            }
         }
         fn = (nccl_allgather_fn)sym;
     });
@@ -545,7 +553,19 @@ static nccl_allgather_fn find_allgather() {
 extern "C" int hpmvs_allgather_records(void* nccl_comm, const hpmvs_record* send, size_t count, hpmvs_record* recv, void* stream) {
     if (!nccl_comm || (count > 0 && (!send || !recv))) return fail(HPMVS_ERR_ARG, "allgather_records: null argument");
     nccl_allgather_fn fn = find_allgather();
-    if (!fn) return fail(HPMVS_ERR_STATE, "allgather_records: RCCL (ncclAllGather) not found in the process nor as librccl.so.1");
+    if (!fn) return fail(HPMVS_ERR_STATE, "allgather_records: RCCL (ncclAllGather) not found in the process, as librccl.so.1 nor as $HPMVS_RCCL_LIBRARY");
+    if (count > 0) {
+        // both buffers must be device memory of ONE device (the communicator's): a host pointer or a buffer of another
+        // GPU would fault inside the collective, on every rank
+        hipPointerAttribute_t as{}, ar{};
+        if (hipPointerGetAttributes(&as, send) != hipSuccess || hipPointerGetAttributes(&ar, recv) != hipSuccess ||
+            as.type != hipMemoryTypeDevice || ar.type != hipMemoryTypeDevice) {
+            (void)hipGetLastError();
+            return fail(HPMVS_ERR_ARG, "allgather_records: send / recv must be device memory");
+        }
+        if (as.device != ar.device)
+            return fail(HPMVS_ERR_ARG, "allgather_records: send is on device " + std::to_string(as.device) + ", recv on device " + std::to_string(ar.device));
+    }
     const int r = fn(send, recv, count * sizeof(hpmvs_record), /*ncclUint8*/ 1, nccl_comm, (hipStream_t)stream);
     if (r != 0) return fail(HPMVS_ERR_HIP, "ncclAllGather failed with ncclResult_t " + std::to_string(r));
     return HPMVS_OK;
@@ -797,6 +817,10 @@ static int optimize_through_service(const hpmvs_scene* s, const hpmvs_options* o
         const int k = k0 + i;
         unsigned spins = 0;
         auto t_check = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
+        // a patch is at most 1000 evaluation rounds of well under a millisecond; far beyond that the device is not
+        // making progress and the caller gets an error instead of waiting for ever
+        static const long limit_s = [] { const char* e = getenv("HPMVS_SERVICE_TIMEOUT_S"); return e && atol(e) > 0 ? atol(e) : 120L; }();
+        const auto t_limit = std::chrono::steady_clock::now() + std::chrono::seconds(limit_s);
         while (S->done[k] == 0) {
             // Poll gently: the flags live in host memory that the GPU writes over PCIe, and hundreds of cores reading
             // those lines back to back delay exactly those writes and the device's reads of the progress words
@@ -810,6 +834,7 @@ static int optimize_through_service(const hpmvs_scene* s, const hpmvs_options* o
                 // the launch must still be running while my flag is down
                 const hipError_t q = hipStreamQuery(S->st);
                 if (q != hipErrorNotReady && S->done[k] == 0) { rc = fail(HPMVS_ERR_HIP, "open batch ended without finishing a published patch"); break; }
+                if (std::chrono::steady_clock::now() > t_limit) { rc = fail(HPMVS_ERR_HIP, "open batch: a published patch was not finished within " + std::to_string(limit_s) + " s (HPMVS_SERVICE_TIMEOUT_S)"); break; }
                 t_check = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
             }
         }

@@ -230,7 +230,10 @@ int hpmvs_last_kernel_ms(const hpmvs_scene *s, float *ms);
  *   hpmvs_pack_records       SoA batch (device arrays) -> n records (device), one kernel on `stream`
  *   hpmvs_allgather_records  ncclAllGather of `count` records per rank over the caller's RCCL communicator
  *                            (xGMI inside a node); RCCL is looked up at run time in the process (the library the
- *                            communicator came from), else librccl.so.1 is opened -- no link-time dependency
+ *                            communicator came from), else librccl.so.1 is opened -- no link-time dependency;
+ *                            $HPMVS_RCCL_LIBRARY names another library to take it from.  HPMVS_ERR_STATE when
+ *                            none is found; HPMVS_ERR_ARG for a null communicator, for host pointers and for
+ *                            send / recv buffers on two different devices (checked before the collective starts)
  *   hpmvs_unpack_records     records (device) -> SoA batch (device arrays); ok / color / fmin included
  * Ragged rounds (n not divisible by the ranks): pad every rank to the largest slice, records beyond a rank's
  * count are zero (ok = 0). */

@@ -84,6 +84,15 @@ int main(int argc, char** argv) {
     HK(hipMalloc((void**)&send, sizeof(hpmvs_record) * n)); HK(hipMalloc((void**)&recv, sizeof(hpmvs_record) * n));
     CK(hpmvs_optimize_batch(sc, &o, &b, /*on_device=*/1, st));
     CK(hpmvs_pack_records(&b, send, st));
+    {   // refused before the collective starts: host memory as a buffer, a null communicator
+        std::vector<hpmvs_record> host_buf(n);
+        if (hpmvs_allgather_records(comm, host_buf.data(), (size_t)n, recv, st) != HPMVS_ERR_ARG ||
+            hpmvs_allgather_records(comm, send, (size_t)n, host_buf.data(), st) != HPMVS_ERR_ARG ||
+            hpmvs_allgather_records(nullptr, send, (size_t)n, recv, st) != HPMVS_ERR_ARG) {
+            fprintf(stderr, "allgather_records accepted a host pointer / null communicator\n");
+            return 3;
+        }
+    }
     CK(hpmvs_allgather_records(comm, send, (size_t)n, recv, st));
     CK(hpmvs_unpack_records(recv, n, &u, st));
     HK(hipStreamSynchronize(st));

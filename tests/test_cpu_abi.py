@@ -72,3 +72,30 @@ def test_expand_direction_table_matches_libm():
         t = api.expand_directions(mode)
         assert t.shape == (n, 2)
         assert np.array_equal(t, orc.expand_directions(mode))
+
+
+def test_allgather_records_failure_paths_without_rccl():
+    """hpmvs_allgather_records before any collective can start (VERDICT r2): a null communicator is an argument error;
+    when no ncclAllGather can be found (HPMVS_RCCL_LIBRARY pointing at nothing) the call reports HPMVS_ERR_STATE with
+    a message naming the look-up, it does not crash.  (Separate process: the look-up is cached.)"""
+    import subprocess, sys, os
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from hpmvs_amd import api
+L = api.lib()
+L.hpmvs_allgather_records.restype = C.c_int
+L.hpmvs_allgather_records.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+buf = (C.c_uint8 * 192)()
+r0 = L.hpmvs_allgather_records(None, buf, 1, buf, None)
+m0 = L.hpmvs_last_error()
+r1 = L.hpmvs_allgather_records(C.c_void_p(0x1000), buf, 1, buf, None)
+m1 = L.hpmvs_last_error()
+print(r0, m0.decode()); print(r1, m1.decode())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HPMVS_RCCL_LIBRARY="/nonexistent/librccl_missing.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    l0, l1 = out.stdout.strip().splitlines()[-2:]
+    assert l0.startswith("-2 ") and "null argument" in l0      # HPMVS_ERR_ARG
+    assert l1.startswith("-3 ") and "HPMVS_RCCL_LIBRARY" in l1  # HPMVS_ERR_STATE
