@@ -80,10 +80,17 @@
 #define BQ_PROF_COUNT(i, n) atomicAdd(&s_prof[(i)], (unsigned long long)(n))
 #define BQ_PROF_BEGIN(v) const long long v = clock64()
 #define BQ_PROF_END(v, i) do { if (__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) { atomicAdd(&s_prof[2 * (i)], (unsigned long long)(clock64() - v)); atomicAdd(&s_prof[2 * (i) + 1], 1ull); } } while (0)
+struct BqProfScope {  // times one pass of a loop body (continue / break leave through the destructor)
+    long long t0; int i;
+    __device__ BqProfScope(int i_) : t0(clock64()), i(i_) {}
+    __device__ ~BqProfScope() { if (__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) { atomicAdd(&s_prof[2 * i], (unsigned long long)(clock64() - t0)); atomicAdd(&s_prof[2 * i + 1], 1ull); } }
+};
+#define BQ_PROF_SCOPE(i) BqProfScope bq_prof_scope_(i)
 #else
 #define BQ_PROF_COUNT(i, n) do { } while (0)
 #define BQ_PROF_BEGIN(v) do { } while (0)
 #define BQ_PROF_END(v, i) do { } while (0)
+#define BQ_PROF_SCOPE(i) do { } while (0)
 #endif
 
 // Loads placed after BQ_STAGE() stay after it: the blocks below read their arrays in stages, and a stage's registers
@@ -433,6 +440,7 @@ BQ_HD_BLOCK void trsbox(BqRef B) {
 #define BQ_ANY(c) (c)
 #endif
     while (BQ_ANY(st == CG_RESTART || st == CG_NEXT)) {
+        BQ_PROF_SCOPE(18);
         if (st == CG_RESTART) { beta = 0.0; st = CG_NEXT; }
         if (st == CG_NEXT) {
             stepsq = 0.0;
@@ -504,6 +512,7 @@ BQ_HD_BLOCK void trsbox(BqRef B) {
         }
     }
     while (BQ_ANY(st == BOUNDARY || st == ALT_SETUP || st == ALT_ITER)) {
+        BQ_PROF_SCOPE(19);
         if (st == BOUNDARY) { crvmin = 0.0; st = ALT_SETUP; }
         if (st == ALT_SETUP) {
             if (nact >= 2) { st = FINISH; continue; }

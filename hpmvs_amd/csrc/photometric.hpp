@@ -264,13 +264,38 @@ struct Taps { uint2 a, b; float f00, f01, f10, f11; };
 
 // Image::getColor (Image.h:104-113) in its evaluation order
 __device__ __forceinline__ void texel(const Taps& t, float& r, float& g, float& b) {
-    r = 0.0f; g = 0.0f; b = 0.0f;
-    r += (float)(t.a.x & 0xff) * t.f00 + (float)(t.b.x & 0xff) * t.f01;
-    g += (float)((t.a.x >> 8) & 0xff) * t.f00 + (float)((t.b.x >> 8) & 0xff) * t.f01;
-    b += (float)((t.a.x >> 16) & 0xff) * t.f00 + (float)((t.b.x >> 16) & 0xff) * t.f01;
+    // (Image::getColor starts from 0 and adds: the first sum is a sum of products of non-negative values, never -0,
+    //  so 0 + it is it)
+    r = (float)(t.a.x & 0xff) * t.f00 + (float)(t.b.x & 0xff) * t.f01;
+    g = (float)((t.a.x >> 8) & 0xff) * t.f00 + (float)((t.b.x >> 8) & 0xff) * t.f01;
+    b = (float)((t.a.x >> 16) & 0xff) * t.f00 + (float)((t.b.x >> 16) & 0xff) * t.f01;
     r += (float)(t.a.x >> 24) * t.f10 + (float)(t.b.x >> 24) * t.f11;
     g += (float)(t.a.y & 0xff) * t.f10 + (float)(t.b.y & 0xff) * t.f11;
     b += (float)((t.a.y >> 8) & 0xff) * t.f10 + (float)((t.b.y >> 8) & 0xff) * t.f11;
+}
+
+// texel() for two texels A, B in the halves of float2 values.  (The `0 +` that texel() starts each channel with is
+// left out here and there: the terms are products of non-negative values, never -0, so adding them to +0 changes nothing.)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void texel_pair(uint2 aA, uint2 bA, float wxA, float wyA, uint2 aB, uint2 bB, float wxB, float wyB,
+                                           float* outA, float* outB) {
+    const v2f dx1 = {wxA, wxB}, dy1 = {wyA, wyB};
+    const v2f one = {1.0f, 1.0f};
+    const v2f dx0 = one - dx1, dy0 = one - dy1;
+    const v2f f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
+#define HPMVS_B(v, sh) (float)(((v) >> (sh)) & 0xffu)
+    const v2f r00 = {HPMVS_B(aA.x, 0), HPMVS_B(aB.x, 0)}, r01 = {HPMVS_B(bA.x, 0), HPMVS_B(bB.x, 0)};
+    const v2f g00 = {HPMVS_B(aA.x, 8), HPMVS_B(aB.x, 8)}, g01 = {HPMVS_B(bA.x, 8), HPMVS_B(bB.x, 8)};
+    const v2f b00 = {HPMVS_B(aA.x, 16), HPMVS_B(aB.x, 16)}, b01 = {HPMVS_B(bA.x, 16), HPMVS_B(bB.x, 16)};
+    const v2f r10 = {(float)(aA.x >> 24), (float)(aB.x >> 24)}, r11 = {(float)(bA.x >> 24), (float)(bB.x >> 24)};
+    const v2f g10 = {HPMVS_B(aA.y, 0), HPMVS_B(aB.y, 0)}, g11 = {HPMVS_B(bA.y, 0), HPMVS_B(bB.y, 0)};
+    const v2f b10 = {HPMVS_B(aA.y, 8), HPMVS_B(aB.y, 8)}, b11 = {HPMVS_B(bA.y, 8), HPMVS_B(bB.y, 8)};
+#undef HPMVS_B
+    const v2f r = (r00 * f00 + r01 * f01) + (r10 * f10 + r11 * f11);
+    const v2f g = (g00 * f00 + g01 * f01) + (g10 * f10 + g11 * f11);
+    const v2f b = (b00 * f00 + b01 * f01) + (b10 * f10 + b11 * f11);
+    outA[0] = r.x; outA[1] = g.x; outA[2] = b.x;
+    outB[0] = r.y; outB[1] = g.y; outB[2] = b.y;
 }
 
 constexpr int kGroups = 9;               // grabs per pass: nine 7-lane groups, lane 63 is spare
@@ -304,6 +329,23 @@ __device__ __forceinline__ float row_chain(const float (&v)[N]) {
         out = a;
     }
     return out;
+}
+
+// two such chains at once, in the halves of a float2 (same additions per half, half the add instructions; the
+// hand-over is two DPP moves instead of being folded into the first add)
+template <int N>
+__device__ __forceinline__ void row_chain_pair(const float (&va)[N], const float (&vb)[N], float& outa, float& outb) {
+    v2f out = {0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < kTex; s++) {
+        v2f a;
+        if (s == 0) { a.x = 0.0f; a.y = 0.0f; }
+        else { a.x = lane_prev(out.x); a.y = lane_prev(out.y); }
+#pragma unroll
+        for (int i = 0; i < N; i++) { const v2f t = {va[i], vb[i]}; a = a + t; }
+        out = a;
+    }
+    outa = out.x; outb = out.y;
 }
 
 // list: the calling lane's own image list (ids; read only for lanes with a pending request).  Must be called by
@@ -542,8 +584,13 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
                         tb[xx] = load8(p0 + 3 * W);
                     }
                 }
+                // Image::getColor two texels at a time: every float32 operation of texel() on the two halves of a
+                // register pair (v_pk_mul_f32 / v_pk_add_f32 are IEEE per half: same values, half the instructions)
 #pragma unroll
-                for (int xx = 0; xx < kTex; xx++) {
+                for (int xx = 0; xx + 1 < kTex; xx += 2)
+                    texel_pair(ta[xx], tb[xx], wx[xx], wy[xx], ta[xx + 1], tb[xx + 1], wx[xx + 1], wy[xx + 1], &t[3 * xx], &t[3 * xx + 3]);
+                {
+                    const int xx = kTex - 1;
                     Taps tp;
                     tp.a = ta[xx]; tp.b = tb[xx];
                     const float dx1 = wx[xx], dx0 = 1.0f - dx1;
@@ -561,7 +608,10 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
                 float vr[kTex], vg[kTex], vb[kTex];
 #pragma unroll
                 for (int xx = 0; xx < kTex; xx++) { vr[xx] = t[3 * xx]; vg[xx] = t[3 * xx + 1]; vb[xx] = t[3 * xx + 2]; }
-                const float s0 = row_chain<kTex>(vr), s1 = row_chain<kTex>(vg), s2 = row_chain<kTex>(vb);
+                // the red and green chains run in the two halves of one register pair (v_pk_add_f32), the blue one beside them
+            float s0, s1;
+            row_chain_pair<kTex>(vr, vg, s0, s1);
+            const float s2 = row_chain<kTex>(vb);
                 a0 = div_by(shfl_f(s0, last), 1.0 / 49.0);
                 a1 = div_by(shfl_f(s1, last), 1.0 / 49.0);
                 a2 = div_by(shfl_f(s2, last), 1.0 / 49.0);
@@ -587,21 +637,20 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
                 t[3 * xx + 2] = div_by(t[3 * xx + 2] - a2, iv);
             }
             // ---- 5. Patch2d::dot with the request's reference texture (Patch2d.hpp:37-44)
-            float raw, rob;
-            {
+            float raw = 0.0f, rob = 0.0f;
+#pragma unroll
+            for (int i = 0; i < kRowVals; i++) refn[i] = g_isref ? t[i] : refn[i];
+            PH_T(t6);
+            PH_ADD(t5, t6, 20);
+            if (__any(act && !g_isref)) {  // (wave-uniform) the first pass of a batch is all reference grabs: nothing to correlate
                 float pr[kRowVals];
 #pragma unroll
-                for (int i = 0; i < kRowVals; i++) {
-                    refn[i] = g_isref ? t[i] : refn[i];
-                    pr[i] = refn[i] * t[i];
-                }
-                PH_T(t6);
-                PH_ADD(t5, t6, 20);
+                for (int i = 0; i < kRowVals; i++) pr[i] = refn[i] * t[i];
                 raw = 1.0f - div_by(shfl_f(row_chain<kRowVals>(pr), last), 1.0 / 147.0);
                 rob = robustincc(raw);
-                PH_T(t7);
-                PH_ADD(t6, t7, 21);
             }
+            PH_T(t7);
+            PH_ADD(t6, t7, 21);
             PH_T(t7b);
 
             // ---- 6. the request's accumulations, in the reference's loop order (identical on the group's lanes)

@@ -8,7 +8,7 @@ ARGS=${@:---steps 3 --warmup 1 --no-cpu}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG; RAW=/tmp/rocprof_raw_$TAG
 mkdir -p $OUT; rm -rf $RAW
-rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o t -- python bench.py $ARGS > $OUT/bench_trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o t -- python bench.py $ARGS > $OUT/bench_trace.log 2>&1
 python profiles/summarize.py $RAW/trace $OUT/${TAG}_trace
 find $RAW/trace -name '*kernel_stats.csv' | head -1 | xargs -r -I{} sh -c 'head -12 {} > '$OUT/${TAG}'_rocprof_kernel_stats_top.csv'
 i=0
@@ -18,7 +18,7 @@ for PMC in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
            "GRBM_GUI_ACTIVE GRBM_COUNT" \
            "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU SQ_INSTS_VALU SQ_INSTS_SALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $RAW/pmc$i -o p -- python bench.py --steps 1 --warmup 0 --no-cpu ${BENCH_EXTRA:-} > $OUT/bench_pmc$i.log 2>&1
+  timeout 900 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $RAW/pmc$i -o p -- python bench.py --steps 1 --warmup 0 --no-cpu ${BENCH_EXTRA:-} > $OUT/bench_pmc$i.log 2>&1
   python profiles/summarize.py $RAW/pmc$i $OUT/${TAG}_pmc$i
 done
 rm -rf $RAW

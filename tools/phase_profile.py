@@ -20,7 +20,7 @@ names=['trsbox','altmov','update','bq_step','L20','L60(trsbox+)','L90(shift)','L
 for i,nm in enumerate(names):
     tot,cnt=int(out[4+2*i]),int(out[5+2*i])
     print(nm,'lane-calls',cnt,'avg cycles per call %.0f'%(tot/max(cnt,1)))
-for i,nm in [(23,'after_eval'),(13,'B:prep'),(14,'B:taps+stage'),(15,'B:means+var'),(20,'B:normalise+products'),(21,'B:ncc sum'),(22,'B:deliver'),(24,'list services (wave passes)'),(25,'region: lock wait'),(27,'region: page in'),(26,'region: page out + release'),(16,'finish (colour, stores)'),(17,'calc_patch_axes')]:
+for i,nm in [(23,'after_eval'),(13,'B:prep'),(14,'B:taps+stage'),(15,'B:means+var'),(20,'B:normalise+products'),(21,'B:ncc sum'),(22,'B:deliver'),(24,'list services (wave passes)'),(25,'region: lock wait'),(27,'region: page in'),(26,'region: page out + release'),(16,'finish (colour, stores)'),(17,'calc_patch_axes'),(18,'trsbox: one pass of the CG loop'),(19,'trsbox: one pass of the boundary loop')]:
     tot,cnt=int(out[4+2*i]),int(out[5+2*i]); print(nm,'wave-passes',cnt,'avg cycles %.0f'%(tot/max(cnt,1)),'total %.3g'%tot)
 print('trsbox per-lane: calls',int(out[4+59]),'CG iters/call %.2f'%(int(out[4+56])/max(int(out[4+59]),1)),'ALT iters/call %.2f'%(int(out[4+57])/max(int(out[4+59]),1)),'angle steps per ALT iter %.1f'%(int(out[4+58])/max(int(out[4+57]),1)))
 print('photometric batches', int(out[4+62]), 'sum of longest request per batch', int(out[4+60]), 'sum of ideal passes ceil(grabs/9)', int(out[4+61]), 'long (>8 grabs) setINCCs requests', int(out[4+63]))
