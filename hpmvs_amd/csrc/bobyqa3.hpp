@@ -213,9 +213,9 @@ enum {  // int32 slots
 __shared__ double bq_lds_d[BQ_ND * BQ_SLOTS];
 __shared__ int bq_lds_i[BQ_NI * BQ_SLOTS];
 #endif
-struct Bobyqa3 { int slot; };
+struct Bobyqa3 { int slot; int slot_i; };  // slot: index into the float64 array, slot_i: into the int32 array (they differ when the including kernel keeps several state regions)
 #define BQ_D(i) bq_lds_d[(i) * BQ_SLOTS + B.slot]
-#define BQ_I(i) bq_lds_i[(i) * BQ_SLOTS + B.slot]
+#define BQ_I(i) bq_lds_i[(i) * BQ_SLOTS + B.slot_i]
 #else
 struct Bobyqa3 { double dd[BQ_ND]; int ii[BQ_NI]; };
 #define BQ_D(i) B.dd[(i)]

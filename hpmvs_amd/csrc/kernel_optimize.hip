@@ -47,10 +47,20 @@
 #define HPMVS_REGION_BYTES (HPMVS_STATE_ND * 8 * BQ_P + HPMVS_STATE_NI * 4 * BQ_P)
 #define HPMVS_REGION_KIB ((HPMVS_REGION_BYTES + 1023) / 1024)  // paged in 1 KiB pieces (one LDS-DMA instruction each)
 #define HPMVS_REGION_16 (HPMVS_REGION_KIB * 64)
-__shared__ uint4 hpmvs_region[HPMVS_REGION_16];
-__shared__ int hpmvs_lock[2];  // [0]: 0 = region free, 1 + w = held by wavefront w; [1]: bit w = wavefront w has left
-#define bq_lds_d ((double*)hpmvs_region)
-#define bq_lds_i ((int*)((char*)hpmvs_region + HPMVS_STATE_ND * 8 * BQ_P))
+// A batch launch runs ONE workgroup of 8 wavefronts per CU that share a POOL of 4 regions (a wavefront takes whichever
+// is free): with a region per pair of wavefronts the partner was in the way 78 % of the time and a wavefront waited
+// 18 k cycles per round for it; four servers behind one queue keep the same utilisation with about half the wait.
+// The open batch (optimize_service_kernel) keeps two-wavefront workgroups with one region, so that it leaves three
+// quarters of a CU's LDS to batch launches.  Regions and lock words are dynamic LDS: [regions][lock per region][done bits].
+#ifndef HPMVS_WG_WAVES
+#define HPMVS_WG_WAVES 8
+#endif
+#ifndef HPMVS_WG_REGIONS
+#define HPMVS_WG_REGIONS 4
+#endif
+extern __shared__ uint4 hpmvs_dyn[];
+#define bq_lds_d ((double*)hpmvs_dyn)
+#define bq_lds_i ((int*)((char*)hpmvs_dyn + HPMVS_STATE_ND * 8 * BQ_P))
 #include "bobyqa3.hpp"
 #include "launch.h"
 #include "photometric.hpp"
@@ -73,7 +83,7 @@ constexpr int kPark16 = HPMVS_REGION_16;  // 16-byte chunks of a wavefront's par
 // the state region <-> this wavefront's parking buffer.  In: LDS-DMA (global_load_lds_dwordx4: 1 KiB per
 // instruction straight into LDS at base + lane * 16, no staging registers, all ~39 pieces in flight at once).
 // Out: ds_read_b128 + 16-byte global stores (fire and forget).
-__device__ __forceinline__ void page_in(const uint4* __restrict__ park) {
+__device__ __forceinline__ void page_in(const uint4* __restrict__ park, uint4* hpmvs_region) {
     // One running per-lane pointer, four pieces per step through the instruction's immediate offset (which moves the
     // global AND the LDS address).  (With one precomputed address per piece the compiler hoisted all 39 out of the
     // kernel's main loop, spilled them, and reloaded each from scratch behind an s_waitcnt vmcnt(0) -- which also
@@ -92,7 +102,7 @@ __device__ __forceinline__ void page_in(const uint4* __restrict__ park) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-__device__ __forceinline__ void page_out(uint4* __restrict__ park) {
+__device__ __forceinline__ void page_out(uint4* __restrict__ park, const uint4* hpmvs_region) {
     const int lane = lane_id();
 #pragma unroll 13
     for (int c = 0; c < HPMVS_REGION_KIB; c++) {
@@ -124,16 +134,17 @@ __device__ __forceinline__ unsigned long long ld_host64(const unsigned long long
 #endif
 // SERVICE = false: a batch launch (the arrays of `b` are device memory, n patches).  SERVICE = true: an open batch (see
 // OPEN BATCH below).  Two instantiations, so that the batch kernel carries none of the open batch's code or registers.
-template <bool SERVICE>
+template <bool SERVICE, int W, int R>
 __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
     const int lane = lane_id();
-    const int wv = (int)(threadIdx.x >> 6);            // which wavefront of the pair
+    const int wv = (int)(threadIdx.x >> 6);            // which wavefront of the workgroup (W of them, R state regions)
+    int* const hpmvs_lock = (int*)(hpmvs_dyn + R * HPMVS_REGION_16);  // [r]: 0 = region r free, 1 + w = held by wavefront w; [R]: bit w = wavefront w has left
     const int n_wgs = (int)gridDim.x;
     const int gw = wv * n_wgs + (int)blockIdx.x;        // wavefront index: all first wavefronts before the second ones
     // this wavefront's image-list rows and parking buffer in the launch workspace (behind the counter block)
     uint16_t* lists = (uint16_t*)((char*)queue + kCounterBytes) + (size_t)gw * kP * kRow;
     uint16_t* row = &lists[(lane < kP ? lane : 0) * kRow];
-    uint4* park = (uint4*)((char*)queue + kCounterBytes + (size_t)2 * n_wgs * kP * kRow * sizeof(uint16_t)) + (size_t)gw * kPark16;
+    uint4* park = (uint4*)((char*)queue + kCounterBytes + (size_t)W * n_wgs * kP * kRow * sizeof(uint16_t)) + (size_t)gw * kPark16;
 
     // ---- per-lane slot state
     // Small batches are spread over as many workgroups as possible (a wavefront with fewer busy slots has shorter
@@ -147,16 +158,18 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
     // with cache-bypassing system-scope loads / stores, the copies with relaxed agent-scope atomics.
     constexpr bool service = SERVICE;
     const int per_wg = (b.n + n_wgs - 1) / n_wgs;
-    int quota = wv == 0 ? (per_wg < kP ? per_wg : kP) : (per_wg - kP < 0 ? 0 : (per_wg - kP < kP ? per_wg - kP : kP));
+    int quota = per_wg - wv * kP;  // the workgroup's share goes to its wavefronts in order
+    quota = quota < 0 ? 0 : (quota < kP ? quota : kP);
     if (service) quota = wv == 0 ? (b.svc_lanes < kP ? b.svc_lanes : kP) : 0;  // few patches per wavefront: latency first
-    if (threadIdx.x == 0) { hpmvs_lock[0] = 0; hpmvs_lock[1] = 0; }
+    if (threadIdx.x <= R) hpmvs_lock[threadIdx.x] = 0;
     __syncthreads();
     if (quota == 0) {  // nothing to do for this wavefront: tell the partner that the region is his
-        if (lane == 0) atomicOr(&hpmvs_lock[1], 1 << wv);
+        if (lane == 0) atomicOr(&hpmvs_lock[R], 1 << wv);
         return;
     }
     __builtin_amdgcn_s_setprio(HPMVS_A_PRIO);
-    bool held = false, solo = false;  // region held by this wavefront; partner gone (held for good, no paging)
+    bool held = false, solo = false;  // a region is held by this wavefront; no more wavefronts than regions are left (held for good, no paging)
+    int reg = 0;                      // which region
     bool parked = false;              // my states are in the parking buffer
     int stage = (lane < quota) ? S_FETCH : S_IDLE;  // the other lanes only help in the wave-cooperative phases
     int idx = -1, nimg = 0, ii = 0, refindex = -1, ngrabs = 0, fail_stage = 0, nl_result = 0;
@@ -166,6 +179,7 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
     OptFields F;
     Bobyqa3 B;
     B.slot = lane < kP ? lane : 0;
+    B.slot_i = B.slot;
     // request posted to phase B (with the patch axes of calculatePatchAxis for the request's reference image)
     float ax[3] = {0, 0, 0}, ay[3] = {0, 0, 0}, az[3] = {0, 0, 1};
     int op = OP_NONE, req_ref = 0, req_robust = 0;
@@ -433,16 +447,29 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
             }
             if (!held) {  // take the region and bring my patches' states in
                 BQ_PROF_BEGIN(tpg_);
-                if (lane == 0)
-                    while (atomicCAS(&hpmvs_lock[0], 0, 1 + wv) != 0) __builtin_amdgcn_s_sleep(8);
+                int got = 0;
+                if (lane == 0) {
+                    int r = R > 1 ? wv % R : 0;  // (start at different regions: fewer failed attempts)
+                    for (;;) {
+                        if (atomicCAS(&hpmvs_lock[r], 0, 1 + wv) == 0) break;
+                        r = r + 1 == R ? 0 : r + 1;
+                        if (r == (R > 1 ? wv % R : 0)) __builtin_amdgcn_s_sleep(8);  // every region is taken
+                    }
+                    got = r;
+                }
+                reg = __builtin_amdgcn_readfirstlane(got);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 BQ_PROF_END(tpg_, 25);
+                // my patches' states sit in region `reg` from here on: offsets of its arrays in 8- and 4-byte words
+                B.slot = (lane < kP ? lane : 0) + reg * (HPMVS_REGION_16 * 2);
+                B.slot_i = (lane < kP ? lane : 0) + reg * (HPMVS_REGION_16 * 4);
                 BQ_PROF_BEGIN(tpi_);
-                if (parked) page_in(park);  // (nothing is parked before this wavefront's first release)
+                if (parked) page_in(park, hpmvs_dyn + reg * HPMVS_REGION_16);  // (nothing is parked before this wavefront's first release)
                 BQ_PROF_END(tpi_, 27);
                 held = true;
-                solo = (hpmvs_lock[1] >> (wv ^ 1)) & 1;  // wave-uniform LDS read: the partner has left, no more hand-overs
+                // wave-uniform LDS read: when no more wavefronts than regions are left, nobody waits for mine any more
+                solo = W - __popc((unsigned)hpmvs_lock[R] & ((1u << W) - 1u)) <= R;
             }
 #if HPMVS_BQ_PRIO
             __builtin_amdgcn_s_setprio(HPMVS_BQ_PRIO);  // the region is the contended resource: hold it as briefly as possible
@@ -472,11 +499,11 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
             }
             if (!solo) {  // park my states and hand the region to the partner wavefront
                 BQ_PROF_BEGIN(tpo_);
-                page_out(park);
+                page_out(park, hpmvs_dyn + reg * HPMVS_REGION_16);
                 parked = true;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
-                if (lane == 0) atomicExch(&hpmvs_lock[0], 0);
+                if (lane == 0) atomicExch(&hpmvs_lock[reg], 0);
                 held = false;
                 BQ_PROF_END(tpo_, 26);
             }
@@ -523,7 +550,7 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
                 else { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
                 continue;
             }
-            if (lane == 0) atomicOr(&hpmvs_lock[1], 1 << wv);  // every lane idle: queue drained
+            if (lane == 0) atomicOr(&hpmvs_lock[R], 1 << wv);  // every lane idle: queue drained
             break;
         }
         {
@@ -564,49 +591,55 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
 #endif
 }
 
-__global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
-    optimize_body<false>(sc, o, b, queue);
+__global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
+    optimize_body<false, HPMVS_WG_WAVES, HPMVS_WG_REGIONS>(sc, o, b, queue);
 }
 __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_service_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
-    optimize_body<true>(sc, o, b, queue);
+    optimize_body<true, 2, 1>(sc, o, b, queue);
 }
 
-static int max_workgroups(int n_cus) {
-    // two-wavefront workgroups per CU: LDS (one state region each) and the waves-per-SIMD limit
-    int lds_per_wg = (int)(HPMVS_REGION_16 * 16 + 2 * sizeof(int));
+static size_t lds_bytes(int regions) { return (size_t)regions * HPMVS_REGION_16 * 16 + (size_t)(regions + 1) * sizeof(int); }
+
+static int max_workgroups(int n_cus, int waves, int regions) {
+    // workgroups per CU: LDS (their state regions) and the waves-per-SIMD limit
+    int lds_per_wg = (int)lds_bytes(regions);
 #ifdef HPMVS_PROFILE_PHASES
     lds_per_wg += 64 * 8;
 #endif
     lds_per_wg = (lds_per_wg + 511) & ~511;  // LDS allocation granule
     int per_cu = (160 * 1024) / lds_per_wg;
-    if (per_cu > 2 * HPMVS_WAVES_PER_EU) per_cu = 2 * HPMVS_WAVES_PER_EU;
+    if (per_cu > 4 * HPMVS_WAVES_PER_EU / waves) per_cu = 4 * HPMVS_WAVES_PER_EU / waves;
     return n_cus * per_cu;
 }
 
 size_t optimize_workspace_bytes(int n_cus) {
     // counter block + per wavefront: kP image-list rows and one parking buffer for the optimiser states
-    const size_t waves = (size_t)2 * max_workgroups(n_cus);
+    const size_t waves = (size_t)HPMVS_WG_WAVES * max_workgroups(n_cus, HPMVS_WG_WAVES, HPMVS_WG_REGIONS);
     return kCounterBytes + waves * kP * kRow * sizeof(uint16_t) + waves * (size_t)kPark16 * 16;
 }
 
-// open batch (b.svc_ctrl set): a fixed grid of `wgs` workgroups (one per CU leaves room for batch launches beside it)
+// open batch (b.svc_ctrl set): a fixed grid of `wgs` two-wavefront workgroups (one per CU leaves room for batch launches beside it)
 size_t optimize_workspace_bytes_for(int wgs) {
     return kCounterBytes + (size_t)2 * wgs * kP * kRow * sizeof(uint16_t) + (size_t)2 * wgs * (size_t)kPark16 * 16;
 }
 size_t optimize_stage_bytes_for(int wgs) { return (size_t)2 * wgs * kP * kSvcOutDwords * sizeof(uint32_t); }
 void launch_optimize_service(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int wgs,
                              hipStream_t st) {
-    hipLaunchKernelGGL(optimize_service_kernel, dim3(wgs), dim3(128), 0, st, sc, o, b, workspace);
+    hipLaunchKernelGGL(optimize_service_kernel, dim3(wgs), dim3(128), lds_bytes(1), st, sc, o, b, workspace);
 }
 
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus,
                      hipStream_t st) {
     if (b.n <= 0) return;
-    // persistent two-wavefront workgroups, up to kP patches in flight per wavefront
+    // persistent workgroups, up to kP patches in flight per wavefront
     int wgs = b.n;  // up to one workgroup per patch (see `quota` in the kernel)
-    const int cap = max_workgroups(n_cus);
+    const int cap = max_workgroups(n_cus, HPMVS_WG_WAVES, HPMVS_WG_REGIONS);
     if (wgs > cap) wgs = cap;
-    hipLaunchKernelGGL(optimize_kernel, dim3(wgs), dim3(128), 0, st, sc, o, b, workspace);
+    static const bool attr_set = [] {  // more than 64 KB of dynamic LDS needs the attribute
+        return hipFuncSetAttribute((const void*)optimize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(HPMVS_WG_REGIONS)) == hipSuccess;
+    }();
+    (void)attr_set;
+    hipLaunchKernelGGL(optimize_kernel, dim3(wgs), dim3(64 * HPMVS_WG_WAVES), lds_bytes(HPMVS_WG_REGIONS), st, sc, o, b, workspace);
 }
 
 }  // namespace hpmvs

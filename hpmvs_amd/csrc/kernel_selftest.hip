@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(64) selftest_kernel(int n, const int* kind, co
     const bool active = lane < BQ_P && prob < n;
     Bobyqa3 B;
     B.slot = lane < BQ_P ? lane : 0;
+    B.slot_i = B.slot;
     if (lane < BQ_P) st_rescue_calls[lane] = 0;
     int st = BQ_DONE, k = 0, nt = 0;
     double p[ST_PARAMS];
