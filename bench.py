@@ -266,6 +266,11 @@ def main():
     alg_bytes = 588.0 * float(ngrabs.sum()) + 12.0 * float(nimg_out[ok].sum()) + 2.0 * float((36 + 4 * max_images) * n_seeds)
     achieved = alg_bytes / (last_ms * 1e-3) / 1e9
 
+    # which build of the kernel the library picked for this batch size (kernel_launch.hip: 58 slots per wavefront from
+    # 1600 patches per CU upwards, unless HPMVS_SLOTS forces one)
+    n_cus_dev = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    forced = os.environ.get("HPMVS_SLOTS", "")
+    kernel_name = "optimize_kernel_big" if (forced == "58" or (forced != "29" and n_seeds >= 1600 * n_cus_dev)) else "optimize_kernel"
     out = {
         "metric": "refined_patches_per_sec",
         "value": n_job * args.steps / elapsed,
@@ -290,7 +295,8 @@ def main():
         "mean_grabs_per_patch": float(ngrabs.mean()),
         "scene_bytes_hbm": int(gpu_scene.bytes()),
         "scene_setup_s": t_scene,
-        "roofline": {"bound": "hbm", "kernel": "optimize_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": kernel_name, "slots_per_wavefront": 58 if kernel_name.endswith("_big") else 29,
+                     "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel_ms": last_ms, "kernel_ms_last_launch_library_events": lib_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,

@@ -58,6 +58,15 @@
 #ifndef HPMVS_WG_REGIONS
 #define HPMVS_WG_REGIONS 4
 #endif
+// This file is compiled twice (kernel_optimize_big.hip includes it with HPMVS_VARIANT_BIG, 58 slots per wavefront and 2
+// regions): the externally visible names of the second copy carry a suffix, and it has no open-batch kernel.
+#ifdef HPMVS_VARIANT_BIG
+#define HPMVS_V(name) name##_big
+#define HPMVS_VK(name) name##_big
+#else
+#define HPMVS_VK(name) name  /* the standard kernel keeps its name (profiles, rocprof summaries) */
+#define HPMVS_V(name) name##_std
+#endif
 extern __shared__ uint4 hpmvs_dyn[];
 #define bq_lds_d ((double*)hpmvs_dyn)
 #define bq_lds_i ((int*)((char*)hpmvs_dyn + HPMVS_STATE_ND * 8 * BQ_P))
@@ -591,12 +600,14 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
 #endif
 }
 
-__global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) optimize_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
+__global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) HPMVS_VK(optimize_kernel)(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
     optimize_body<false, HPMVS_WG_WAVES, HPMVS_WG_REGIONS>(sc, o, b, queue);
 }
+#ifndef HPMVS_VARIANT_BIG
 __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_service_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
     optimize_body<true, 2, 1>(sc, o, b, queue);
 }
+#endif
 
 static size_t lds_bytes(int regions) { return (size_t)regions * HPMVS_REGION_16 * 16 + (size_t)(regions + 1) * sizeof(int); }
 
@@ -612,12 +623,13 @@ static int max_workgroups(int n_cus, int waves, int regions) {
     return n_cus * per_cu;
 }
 
-size_t optimize_workspace_bytes(int n_cus) {
+size_t HPMVS_V(optimize_workspace_bytes)(int n_cus) {
     // counter block + per wavefront: kP image-list rows and one parking buffer for the optimiser states
     const size_t waves = (size_t)HPMVS_WG_WAVES * max_workgroups(n_cus, HPMVS_WG_WAVES, HPMVS_WG_REGIONS);
     return kCounterBytes + waves * kP * kRow * sizeof(uint16_t) + waves * (size_t)kPark16 * 16;
 }
 
+#ifndef HPMVS_VARIANT_BIG
 // open batch (b.svc_ctrl set): a fixed grid of `wgs` two-wavefront workgroups (one per CU leaves room for batch launches beside it)
 size_t optimize_workspace_bytes_for(int wgs) {
     return kCounterBytes + (size_t)2 * wgs * kP * kRow * sizeof(uint16_t) + (size_t)2 * wgs * (size_t)kPark16 * 16;
@@ -627,8 +639,9 @@ void launch_optimize_service(const DevScene& sc, const DevOptions& o, const DevB
                              hipStream_t st) {
     hipLaunchKernelGGL(optimize_service_kernel, dim3(wgs), dim3(128), lds_bytes(1), st, sc, o, b, workspace);
 }
+#endif
 
-void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus,
+void HPMVS_V(launch_optimize)(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus,
                      hipStream_t st) {
     if (b.n <= 0) return;
     // persistent workgroups, up to kP patches in flight per wavefront
@@ -636,10 +649,10 @@ void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b,
     const int cap = max_workgroups(n_cus, HPMVS_WG_WAVES, HPMVS_WG_REGIONS);
     if (wgs > cap) wgs = cap;
     static const bool attr_set = [] {  // more than 64 KB of dynamic LDS needs the attribute
-        return hipFuncSetAttribute((const void*)optimize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(HPMVS_WG_REGIONS)) == hipSuccess;
+        return hipFuncSetAttribute((const void*)HPMVS_VK(optimize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(HPMVS_WG_REGIONS)) == hipSuccess;
     }();
     (void)attr_set;
-    hipLaunchKernelGGL(optimize_kernel, dim3(wgs), dim3(64 * HPMVS_WG_WAVES), lds_bytes(HPMVS_WG_REGIONS), st, sc, o, b, workspace);
+    hipLaunchKernelGGL(HPMVS_VK(optimize_kernel), dim3(wgs), dim3(64 * HPMVS_WG_WAVES), lds_bytes(HPMVS_WG_REGIONS), st, sc, o, b, workspace);
 }
 
 }  // namespace hpmvs
