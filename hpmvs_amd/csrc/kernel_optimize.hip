@@ -2,27 +2,26 @@
 //
 // Mapping (MI355X-first, not a translation of the reference's one-thread-per-patch OpenMP loop):
 //
-//   * A persistent grid of single-wavefront workgroups (8 per CU, bounded by LDS) pulls patches from a
-//     global work queue.
-//   * Lanes 0..kP-1 of a wave each own one patch ("slot") and run that patch's control logic as
-//     plain SIMT code: the optimize() pipeline of the reference
-//     (src/hpmvs/PatchOptimizer.cpp:48-103: addImages / filterImagesNCC / sortImages /
-//     assureImageAngles / optimizePatch / ... / setRefImage) and the BOBYQA state machine
-//     (bobyqa3.hpp).  This is "phase A"; it ends when the lane needs photometric data.
-//   * Photometric work is done by the WHOLE WAVE for all posted requests at once ("phase B",
-//     wave_eval_rows in photometric.hpp): the (request, image) pairs become jobs, one lane each
-//     prepares its image; then nine 7-lane groups (one lane per window ROW) each serve one request,
-//     grab by grab, forming the reference's sequential float32 sums as DPP chains through the
-//     group's lanes.  No LDS, no barriers; the results go back to the requesting lanes.
-//
-//   Patches finish at different times (40-1000 evaluations); a finished lane immediately pulls the
-//   next patch from the queue, so slots stay busy until the queue drains.
-//
-//   The per-patch optimiser state (177 float64 + 13 int32) and image lists (uint16 ids, padded
-//   rows) live in LDS as [index][slot], so the kP lanes touch consecutive words and none of it goes
-//   through scratch / HBM.  (A first version kept the state in per-lane scratch for 64 patches per
-//   wave: PMC showed 2.1 G scratch/flat instructions and 157 GB of HBM traffic per 1e5-patch launch
-//   against 13 GB of algorithmic image bytes -- profiles/r01a_scratch_state.)
+//   * A persistent grid -- one workgroup of 8 wavefronts per CU -- pulls patches from a global work queue.
+//   * Lanes 0..kP-1 of a wavefront each own one patch ("slot") and run that patch's control logic as a small
+//     per-lane stage machine: the optimize() pipeline of the reference (src/hpmvs/PatchOptimizer.cpp:48-103:
+//     addImages / filterImagesNCC / sortImages / assureImageAngles / optimizePatch / ... / setRefImage).
+//     Whenever a lane needs something expensive it posts an op and stops; the wavefront serves the posted ops
+//     cooperatively, 64 lanes wide:
+//       - list services (pipeline.hpp): the image-list passes, one request at a time;
+//       - optimiser service: bq_start / bq_step (the BOBYQA state machine, bobyqa3.hpp) for all lanes that have an
+//         objective value to consume, with the patches' optimiser states in an LDS region taken from the CU's pool
+//         (LDS TIME-SHARING below);
+//       - photometric service ("phase B", wave_eval_rows in photometric.hpp): the (request, image) pairs become jobs,
+//         one lane each prepares its image; then nine 7-lane groups (one lane per window ROW) each serve one request,
+//         grab by grab, forming the reference's sequential float32 sums as DPP chains through the group's lanes.
+//         No LDS, no barriers; the results go back to the requesting lanes.
+//   * Patches finish at different times (40-1000 evaluations); a finished lane immediately pulls the next patch
+//     from the queue, so slots stay busy until the queue drains.
+//   * The image lists (uint16 ids, one 128-byte row per slot) and the parked optimiser states live in the launch
+//     workspace (global memory, L2 resident); nothing per-patch goes through scratch memory.
+//   * The file is compiled twice: 29 slots per wavefront and four state regions per CU (this file), and 58 slots / two
+//     regions for batches that fill the machine many times over (kernel_optimize_big.hip; kernel_launch.hip chooses).
 #include <hip/hip_runtime.h>
 
 // optimiser state of the kP patches a wavefront owns lives in LDS while the wavefront is in phase A (bobyqa3.hpp)
@@ -32,15 +31,14 @@
 #ifndef BQ_P
 #define BQ_P 29
 #endif
-// LDS TIME-SHARING.  The float64 optimiser blocks of phase A cost about the same per round whether 13 or 29 lanes
-// run them (measured: 146 k cycles at 14 lanes, 175 k at 28), so patches per wavefront is THE lever -- and the
-// 160 KB of LDS per CU, at 1364 B of optimiser state per patch, is what bounds it.  But a wavefront needs its
-// optimiser state only in phase A; in phase B (the photometric requests, no LDS) it is dead weight.  So a
-// workgroup is TWO wavefronts that share ONE state region of 29 slots (39.6 KB, four workgroups per CU): the
-// wavefront that enters phase A takes the region (LDS lock), pages its 29 states in from a per-wavefront
-// parking buffer in global memory (40 KB, coalesced 16-byte accesses, ~1 % of a round), runs phase A 29 lanes
-// wide, pages out and releases; its partner does the same while the first one is in phase B.  Twice the
-// lanes per optimiser block at the same occupancy (8 wavefronts per CU).
+// LDS TIME-SHARING.  The float64 optimiser blocks cost about the same per call whether 13, 29 or 58 lanes run them
+// (measured per call: 146 k cycles at 14 lanes, 175 k at 28 before the blocks were rewritten; 109 k at 28 and 123 k at
+// 58 now), so patches per wavefront is THE lever -- and the 160 KB of LDS per CU, at 1364 B of optimiser state per
+// patch, is what bounds it.  But a wavefront needs its optimiser state only inside the optimiser service; during
+// the photometric service (no LDS) it is dead weight.  So the 8 wavefronts of a CU share a POOL of state regions
+// (four of 29 slots, or two of 58): the wavefront that enters the optimiser service takes a free region (LDS
+// compare-and-swap locks), pages its states in from its parking buffer in global memory with LDS-DMA, runs bq_step
+// kP lanes wide, pages out and releases.  Several times the lanes per optimiser block at the same occupancy.
 #define BQ_SLOTS BQ_P
 #define HPMVS_STATE_ND 164
 #define HPMVS_STATE_NI 13
