@@ -89,6 +89,7 @@ struct hpmvs_scene {
 };
 
 static int service_quiesce(const hpmvs_scene* s);
+static void service_close_all(const hpmvs_scene* s);
 static void service_free(hpmvs_scene* s);
 
 // Workspace hand-out (call with s->mu held).  Before a workspace is reused the launch that used it last must
@@ -483,6 +484,11 @@ DevScene dev_scene(const hpmvs_scene* s) {
 // brackets it with the scene's event pair.
 static int enqueue_refinement(const hpmvs_scene* s, const DevOptions& d, const DevBatch& batch, hipStream_t st) {
     int rc;
+    // A batch launch needs whole CUs (one workgroup takes a CU's LDS), an open batch holds a quarter of every CU for as
+    // long as single-patch callers keep it open -- and its long-running kernel may sit in the very hardware queue this
+    // launch's packets go to.  So the open batches end first: closed (their published patches are still finished, a few
+    // milliseconds) and drained.  Callers that come later start a new one, which queues behind this launch (service_open).
+    if ((rc = service_quiesce(s))) return rc;
     {
         int32_t* q;
         int slot;
@@ -692,6 +698,11 @@ static int service_wait_drained(hpmvs_scene::Service& S) {
     }
     return HPMVS_OK;
 }
+static void service_close_all(const hpmvs_scene* s) {
+    std::lock_guard<std::mutex> lk(s->svc_mu);
+    for (int k = 0; k < 2; k++)
+        if (s->svc[k]) service_close(*s->svc[k]);
+}
 // closes and drains every open batch of the scene (before anything that synchronises the whole device)
 static int service_quiesce(const hpmvs_scene* s) {
     std::lock_guard<std::mutex> lk(s->svc_mu);
@@ -703,7 +714,7 @@ static int service_quiesce(const hpmvs_scene* s) {
         }
     return HPMVS_OK;
 }
-static int service_open(const hpmvs_scene* s, hpmvs_scene::Service& S, const hpmvs_options* o) {  // svc_mu held
+static int service_open(const hpmvs_scene* s, hpmvs_scene::Service& S, const hpmvs_options* o) {  // s->mu and svc_mu held
     using Service = hpmvs_scene::Service;
     int rc = service_wait_drained(S);
     if (rc) return rc;
@@ -743,6 +754,10 @@ static int service_open(const hpmvs_scene* s, hpmvs_scene::Service& S, const hpm
     D.svc_ctrl = (const int32_t*)S.ctrl; D.svc_done = (int32_t*)S.done; D.svc_lanes = Service::kLanes;
     if (const char* e = getenv("HPMVS_SERVICE_LANES")) D.svc_lanes = atoi(e) > 0 ? atoi(e) : D.svc_lanes;  // (experiments)
     HIPCHK(hipMemsetAsync(S.ws, 0, kQueueSlotBytes, S.st));
+    // behind every batch launch enqueued so far (they need whole CUs and must not find this launch in their way; launches
+    // enqueued later end it: enqueue_refinement)
+    for (int k = 0; k < kQueueSlots; k++)
+        if (s->slot_used[k]) HIPCHK(hipStreamWaitEvent(S.st, s->slot_done[k], 0));
     launch_optimize_service(dev_scene(s), make_dev_options(o), D, S.ws, S.wgs, S.st);
     HIPCHK(hipGetLastError());
     S.open = true; S.running = true;
@@ -775,25 +790,38 @@ static int optimize_through_service(const hpmvs_scene* s, const hpmvs_options* o
     const auto t_in = std::chrono::steady_clock::now();
     Service* S = nullptr;
     int k0 = 0;
+    auto usable = [&](const Service* cur) {
+        return cur && cur->open && cur->published + n <= Service::kCap && memcmp(&cur->opts, o, sizeof(*o)) == 0;
+    };
+    for (;;) {
+        {
+            // the critical section is a few microseconds; a contended futex hand-over costs far more than that (256
+            // callers: ~1 ms per submission in the convoy), so try for a moment before queueing up
+            bool got = false;
+            for (int spin = 0; spin < 400 && !(got = s->svc_mu.try_lock()); spin++) __builtin_ia32_pause();
+            if (!got) s->svc_mu.lock();
+        }
+        if (usable(s->svc[0] ? s->svc[s->svc_cur] : nullptr)) break;  // (svc_mu stays locked)
+        s->svc_mu.unlock();
+        // No open batch that takes this patch: start one -- under the scene lock first (lock order: mu, then svc_mu), so
+        // that it is ordered against batch launches: one enqueued before waits on the stream, one enqueued after ends it.
+        std::lock_guard<std::mutex> l1(s->mu);
+        std::lock_guard<std::mutex> l2(s->svc_mu);
+        if (!s->svc[0]) { s->svc[0] = new Service(); s->svc[1] = new Service(); }
+        Service* cur = s->svc[s->svc_cur];
+        if (usable(cur)) continue;  // somebody else did meanwhile
+        service_close(*cur);
+        s->svc_cur ^= 1;
+        cur = s->svc[s->svc_cur];
+        service_close(*cur);  // (can only be open if the options flipped twice)
+        const int rc = service_open(s, *cur, o);
+        if (rc) return rc;
+    }
     {
-        // the critical section is a few microseconds; a contended futex hand-over costs far more than that (256 callers:
-        // ~1 ms per submission in the convoy), so try for a moment before queueing up
-        bool got = false;
-        for (int spin = 0; spin < 400 && !(got = s->svc_mu.try_lock()); spin++) __builtin_ia32_pause();
-        if (!got) s->svc_mu.lock();
         std::lock_guard<std::mutex> lk(s->svc_mu, std::adopt_lock);
         const auto t_held = std::chrono::steady_clock::now();
         struct Hold { bool on; std::chrono::steady_clock::time_point t0; ~Hold() { if (on) g_svc_ns_hold += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } } hold{stats, t_held};
-        if (!s->svc[0]) { s->svc[0] = new Service(); s->svc[1] = new Service(); }
         Service* cur = s->svc[s->svc_cur];
-        if (!cur->open || cur->published + n > Service::kCap || memcmp(&cur->opts, o, sizeof(*o)) != 0) {
-            service_close(*cur);
-            s->svc_cur ^= 1;
-            cur = s->svc[s->svc_cur];
-            service_close(*cur);  // (can only be open if the options flipped twice)
-            const int rc = service_open(s, *cur, o);
-            if (rc) return rc;
-        }
         S = cur;
         k0 = S->published;
         for (int i = 0; i < n; i++) {

@@ -371,3 +371,51 @@ np.savez(sys.argv[1], ok=b.ok, center=b.center, normal=b.normal, n_images=b.n_im
     n = len(tiny_seeds.scale)
     assert np.array_equal(outs["58"]["ok"][:n], b.ok) and np.array_equal(outs["58"]["center"][:n], b.center)
     assert np.array_equal(outs["58"]["nevals"][:n], b.nevals) and np.array_equal(outs["58"]["x"][:n], b.x)
+
+
+def test_batch_launch_while_single_patch_callers_keep_an_open_batch_busy(tiny_seeds, gpu_scene):
+    """A batch launch takes whole CUs (its workgroups use a CU's LDS), the open batch behind single-patch callers holds
+    a quarter of every CU for as long as callers keep coming.  The batch launch tells the open batch to end instead of
+    waiting for the callers to pause: it completes promptly while 16 threads call optimize-of-one in a loop, both
+    give the results of an undisturbed run, and the callers carry on afterwards."""
+    import threading, time
+    from hpmvs_amd import api
+    n = len(tiny_seeds.scale)
+    ref = api.Batch.from_seeds(tiny_seeds, np.arange(n))
+    api.optimize_batch(gpu_scene, ref)
+    stop = threading.Event()
+    errors, calls = [], [0] * 16
+
+    def caller(k):
+        i = 0
+        try:
+            while not stop.is_set():
+                j = (k * 7 + i) % n
+                b = api.Batch.from_seeds(tiny_seeds, np.array([j]))
+                api.optimize_batch(gpu_scene, b)
+                if b.ok[0] != ref.ok[j] or (b.ok[0] and not np.array_equal(b.center[0], ref.center[j])):
+                    errors.append((k, j))
+                i += 1
+                calls[k] = i
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=caller, args=(k,)) for k in range(16)]
+    for t in threads:
+        t.start()
+    time.sleep(0.3)
+    before = sum(calls)
+    big = api.Batch.from_seeds(tiny_seeds, np.tile(np.arange(n), 100))
+    t0 = time.time()
+    api.optimize_batch(gpu_scene, big)
+    dt = time.time() - t0
+    time.sleep(0.3)
+    after = sum(calls)
+    stop.set()
+    for t in threads:
+        t.join(timeout=60)
+    assert not errors, errors[:3]
+    assert dt < 20.0, dt
+    assert before > 0 and after > before, (before, after)
+    assert np.array_equal(big.ok.reshape(100, n), np.tile(ref.ok, (100, 1)))
+    assert np.array_equal(big.center.reshape(100, n, 4)[37], ref.center)
