@@ -7,6 +7,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -29,3 +30,62 @@ def test_forced_dist_round_on_one_gpu():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_c3_forced_dist_n1.json"), "w") as fh:
         fh.write(json.dumps(line) + "\n")
+
+
+def test_c_and_python_record_codecs_agree_including_rejection_codes():
+    """the 192-byte record has two implementations -- the C ABI's kernels (hpmvs_pack_records /
+    hpmvs_unpack_records) and hpmvs_amd.distributed.  Packed by one and unpacked by the other, in both directions,
+    with a NEGATIVE image count (seed_init's rejection codes travel as -k), an empty list and a full 64-id list."""
+    import ctypes as C
+    import torch
+    from hpmvs_amd import api
+    from hpmvs_amd import distributed as dd
+    L = api.lib()
+    dev = torch.device("cuda", 0)
+    n, m = 6, 64
+    rng = np.random.default_rng(7)
+    nim = np.array([-3, 64, 0, 5, -11, 1], np.int32)
+    imgs = np.full((n, m), -1, np.int32)
+    for k in range(n):
+        if nim[k] > 0:
+            imgs[k, :nim[k]] = rng.integers(0, 65535, nim[k])
+    host = dict(center=rng.random((n, 4), np.float32), normal=rng.random((n, 4), np.float32), scale=rng.random(n, np.float32),
+                n_images=nim, images=imgs, ok=np.array([0, 1, 0, 1, 0, 1], np.uint8), color=rng.random((n, 3), np.float32),
+                ncc=np.zeros(n, np.float32), fmin=rng.random(n), x=np.zeros((n, 3)), result=np.zeros(n, np.int32),
+                nevals=np.zeros(n, np.int32), stage=np.zeros(n, np.int32), ngrabs=np.zeros(n, np.int32))
+    t = {k: torch.from_numpy(v).to(dev) for k, v in host.items()}
+
+    def c_batch(tt):
+        b = api.PatchBatch()
+        b.n, b.max_images = n, m
+        for k in host:
+            setattr(b, k, tt[k].data_ptr())
+        return b
+
+    # C pack -> Python unpack
+    rec = torch.empty((n, dd.RECORD_BYTES), dtype=torch.uint8, device=dev)
+    b = c_batch(t)
+    assert L.hpmvs_pack_records(C.byref(b), C.c_void_p(rec.data_ptr()), None) == 0, L.hpmvs_last_error()
+    torch.cuda.synchronize()
+    u = dd.unpack_records(rec.cpu())
+    assert np.array_equal(u["n_images"], nim) and np.array_equal(u["ok"], host["ok"].astype(bool))
+    live = np.arange(m)[None, :] < np.clip(nim, 0, None)[:, None]
+    assert np.array_equal(u["images"][live], imgs[live]) and np.all(u["images"][~live] == -1)
+    assert np.array_equal(u["center"], host["center"]) and np.array_equal(u["fmin"], host["fmin"])
+    # the Python packer writes the same bytes
+    tp = torch.from_numpy
+    ref = dd.pack_records(tp(host["center"]), tp(host["normal"]), tp(host["color"]), tp(host["scale"]), tp(host["fmin"]),
+                          tp(host["ok"]), tp(nim), tp(imgs))
+    assert torch.equal(ref, rec.cpu())
+    # Python pack -> C unpack
+    out = {k: torch.zeros_like(v) for k, v in t.items()}
+    out["images"].fill_(-7)
+    ob = c_batch(out)
+    rec2 = ref.to(dev)
+    assert L.hpmvs_unpack_records(C.c_void_p(rec2.data_ptr()), n, C.byref(ob), None) == 0, L.hpmvs_last_error()
+    torch.cuda.synchronize()
+    assert np.array_equal(out["n_images"].cpu().numpy(), nim)
+    assert np.array_equal(out["ok"].cpu().numpy(), host["ok"])
+    got = out["images"].cpu().numpy()
+    assert np.array_equal(got[live], imgs[live]) and np.all(got[~live] == -1)
+    assert np.array_equal(out["center"].cpu().numpy(), host["center"])
