@@ -76,7 +76,7 @@ struct hpmvs_scene {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t slot_done[kQueueSlots] = {};   // recorded behind the last launch that used workspace k
     mutable bool slot_used[kQueueSlots] = {};
-    mutable std::mutex mu;
+    mutable std::recursive_mutex mu;  // (recursive: a host-staged call holds it from its first allocation to its last free, see Exclusive)
     mutable bool timed = false;
     // Small host-pointer batches (the unchanged callers' optimize() = batch of 1, and what a combiner makes of
     // concurrent callers) are staged through persistent blocks: pinned host + device memory and a stream per
@@ -376,11 +376,28 @@ int hpmvs_build_pyramid(int device, const uint8_t* src, int w, int h, uint8_t* d
 
 namespace {
 
+// hipMalloc / hipFree (and friends) wait for the device to be idle -- which it never is while single-patch callers keep an
+// open batch running (a second one starts while the first drains).  Whatever allocates or frees while a scene is in use
+// does it in an Exclusive scope: the scene lock (nobody can start an open batch meanwhile, service_open needs it) with
+// the open batches ended and drained.
+struct Exclusive {
+    const hpmvs_scene* s;
+    explicit Exclusive(const hpmvs_scene* s_) : s(s_) { if (s) { s->mu.lock(); (void)service_quiesce(s); } }
+    ~Exclusive() { if (s) s->mu.unlock(); }
+    Exclusive(const Exclusive&) = delete;
+    Exclusive& operator=(const Exclusive&) = delete;
+};
+
 struct Staged {
     DevBatch d;
     std::vector<void*> tmp;
     bool staged = false;
-    ~Staged() { for (void* p : tmp) hipFree(p); }
+    const hpmvs_scene* scene = nullptr;  // set by calls against a scene: the buffers are freed in an Exclusive scope
+    ~Staged() {
+        if (tmp.empty()) return;
+        Exclusive ex(scene);
+        for (void* p : tmp) hipFree(p);
+    }
 };
 
 template <typename T>
@@ -805,7 +822,7 @@ static int optimize_through_service(const hpmvs_scene* s, const hpmvs_options* o
         s->svc_mu.unlock();
         // No open batch that takes this patch: start one -- under the scene lock first (lock order: mu, then svc_mu), so
         // that it is ordered against batch launches: one enqueued before waits on the stream, one enqueued after ends it.
-        std::lock_guard<std::mutex> l1(s->mu);
+        std::lock_guard<std::recursive_mutex> l1(s->mu);
         std::lock_guard<std::mutex> l2(s->svc_mu);
         if (!s->svc[0]) { s->svc[0] = new Service(); s->svc[1] = new Service(); }
         Service* cur = s->svc[s->svc_cur];
@@ -911,6 +928,7 @@ static int optimize_small_host_batch(const hpmvs_scene* s, const hpmvs_options* 
     if (!e.st || !e.dev || !e.host) {
         // all three or nothing: a failed allocation must not leave a half-initialised entry behind
         const PoolLayout cap = pool_layout((size_t)hpmvs_scene::kStageCapPatches, (size_t)HPMVS_MAX_IMAGES);
+        Exclusive ex(s);  // (allocations wait for an idle device)
         hipStream_t st = e.st;
         char *dv = nullptr, *hv = nullptr;
         bool good = st || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
@@ -942,7 +960,7 @@ static int optimize_small_host_batch(const hpmvs_scene* s, const hpmvs_options* 
     const DevOptions dopt = make_dev_options(o);
     int rc;
     {
-        std::lock_guard<std::mutex> lk(s->mu);
+        std::lock_guard<std::recursive_mutex> lk(s->mu);
         if ((rc = enqueue_refinement(s, dopt, D, e.st))) return rc;
     }
     HIPCHK(hipMemcpyAsync(h, e.dev, L.total, hipMemcpyDeviceToHost, e.st));  // inputs come back refined in place
@@ -974,12 +992,14 @@ int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_pat
     if (!on_device && !stream && b->n <= hpmvs_scene::kStageCapPatches) return optimize_small_host_batch(s, o, b);
     hipStream_t st = (hipStream_t)stream;
     Staged sg;
+    sg.scene = s;
+    Exclusive ex(s);  // allocations, the launch and the copies of a host-staged call (see Exclusive)
     rc = stage_batch(sg, b, on_device != 0, true);
     if (rc) return rc;
     const DevOptions d = make_dev_options(o);
     {
         {
-            std::lock_guard<std::mutex> lk(s->mu);  // workspace hand-out + the scene's single event pair
+            std::lock_guard<std::recursive_mutex> lk(s->mu);  // workspace hand-out + the scene's single event pair
             if ((rc = enqueue_refinement(s, d, sg.d, st))) return rc;
         }
         if (!on_device) {
@@ -1024,6 +1044,8 @@ int hpmvs_init_patches_batch(const hpmvs_scene* s, const hpmvs_options* o, int s
     HIPCHK(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     Staged sg;
+    sg.scene = s;
+    Exclusive ex(s);  // allocations, the launch and the copies of a host-staged call (see Exclusive)
     rc = stage_batch(sg, b, on_device != 0, true, /*copy_inputs=*/false);
     if (rc) return rc;
     const double* dxyz = xyz;
@@ -1040,7 +1062,7 @@ int hpmvs_init_patches_batch(const hpmvs_scene* s, const hpmvs_options* o, int s
     const DevOptions d = make_dev_options(o);
     {
         {
-            std::lock_guard<std::mutex> lk(s->mu);
+            std::lock_guard<std::recursive_mutex> lk(s->mu);
             launch_seed_init(dev_scene(s), d, start_level, n_points, dxyz, doff, dimg, sg.d, st);
             HIPCHK(hipGetLastError());
             if ((rc = enqueue_refinement(s, d, sg.d, st))) return rc;
@@ -1100,7 +1122,7 @@ int hpmvs_expand_batch(const hpmvs_scene* s, const hpmvs_options* o, int mode, c
     }
     const DevOptions d = make_dev_options(o);
     {
-        std::lock_guard<std::mutex> lk(s->mu);
+        std::lock_guard<std::recursive_mutex> lk(s->mu);
         launch_expand_init(dev_scene(s), mode, parents->n, sp.d, dcc, dcw, dskip, sg.d, st);
         HIPCHK(hipGetLastError());
         if ((rc = enqueue_refinement(s, d, sg.d, st))) return rc;
@@ -1128,6 +1150,8 @@ int hpmvs_objective_batch(const hpmvs_scene* s, const hpmvs_options* o, const hp
     HIPCHK(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     Staged sg;
+    sg.scene = s;
+    Exclusive ex(s);  // allocations, the launch and the copies of a host-staged call (see Exclusive)
     rc = stage_batch(sg, b, on_device != 0, false);
     if (rc) return rc;
     const DevOptions d = make_dev_options(o);
@@ -1159,6 +1183,8 @@ int hpmvs_inccs_batch(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_
     HIPCHK(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     Staged sg;
+    sg.scene = s;
+    Exclusive ex(s);  // allocations, the launch and the copies of a host-staged call (see Exclusive)
     rc = stage_batch(sg, b, on_device != 0, false);
     if (rc) return rc;
     const DevOptions d = make_dev_options(o);
@@ -1180,7 +1206,7 @@ int hpmvs_inccs_batch(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_
 int hpmvs_scene_depth_reset(hpmvs_scene* s) {
     if (!s || !s->committed) return fail(HPMVS_ERR_STATE, "scene_depth_reset: scene not committed");
     HIPCHK(hipSetDevice(s->device));
-    std::lock_guard<std::mutex> lk(s->mu);
+    std::lock_guard<std::recursive_mutex> lk(s->mu);
     if (!s->depth_pool) {
         // Scene.cpp:74-80: rows = height(level) / DEPTH_SUBSAMPLE, cols = width(level) / DEPTH_SUBSAMPLE (a double 2)
         size_t total = 0;
@@ -1252,6 +1278,8 @@ int hpmvs_set_depths_batch(hpmvs_scene* s, const hpmvs_patch_batch* b, int on_de
     HIPCHK(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     Staged sg;
+    sg.scene = s;
+    Exclusive ex(s);  // allocations, the launch and the copies of a host-staged call (see Exclusive)
     if ((rc = stage_batch(sg, b, on_device != 0, false))) return rc;
     if (!on_device && b->ok) { if ((rc = stage_in(sg, sg.d.ok, b->ok, (size_t)b->n, true))) return rc; }
     launch_set_depths(dev_scene(s), s->ddepth, sg.d, st);
@@ -1268,6 +1296,8 @@ int hpmvs_depth_gates_batch(const hpmvs_scene* s, const hpmvs_patch_batch* b, fl
     HIPCHK(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     Staged sg;
+    sg.scene = s;
+    Exclusive ex(s);  // allocations, the launch and the copies of a host-staged call (see Exclusive)
     if ((rc = stage_batch(sg, b, on_device != 0, false))) return rc;
     if (on_device) {
         launch_depth_gates(dev_scene(s), s->ddepth, sg.d, margin, abs_int, n_visible, n_blocking, n_free, st);

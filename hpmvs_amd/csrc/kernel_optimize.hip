@@ -109,16 +109,28 @@ __device__ __forceinline__ void page_in(const uint4* __restrict__ park, uint4* h
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-__device__ __forceinline__ void page_out(uint4* __restrict__ park, const uint4* hpmvs_region) {
+// A REAL call: inlined into the kernel (every VGPR taken) the compiler left it one register quad, i.e. ds_read_b128,
+// s_waitcnt, global_store, 78 times in a row -- 113 cycles per KiB, 8.8 k cycles per page-out with 58 slots, all of it
+// while the region is held.  As a function it has the caller-saved registers to itself: eight reads in flight.
+__device__ __attribute__((noinline)) void page_out(uint4* __restrict__ park, int region_index) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) u4 gu4;
     const int lane = lane_id();
-#pragma unroll 13
-    for (int c = 0; c < HPMVS_REGION_KIB; c++) {
-#if HPMVS_PARK_AUX
-        { typedef unsigned int u4 __attribute__((ext_vector_type(4))); __builtin_nontemporal_store(((const u4*)hpmvs_region)[c * 64 + lane], &((u4*)park)[c * 64 + lane]); }
-#else
-        park[c * 64 + lane] = hpmvs_region[c * 64 + lane];
-#endif
+    const u4* region = (const u4*)(hpmvs_dyn + region_index * HPMVS_REGION_16);
+    gu4* out = (gu4*)(unsigned long long)park;  // (global, not flat, stores)
+    int c = 0;
+#pragma unroll
+    for (; c + 8 <= HPMVS_REGION_KIB; c += 8) {
+        const u4 v0 = region[(c + 0) * 64 + lane], v1 = region[(c + 1) * 64 + lane], v2 = region[(c + 2) * 64 + lane],
+                    v3 = region[(c + 3) * 64 + lane], v4 = region[(c + 4) * 64 + lane], v5 = region[(c + 5) * 64 + lane],
+                    v6 = region[(c + 6) * 64 + lane], v7 = region[(c + 7) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);  // all eight reads are issued before the first store waits for its data
+        out[(c + 0) * 64 + lane] = v0; out[(c + 1) * 64 + lane] = v1; out[(c + 2) * 64 + lane] = v2; out[(c + 3) * 64 + lane] = v3;
+        out[(c + 4) * 64 + lane] = v4; out[(c + 5) * 64 + lane] = v5; out[(c + 6) * 64 + lane] = v6; out[(c + 7) * 64 + lane] = v7;
+        __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (; c < HPMVS_REGION_KIB; c++) out[c * 64 + lane] = region[c * 64 + lane];
 }
 
 }  // namespace
@@ -506,7 +518,7 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
             }
             if (!solo) {  // park my states and hand the region to the partner wavefront
                 BQ_PROF_BEGIN(tpo_);
-                page_out(park, hpmvs_dyn + reg * HPMVS_REGION_16);
+                page_out(park, reg);
                 parked = true;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
