@@ -23,6 +23,7 @@
 //   * The file is compiled twice: 29 slots per wavefront and four state regions per CU (this file), and 58 slots / two
 //     regions for batches that fill the machine many times over (kernel_optimize_big.hip; kernel_launch.hip chooses).
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 // optimiser state of the kP patches a wavefront owns lives in LDS while the wavefront is in phase A (bobyqa3.hpp)
 #include "prof.h"
@@ -658,10 +659,13 @@ void HPMVS_V(launch_optimize)(const DevScene& sc, const DevOptions& o, const Dev
     int wgs = b.n;  // up to one workgroup per patch (see `quota` in the kernel)
     const int cap = max_workgroups(n_cus, HPMVS_WG_WAVES, HPMVS_WG_REGIONS);
     if (wgs > cap) wgs = cap;
-    static const bool attr_set = [] {  // more than 64 KB of dynamic LDS needs the attribute
-        return hipFuncSetAttribute((const void*)HPMVS_VK(optimize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(HPMVS_WG_REGIONS)) == hipSuccess;
-    }();
-    (void)attr_set;
+    // more than 64 KB of dynamic LDS needs the attribute -- once per device of the process
+    static std::atomic<unsigned long long> attr_done{0ull};
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !((attr_done.load(std::memory_order_relaxed) >> dev) & 1ull)) {
+        (void)hipFuncSetAttribute((const void*)HPMVS_VK(optimize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(HPMVS_WG_REGIONS));
+        attr_done.fetch_or(1ull << dev, std::memory_order_relaxed);
+    }
     hipLaunchKernelGGL(HPMVS_VK(optimize_kernel), dim3(wgs), dim3(64 * HPMVS_WG_WAVES), lds_bytes(HPMVS_WG_REGIONS), st, sc, o, b, workspace);
 }
 
