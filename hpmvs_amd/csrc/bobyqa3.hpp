@@ -409,7 +409,7 @@ BQ_HD_BLOCK void trsbox(BqRef B) {
     for (int i = 0; i < 6; i++) hq_[i] = BQA(hq, i);
     for (int i = 0; i < 7; i++) pq_[i] = BQA(pq, i);
     for (int i = 0; i < 21; i++) xpt_[i] = BQA(xpt, i);
-    int iterc = 0, nact = 0, itermax = 0, iact = 0, itcsav = 0, isav, iu;
+    int iterc = 0, nact = 0, itermax = 0, iact = 0, isav, iu;
     double delsq, qred = 0.0, crvmin = -1.0, beta = 0.0, stepsq, gredsq = 0.0, resid, ds, shs, temp, blen, stplen,
                   sdec, ggsav = 0.0, dredsq = 0.0, dredg = 0.0, sredg = 0.0, angbd = 0.0, xsav = 0.0, ssq, tempa,
                   tempb, dhs, dhd, redmax, redsav, angt = 0.0, sth, cth, rednew, rdprev = 0.0, rdnext = 0.0;
@@ -525,7 +525,6 @@ BQ_HD_BLOCK void trsbox(BqRef B) {
                     s[i] = d_[i];
                 } else s[i] = 0.0;
             }
-            itcsav = iterc;
             hess_mul_local(hq_, pq_, xpt_, s, hs);
             for (int i = 0; i < 3; i++) hred[i] = hs[i];
             st = ALT_ITER;
@@ -1370,7 +1369,6 @@ BQ_HD_BLOCK int label230(BqRef B) {
 // Runs from `label` until the next objective evaluation is needed (returns BQ_CONTINUE with
 // B.xeval set) or the run ends (BQ_DONE).
 BQ_HD_BLOCK int step_label(BqRef B, int label) {
-    double w[14];
     {
         switch (label) {
         case L20: {  // model gradient at xopt when kopt moved away from kbase (bobyqa.c:2149-2182)
@@ -1553,6 +1551,7 @@ BQ_HD int run(BqRef B, int label) {
             BQ_PROF_BEGIN(tl_);
             const int was = label;
             label = step_label(B, label);
+            (void)was;
             BQ_PROF_END(tl_, 4 + was);  // per-label timers (profiling builds only)
         }
     }

@@ -160,7 +160,7 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
     const int wv = (int)(threadIdx.x >> 6);            // which wavefront of the workgroup (W of them, R state regions)
     int* const hpmvs_lock = (int*)(hpmvs_dyn + R * HPMVS_REGION_16);  // [r]: 0 = region r free, 1 + w = held by wavefront w; [R]: bit w = wavefront w has left
     const int n_wgs = (int)gridDim.x;
-    const int gw = wv * n_wgs + (int)blockIdx.x;        // wavefront index: all first wavefronts before the second ones
+    const int gw = wv * n_wgs + (int)blockIdx.x;        // wavefront index: the first wavefronts of all workgroups, then the second ones, ...
     // this wavefront's image-list rows and parking buffer in the launch workspace (behind the counter block)
     uint16_t* lists = (uint16_t*)((char*)queue + kCounterBytes) + (size_t)gw * kP * kRow;
     uint16_t* row = &lists[(lane < kP ? lane : 0) * kRow];
@@ -169,7 +169,8 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
     // ---- per-lane slot state
     // Small batches are spread over as many workgroups as possible (a wavefront with fewer busy slots has shorter
     // rounds: one lone patch advances ~2.4x faster than one of ten), and over the FIRST wavefronts of the
-    // workgroups before any second one gets work: a lone wavefront keeps the state region and never pages.
+    // workgroups before any second one gets work: while a workgroup has no more busy wavefronts than regions, each keeps
+    // its region and never pages.
     // OPEN BATCH (b.svc_ctrl != nullptr; the service behind single-patch host callers, capi.hip): the patch arrays
     // are host memory, the host appends patches while this launch runs, and a lane that holds queue ticket i waits
     // (without blocking its wavefront) until patch i has been published.  The first wavefront of workgroup 0 (the
@@ -183,7 +184,7 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
     if (service) quota = wv == 0 ? (b.svc_lanes < kP ? b.svc_lanes : kP) : 0;  // few patches per wavefront: latency first
     if (threadIdx.x <= R) hpmvs_lock[threadIdx.x] = 0;
     __syncthreads();
-    if (quota == 0) {  // nothing to do for this wavefront: tell the partner that the region is his
+    if (quota == 0) {  // nothing to do for this wavefront: tell the others (fewer wavefronts than regions left: no more paging)
         if (lane == 0) atomicOr(&hpmvs_lock[R], 1 << wv);
         return;
     }
@@ -517,7 +518,7 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
                     }
                 }
             }
-            if (!solo) {  // park my states and hand the region to the partner wavefront
+            if (!solo) {  // park my states and give the region back to the pool
                 BQ_PROF_BEGIN(tpo_);
                 page_out(park, reg);
                 parked = true;
