@@ -68,7 +68,8 @@ struct hpmvs_scene {
     mutable size_t depth_floats = 0;
     mutable DevDepthView* ddepth = nullptr;
     mutable std::vector<DevDepthView> hdepth;
-    int32_t* dqueue = nullptr;          // kQueueSlots launch workspaces of ws_bytes each
+    mutable int32_t* dqueue[kQueueSlots] = {};  // launch workspaces of ws_bytes each: the first at commit, the others on first concurrent use
+    mutable int n_queues = 0;
     size_t ws_bytes = 0;
     mutable unsigned next_slot = 0;
     mutable int32_t* last_queue = nullptr;
@@ -76,7 +77,7 @@ struct hpmvs_scene {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t slot_done[kQueueSlots] = {};   // recorded behind the last launch that used workspace k
     mutable bool slot_used[kQueueSlots] = {};
-    mutable std::recursive_mutex mu;  // (recursive: a host-staged call holds it from its first allocation to its last free, see Exclusive)
+    mutable std::recursive_mutex mu;  // (recursive: Exclusive scopes nest with the workspace hand-out)
     mutable bool timed = false;
     // Small host-pointer batches (the unchanged callers' optimize() = batch of 1, and what a combiner makes of
     // concurrent callers) are staged through persistent blocks: pinned host + device memory and a stream per
@@ -96,9 +97,31 @@ static void service_free(hpmvs_scene* s);
 // have finished: more than kQueueSlots launches in flight against one scene (e.g. 256 OpenMP threads each
 // calling optimize()) simply queue up here instead of sharing a counter / image-list rows.
 static int acquire_workspace(const hpmvs_scene* s, int32_t** q, int* slot) {
-    const int k = (int)(s->next_slot++ % kQueueSlots);
-    if (s->slot_used[k]) HIPCHK(hipEventSynchronize(s->slot_done[k]));
-    *q = (int32_t*)((char*)s->dqueue + (size_t)k * s->ws_bytes);
+    // A workspace whose last launch has finished is taken again; only when every allocated one is still in flight does
+    // the scene grow another (179 MB each: a scene driven by one scheduler thread never needs more than one or two),
+    // and with all kQueueSlots in flight the caller waits for the oldest.
+    int k = -1;
+    for (int i = 0; i < s->n_queues && k < 0; i++) {
+        const int c = (int)((s->next_slot + i) % (unsigned)s->n_queues);
+        if (!s->slot_used[c]) k = c;
+        else if (hipEventQuery(s->slot_done[c]) == hipSuccess) k = c;
+        else (void)hipGetLastError();  // hipErrorNotReady is not an error here
+    }
+    if (k < 0 && s->n_queues < kQueueSlots) {
+        int32_t* w = nullptr;
+        HIPCHK(hipMalloc((void**)&w, s->ws_bytes));
+        if (hipMemset(w, 0, s->ws_bytes) != hipSuccess) { hipFree(w); return fail(HPMVS_ERR_HIP, "cannot clear a launch workspace"); }
+        k = s->n_queues;
+        s->dqueue[k] = w;
+        s->n_queues++;
+        const_cast<hpmvs_scene*>(s)->bytes += s->ws_bytes;
+    }
+    if (k < 0) {
+        k = (int)(s->next_slot % kQueueSlots);
+        HIPCHK(hipEventSynchronize(s->slot_done[k]));
+    }
+    s->next_slot = (unsigned)k + 1;
+    *q = s->dqueue[k];
     *slot = k;
     s->last_queue = *q;
     return HPMVS_OK;
@@ -299,8 +322,10 @@ int hpmvs_scene_commit(hpmvs_scene* s) {
     HIPCHK(hipMemcpy(s->dcovis, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice));
     for (int k = 0; k < kQueueSlots; k++) HIPCHK(hipEventCreateWithFlags(&s->slot_done[k], hipEventDisableTiming));
     s->ws_bytes = (optimize_workspace_bytes(s->n_cus) + 255) & ~(size_t)255;
-    HIPCHK(hipMalloc((void**)&s->dqueue, kQueueSlots * s->ws_bytes));
-    HIPCHK(hipMemset(s->dqueue, 0, kQueueSlots * s->ws_bytes));
+    HIPCHK(hipMalloc((void**)&s->dqueue[0], s->ws_bytes));  // the others on first concurrent use (acquire_workspace)
+    HIPCHK(hipMemset(s->dqueue[0], 0, s->ws_bytes));
+    s->n_queues = 1;
+    s->bytes += s->ws_bytes;
     s->bytes += sizeof(DevView) * (size_t)s->n_views + sizeof(int32_t) * (off.size() + flat.size());
     s->committed = true;
     return HPMVS_OK;
@@ -316,7 +341,7 @@ int hpmvs_scene_destroy(hpmvs_scene* s) {
     if (s->dviews) hipFree(s->dviews);
     if (s->dcovis_off) hipFree(s->dcovis_off);
     if (s->dcovis) hipFree(s->dcovis);
-    if (s->dqueue) hipFree(s->dqueue);
+    for (int k = 0; k < s->n_queues; k++) if (s->dqueue[k]) hipFree(s->dqueue[k]);
     for (auto& e : s->stage) {
         if (e.st) hipStreamDestroy(e.st);
         if (e.dev) hipFree(e.dev);
@@ -379,7 +404,9 @@ namespace {
 // hipMalloc / hipFree (and friends) wait for the device to be idle -- which it never is while single-patch callers keep an
 // open batch running (a second one starts while the first drains).  Whatever allocates or frees while a scene is in use
 // does it in an Exclusive scope: the scene lock (nobody can start an open batch meanwhile, service_open needs it) with
-// the open batches ended and drained.
+// the open batches ended and drained.  A host-staged call is in such a scope twice, briefly: for its allocations and (in
+// ~Staged) for its frees; its copies, its launch and its wait run outside, so that concurrent big host batches against
+// one scene overlap.
 struct Exclusive {
     const hpmvs_scene* s;
     explicit Exclusive(const hpmvs_scene* s_) : s(s_) { if (s) { s->mu.lock(); (void)service_quiesce(s); } }
@@ -391,6 +418,8 @@ struct Exclusive {
 struct Staged {
     DevBatch d;
     std::vector<void*> tmp;
+    struct Fill { void* dst; const void* src; size_t bytes; };  // src == nullptr: zero-fill
+    std::vector<Fill> fills;  // what stage_in allocated still has to be filled: stage_flush, outside the Exclusive scope
     bool staged = false;
     const hpmvs_scene* scene = nullptr;  // set by calls against a scene: the buffers are freed in an Exclusive scope
     ~Staged() {
@@ -407,9 +436,20 @@ int stage_in(Staged& st, T*& dst, const T* host, size_t count, bool copy) {
     void* p = nullptr;
     HIPCHK(hipMalloc(&p, sizeof(T) * count));
     st.tmp.push_back(p);
-    if (copy) HIPCHK(hipMemcpy(p, host, sizeof(T) * count, hipMemcpyHostToDevice));
-    else HIPCHK(hipMemset(p, 0, sizeof(T) * count));
+    st.fills.push_back({p, copy ? (const void*)host : nullptr, sizeof(T) * count});
     dst = (T*)p;
+    return HPMVS_OK;
+}
+
+// The copies / zero-fills of everything stage_in allocated.  Separate from the allocations so that only those (and the
+// frees) run in the Exclusive scope: two threads staging big host batches against one scene overlap their copies and
+// their launches (16 workspaces), they only take turns at hipMalloc / hipFree.
+int stage_flush(Staged& st) {
+    for (const Staged::Fill& f : st.fills) {
+        if (f.src) HIPCHK(hipMemcpy(f.dst, f.src, f.bytes, hipMemcpyHostToDevice));
+        else HIPCHK(hipMemset(f.dst, 0, f.bytes));
+    }
+    st.fills.clear();
     return HPMVS_OK;
 }
 
@@ -620,6 +660,7 @@ extern "C" int hpmvs_selftest_bobyqa(int device, int n, const int32_t* kind, con
     if ((rc = stage_in(sg, dne, (const int*)nevals, N, false))) return rc;
     if ((rc = stage_in(sg, dres, (const int*)rescue_calls, N, false))) return rc;
     if (trace && (rc = stage_in(sg, dtr, (const double*)trace, 4 * N * (size_t)trace_cap, false))) return rc;
+    if ((rc = stage_flush(sg))) return rc;
     launch_selftest(n, dkind, dpar, dx0, dlb, dub, maxeval, dxf, dmin, drc, dne, dres, dtr, trace_cap, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
@@ -696,6 +737,7 @@ struct hpmvs_scene::Service {
     volatile int32_t* ctrl = nullptr;
     volatile int32_t* done = nullptr;
     int published = 0;
+    unsigned gen = 0;                       // launch generation (service_open increments it): a closer ends only the launch it published into
     std::atomic<int> outstanding{0};        // published patches whose owner has not picked up the results yet
     bool open = false, running = false;
     hpmvs_options opts;
@@ -763,6 +805,7 @@ static int service_open(const hpmvs_scene* s, hpmvs_scene::Service& S, const hpm
     memset((void*)S.ctrl, 0, 256 + sizeof(int32_t) * (size_t)Service::kCap);  // ctrl + done flags
     S.opts = *o;
     S.published = 0; S.outstanding.store(0);
+    S.gen++;
     DevBatch D;
     memset(&D, 0, sizeof(D));
     D.n = Service::kCap; D.max_images = HPMVS_MAX_IMAGES;
@@ -807,6 +850,7 @@ static int optimize_through_service(const hpmvs_scene* s, const hpmvs_options* o
     const auto t_in = std::chrono::steady_clock::now();
     Service* S = nullptr;
     int k0 = 0;
+    unsigned my_gen = 0;
     auto usable = [&](const Service* cur) {
         return cur && cur->open && cur->published + n <= Service::kCap && memcmp(&cur->opts, o, sizeof(*o)) == 0;
     };
@@ -840,6 +884,7 @@ static int optimize_through_service(const hpmvs_scene* s, const hpmvs_options* o
         struct Hold { bool on; std::chrono::steady_clock::time_point t0; ~Hold() { if (on) g_svc_ns_hold += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } } hold{stats, t_held};
         Service* cur = s->svc[s->svc_cur];
         S = cur;
+        my_gen = S->gen;
         k0 = S->published;
         for (int i = 0; i < n; i++) {
             uint32_t* rec = S->in + (size_t)(k0 + i) * kSvcInDwords;
@@ -915,7 +960,9 @@ static int optimize_through_service(const hpmvs_scene* s, const hpmvs_options* o
     }
     if (S->outstanding.fetch_sub(n, std::memory_order_acq_rel) == n) {  // I was the last one waiting
         std::lock_guard<std::mutex> lk(s->svc_mu);
-        if (S->outstanding.load() == 0) service_close(*S);  // nobody is waiting: let the launch end
+        // nobody is waiting: let the launch end -- the one I published into (the object may have been reopened since:
+        // a thread spinning in service_open goes on as soon as the count reaches zero)
+        if (S->gen == my_gen && S->outstanding.load() == 0) service_close(*S);
     }
     return rc;
 }
@@ -993,9 +1040,12 @@ int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_pat
     hipStream_t st = (hipStream_t)stream;
     Staged sg;
     sg.scene = s;
-    Exclusive ex(s);  // allocations, the launch and the copies of a host-staged call (see Exclusive)
-    rc = stage_batch(sg, b, on_device != 0, true);
+    if (!on_device) {
+        Exclusive ex(s);  // the allocations of a host-staged call (see Exclusive; ~Staged frees in one of its own)
+        rc = stage_batch(sg, b, false, true);
+    } else rc = stage_batch(sg, b, true, true);
     if (rc) return rc;
+    if ((rc = stage_flush(sg))) return rc;
     const DevOptions d = make_dev_options(o);
     {
         {
@@ -1045,20 +1095,20 @@ int hpmvs_init_patches_batch(const hpmvs_scene* s, const hpmvs_options* o, int s
     hipStream_t st = (hipStream_t)stream;
     Staged sg;
     sg.scene = s;
-    Exclusive ex(s);  // allocations, the launch and the copies of a host-staged call (see Exclusive)
-    rc = stage_batch(sg, b, on_device != 0, true, /*copy_inputs=*/false);
-    if (rc) return rc;
     const double* dxyz = xyz;
     const int32_t *doff = meas_off, *dimg = meas_img;
     const size_t n = (size_t)n_points;
     if (!on_device) {
+        Exclusive ex(s);  // the allocations of a host-staged call (see Exclusive)
+        if ((rc = stage_batch(sg, b, false, true, /*copy_inputs=*/false))) return rc;
         double* tx = nullptr; int32_t *to = nullptr, *ti = nullptr;
         const size_t nm = (size_t)meas_off[n_points];
         if ((rc = stage_in(sg, tx, xyz, 3 * n, true))) return rc;
         if ((rc = stage_in(sg, to, meas_off, n + 1, true))) return rc;
         if ((rc = stage_in(sg, ti, meas_img, nm ? nm : 1, nm != 0))) return rc;
         dxyz = tx; doff = to; dimg = ti;
-    }
+    } else if ((rc = stage_batch(sg, b, true, true, /*copy_inputs=*/false))) return rc;
+    if ((rc = stage_flush(sg))) return rc;
     const DevOptions d = make_dev_options(o);
     {
         {
@@ -1107,19 +1157,25 @@ int hpmvs_expand_batch(const hpmvs_scene* s, const hpmvs_options* o, int mode, c
     HIPCHK(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     Staged sp, sg;
-    if ((rc = stage_batch(sp, parents, on_device != 0, false))) return rc;
-    if ((rc = stage_batch(sg, out, on_device != 0, true, /*copy_inputs=*/false))) return rc;
+    sp.scene = s; sg.scene = s;  // (this entry point had been left out of the Exclusive protocol)
     const size_t n = (size_t)parents->n;
     const float *dcc = cell_center, *dcw = cell_width;
     const uint8_t* dskip = skip;
     if (!on_device) {
+        Exclusive ex(s);  // the allocations of a host-staged call (see Exclusive)
+        if ((rc = stage_batch(sp, parents, false, false))) return rc;
+        if ((rc = stage_batch(sg, out, false, true, /*copy_inputs=*/false))) return rc;
         float *tc = nullptr, *tw = nullptr;
         uint8_t* ts = nullptr;
         if ((rc = stage_in(sp, tc, cell_center, 3 * n, true))) return rc;
         if ((rc = stage_in(sp, tw, cell_width, n, true))) return rc;
         if ((rc = stage_in(sp, ts, skip, n * N, true))) return rc;
         dcc = tc; dcw = tw; dskip = ts;
+    } else {
+        if ((rc = stage_batch(sp, parents, true, false))) return rc;
+        if ((rc = stage_batch(sg, out, true, true, /*copy_inputs=*/false))) return rc;
     }
+    if ((rc = stage_flush(sp)) || (rc = stage_flush(sg))) return rc;
     const DevOptions d = make_dev_options(o);
     {
         std::lock_guard<std::recursive_mutex> lk(s->mu);
@@ -1151,21 +1207,24 @@ int hpmvs_objective_batch(const hpmvs_scene* s, const hpmvs_options* o, const hp
     hipStream_t st = (hipStream_t)stream;
     Staged sg;
     sg.scene = s;
-    Exclusive ex(s);  // allocations, the launch and the copies of a host-staged call (see Exclusive)
-    rc = stage_batch(sg, b, on_device != 0, false);
-    if (rc) return rc;
     const DevOptions d = make_dev_options(o);
     const size_t n = (size_t)b->n;
     if (on_device) {
+        if ((rc = stage_batch(sg, b, true, false))) return rc;
         launch_objective(dev_scene(s), d, sg.d, x, f_out, ngrabs_out, st);
         HIPCHK(hipGetLastError());
         return HPMVS_OK;
     }
     double *dx = nullptr, *df = nullptr;
     int32_t* dg = nullptr;
-    if ((rc = stage_in(sg, dx, x, 3 * n, true))) return rc;
-    if ((rc = stage_in(sg, df, f_out, n, false))) return rc;
-    if ((rc = stage_in(sg, dg, ngrabs_out, n, false))) return rc;
+    {
+        Exclusive ex(s);  // the allocations of a host-staged call (see Exclusive)
+        if ((rc = stage_batch(sg, b, false, false))) return rc;
+        if ((rc = stage_in(sg, dx, x, 3 * n, true))) return rc;
+        if ((rc = stage_in(sg, df, f_out, n, false))) return rc;
+        if ((rc = stage_in(sg, dg, ngrabs_out, n, false))) return rc;
+    }
+    if ((rc = stage_flush(sg))) return rc;
     launch_objective(dev_scene(s), d, sg.d, dx, df, dg, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
@@ -1184,18 +1243,21 @@ int hpmvs_inccs_batch(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_
     hipStream_t st = (hipStream_t)stream;
     Staged sg;
     sg.scene = s;
-    Exclusive ex(s);  // allocations, the launch and the copies of a host-staged call (see Exclusive)
-    rc = stage_batch(sg, b, on_device != 0, false);
-    if (rc) return rc;
     const DevOptions d = make_dev_options(o);
     const size_t n = (size_t)b->n;
     if (on_device) {
+        if ((rc = stage_batch(sg, b, true, false))) return rc;
         launch_inccs(dev_scene(s), d, sg.d, ref_idx, robust, out, st);
         HIPCHK(hipGetLastError());
         return HPMVS_OK;
     }
     float* dout = nullptr;
-    if ((rc = stage_in(sg, dout, out, n * b->max_images, false))) return rc;
+    {
+        Exclusive ex(s);  // the allocations of a host-staged call (see Exclusive)
+        if ((rc = stage_batch(sg, b, false, false))) return rc;
+        if ((rc = stage_in(sg, dout, out, n * b->max_images, false))) return rc;
+    }
+    if ((rc = stage_flush(sg))) return rc;
     launch_inccs(dev_scene(s), d, sg.d, ref_idx, robust, dout, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
@@ -1206,28 +1268,37 @@ int hpmvs_inccs_batch(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_
 int hpmvs_scene_depth_reset(hpmvs_scene* s) {
     if (!s || !s->committed) return fail(HPMVS_ERR_STATE, "scene_depth_reset: scene not committed");
     HIPCHK(hipSetDevice(s->device));
-    std::lock_guard<std::recursive_mutex> lk(s->mu);
-    if (!s->depth_pool) {
+    Exclusive ex(s);  // (the first call allocates: hipMalloc waits for an idle device, see Exclusive)
+    if (!s->depth_pool || !s->ddepth) {
         // Scene.cpp:74-80: rows = height(level) / DEPTH_SUBSAMPLE, cols = width(level) / DEPTH_SUBSAMPLE (a double 2)
         size_t total = 0;
-        s->hdepth.assign((size_t)s->n_views, DevDepthView{});
+        std::vector<DevDepthView> hd((size_t)s->n_views, DevDepthView{});
         for (int v = 0; v < s->n_views; v++)
             for (int l = 0; l < s->hviews[v].n_levels; l++) {
-                s->hdepth[v].rows[l] = (int)((double)s->hviews[v].h[l] / 2.0);
-                s->hdepth[v].cols[l] = (int)((double)s->hviews[v].w[l] / 2.0);
-                total += (size_t)s->hdepth[v].rows[l] * s->hdepth[v].cols[l];
+                hd[v].rows[l] = (int)((double)s->hviews[v].h[l] / 2.0);
+                hd[v].cols[l] = (int)((double)s->hviews[v].w[l] / 2.0);
+                total += (size_t)hd[v].rows[l] * hd[v].cols[l];
             }
         if (total == 0) return fail(HPMVS_ERR_STATE, "scene_depth_reset: empty scene");
-        HIPCHK(hipMalloc((void**)&s->depth_pool, total * sizeof(float)));
-        s->depth_floats = total;
+        // both buffers into locals; the scene sees them only when everything succeeded (a failure half way must not
+        // leave a pool without its table: the kernels test one and dereference the other)
+        float* pool = nullptr;
+        DevDepthView* table = nullptr;
+        struct Undo { float*& a; DevDepthView*& b; ~Undo() { if (a) hipFree(a); if (b) hipFree(b); } } undo{pool, table};
+        HIPCHK(hipMalloc((void**)&pool, total * sizeof(float)));
         size_t off = 0;
         for (int v = 0; v < s->n_views; v++)
             for (int l = 0; l < s->hviews[v].n_levels; l++) {
-                s->hdepth[v].d[l] = s->depth_pool + off;
-                off += (size_t)s->hdepth[v].rows[l] * s->hdepth[v].cols[l];
+                hd[v].d[l] = pool + off;
+                off += (size_t)hd[v].rows[l] * hd[v].cols[l];
             }
-        HIPCHK(hipMalloc((void**)&s->ddepth, sizeof(DevDepthView) * (size_t)s->n_views));
-        HIPCHK(hipMemcpy(s->ddepth, s->hdepth.data(), sizeof(DevDepthView) * (size_t)s->n_views, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&table, sizeof(DevDepthView) * (size_t)s->n_views));
+        HIPCHK(hipMemcpy(table, hd.data(), sizeof(DevDepthView) * (size_t)s->n_views, hipMemcpyHostToDevice));
+        if (s->depth_pool) hipFree(s->depth_pool);  // (a half-initialised scene of an older library state)
+        if (s->ddepth) hipFree(s->ddepth);
+        s->depth_pool = pool; s->ddepth = table; s->depth_floats = total; s->hdepth.swap(hd);
+        s->bytes += total * sizeof(float) + sizeof(DevDepthView) * (size_t)s->n_views;
+        pool = nullptr; table = nullptr;
     }
     launch_depth_fill(s->depth_pool, s->depth_floats, nullptr);
     HIPCHK(hipGetLastError());
@@ -1236,7 +1307,7 @@ int hpmvs_scene_depth_reset(hpmvs_scene* s) {
 }
 
 static int depth_level(const hpmvs_scene* s, int view, int level, const char* who, float** p, int* rows, int* cols) {
-    if (!s || !s->depth_pool) return fail(HPMVS_ERR_STATE, std::string(who) + ": call hpmvs_scene_depth_reset first");
+    if (!s || !s->depth_pool || !s->ddepth) return fail(HPMVS_ERR_STATE, std::string(who) + ": call hpmvs_scene_depth_reset first");
     if (view < 0 || view >= s->n_views || level < 0 || level >= s->hviews[view].n_levels)
         return fail(HPMVS_ERR_ARG, std::string(who) + ": bad view / level");
     *p = s->hdepth[view].d[level]; *rows = s->hdepth[view].rows[level]; *cols = s->hdepth[view].cols[level];
@@ -1265,7 +1336,7 @@ int hpmvs_scene_depth_get_level(const hpmvs_scene* s, int view, int level, float
 
 static int check_depth_batch(const hpmvs_scene* s, const hpmvs_patch_batch* b, const char* who) {
     if (!s || !b) return fail(HPMVS_ERR_ARG, std::string(who) + ": null scene / batch");
-    if (!s->committed || !s->depth_pool) return fail(HPMVS_ERR_STATE, std::string(who) + ": call hpmvs_scene_depth_reset first");
+    if (!s->committed || !s->depth_pool || !s->ddepth) return fail(HPMVS_ERR_STATE, std::string(who) + ": call hpmvs_scene_depth_reset first");
     if (b->n < 0 || b->max_images < 1 || b->max_images > HPMVS_MAX_IMAGES) return fail(HPMVS_ERR_ARG, std::string(who) + ": bad n/max_images");
     if (b->n > 0 && (!b->center || !b->normal || !b->scale || !b->n_images || !b->images))
         return fail(HPMVS_ERR_ARG, std::string(who) + ": batch input arrays missing");
@@ -1279,9 +1350,12 @@ int hpmvs_set_depths_batch(hpmvs_scene* s, const hpmvs_patch_batch* b, int on_de
     hipStream_t st = (hipStream_t)stream;
     Staged sg;
     sg.scene = s;
-    Exclusive ex(s);  // allocations, the launch and the copies of a host-staged call (see Exclusive)
-    if ((rc = stage_batch(sg, b, on_device != 0, false))) return rc;
-    if (!on_device && b->ok) { if ((rc = stage_in(sg, sg.d.ok, b->ok, (size_t)b->n, true))) return rc; }
+    if (!on_device) {
+        Exclusive ex(s);  // the allocations of a host-staged call (see Exclusive)
+        if ((rc = stage_batch(sg, b, false, false))) return rc;
+        if (b->ok) { if ((rc = stage_in(sg, sg.d.ok, b->ok, (size_t)b->n, true))) return rc; }
+    } else if ((rc = stage_batch(sg, b, true, false))) return rc;
+    if ((rc = stage_flush(sg))) return rc;
     launch_set_depths(dev_scene(s), s->ddepth, sg.d, st);
     HIPCHK(hipGetLastError());
     if (!on_device) HIPCHK(hipStreamSynchronize(st));
@@ -1297,18 +1371,22 @@ int hpmvs_depth_gates_batch(const hpmvs_scene* s, const hpmvs_patch_batch* b, fl
     hipStream_t st = (hipStream_t)stream;
     Staged sg;
     sg.scene = s;
-    Exclusive ex(s);  // allocations, the launch and the copies of a host-staged call (see Exclusive)
-    if ((rc = stage_batch(sg, b, on_device != 0, false))) return rc;
     if (on_device) {
+        if ((rc = stage_batch(sg, b, true, false))) return rc;
         launch_depth_gates(dev_scene(s), s->ddepth, sg.d, margin, abs_int, n_visible, n_blocking, n_free, st);
         HIPCHK(hipGetLastError());
         return HPMVS_OK;
     }
     const size_t n = (size_t)b->n;
     int32_t *dv = nullptr, *db = nullptr, *df = nullptr;
-    if ((rc = stage_in(sg, dv, n_visible, n, false))) return rc;
-    if ((rc = stage_in(sg, db, n_blocking, n, false))) return rc;
-    if ((rc = stage_in(sg, df, n_free, n, false))) return rc;
+    {
+        Exclusive ex(s);  // the allocations of a host-staged call (see Exclusive)
+        if ((rc = stage_batch(sg, b, false, false))) return rc;
+        if ((rc = stage_in(sg, dv, n_visible, n, false))) return rc;
+        if ((rc = stage_in(sg, db, n_blocking, n, false))) return rc;
+        if ((rc = stage_in(sg, df, n_free, n, false))) return rc;
+    }
+    if ((rc = stage_flush(sg))) return rc;
     launch_depth_gates(dev_scene(s), s->ddepth, sg.d, margin, abs_int, dv, db, df, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));

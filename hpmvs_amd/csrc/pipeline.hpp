@@ -147,7 +147,10 @@ __device__ __forceinline__ int coop_sort_images(const DevScene& sc, const DevOpt
         // greedy pick: the smallest weight, the earliest entry among equals
         const bool mine = (alive >> lane) & 1ull;
         const float mn = wave_min_f32(mine ? w : __int_as_float(0x7f800000));
-        const int best = __ffsll((long long)__ballot(mine && w == mn)) - 1;
+        // (weights that are all NaN -- a camera with a non-finite focal sum -- compare equal to nothing: the earliest
+        //  remaining entry then, so that every pass removes one entry and the loop ends)
+        const unsigned long long eq = __ballot(mine && w == mn);
+        const int best = __ffsll((long long)(eq ? eq : alive)) - 1;
         const int bid = bcast_i(id, best);
         if (lane == out) nid = bid;
         out++;

@@ -121,3 +121,78 @@ def test_expand_with_device_pointers_on_a_stream(tiny_scene, tiny_seeds, gpu_sce
     assert np.array_equal(ot["scale"].cpu().numpy(), want.scale)
     acc = want.ok.astype(bool)
     assert np.array_equal(ot["n_images"].cpu().numpy()[acc], want.n_images[acc])
+
+
+def test_expand_and_concurrent_host_batches_while_callers_keep_an_open_batch_busy(tiny_scene, tiny_seeds, gpu_scene):
+    """hpmvs_expand_batch takes part in the Exclusive protocol (its allocations and frees quiesce the open
+    batch), and host-staged calls hold the scene lock only around their allocations and frees: an expandBatch and two
+    big host batches issued from three threads at once, while 8 threads call optimize-of-one in a loop, all finish
+    promptly with the results of undisturbed runs."""
+    import threading, time
+    from hpmvs_amd import api
+    par = refined_parents(tiny_scene, tiny_seeds, gpu_scene)
+    n = len(tiny_seeds.scale)
+    width = (par.scale * np.float32(2.0 / 0.9)).astype(np.float32)
+    cc = np.ascontiguousarray(par.center[:, :3])
+    want_exp = api.expand_batch(gpu_scene, api.EXPAND_EXTEND, par, cc, width)
+    ref = api.Batch.from_seeds(tiny_seeds, np.arange(n))
+    api.optimize_batch(gpu_scene, ref)
+    stop = threading.Event()
+    errors, calls = [], [0] * 8
+
+    def caller(k):
+        i = 0
+        try:
+            while not stop.is_set():
+                j = (k * 11 + i) % n
+                b = api.Batch.from_seeds(tiny_seeds, np.array([j]))
+                api.optimize_batch(gpu_scene, b)
+                if b.ok[0] != ref.ok[j] or (b.ok[0] and not np.array_equal(b.center[0], ref.center[j])):
+                    errors.append(("caller", k, j))
+                i += 1
+                calls[k] = i
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    results = {}
+
+    def big(tag):
+        try:
+            b = api.Batch.from_seeds(tiny_seeds, np.tile(np.arange(n), 30))
+            api.optimize_batch(gpu_scene, b)
+            results[tag] = b
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def expand():
+        try:
+            results["exp"] = [api.expand_batch(gpu_scene, api.EXPAND_EXTEND, par, cc, width) for _ in range(3)]
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=caller, args=(k,)) for k in range(8)]
+    for t in threads:
+        t.start()
+    time.sleep(0.3)
+    before = sum(calls)
+    work = [threading.Thread(target=big, args=("a",)), threading.Thread(target=big, args=("b",)), threading.Thread(target=expand)]
+    t0 = time.time()
+    for t in work:
+        t.start()
+    for t in work:
+        t.join(timeout=120)
+    dt = time.time() - t0
+    time.sleep(0.3)
+    after = sum(calls)
+    stop.set()
+    for t in threads:
+        t.join(timeout=60)
+    assert not errors, errors[:3]
+    assert dt < 30.0, dt
+    assert before > 0 and after > before, (before, after)
+    for tag in ("a", "b"):
+        assert np.array_equal(results[tag].ok.reshape(30, n), np.tile(ref.ok, (30, 1)))
+        assert np.array_equal(results[tag].center.reshape(30, n, 4)[17], ref.center)
+    for e in results["exp"]:
+        assert np.array_equal(e.ok, want_exp.ok) and np.array_equal(e.stage, want_exp.stage)
+        assert np.array_equal(e.center, want_exp.center) and np.array_equal(e.normal, want_exp.normal)
