@@ -9,12 +9,14 @@ refinement of depth + normal against NCC over the attached views, reference-imag
 its shard of synthetic seed patches, all inputs already resident in HBM, and -- for N > 1 -- one
 RCCL all-gather of the fixed-size refined-patch records (north_star's exchange step).
 
-Default workload = the configuration BASELINE.json's metric is quoted on (configs[2], "c2"): 50
-synthetic 3840x2160 views, 1e6 seed patches per GPU.  `--scaling weak` (default): every rank refines
-its own 1e6 seeds of the replicated scene.  `--scaling strong` (configs[3]/[4], "c3"/"c4"): ONE
-batch, identical on every rank, is cut with `shard_range` (reference Scene.cpp:94-96,114: the
-OpenMP loop over one seed vector) and the refined records are all-gathered, so every rank ends the
-step holding the full refined set.
+Default workload: at N = 1 the configuration BASELINE.json's metric is quoted on (configs[2], "c2": 50
+synthetic 3840x2160 views, 1e6 seed patches); at N > 1 BASELINE configs[3] ("c3"): THE SAME batch of
+1e6 seeds, identical on every rank, cut with `shard_range` (reference Scene.cpp:94-96,114: the OpenMP
+loop over one seed vector; the round structure is main.cpp:145-181) and the refined records
+all-gathered, so every rank ends the step holding the full refined set -- `scaling: "strong"`, and
+N = 1 of that is exactly c2.  `--workload c2_50v_4k_1e6 --scaling weak` with N > 1 gives every rank
+its own 1e6 seeds instead.  The N > 1 line also carries per-rank kernel and exchange times
+(`per_rank`), so that a scaling curve can be read against the one-GPU shard timings of DESIGN section 7.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline_issue : the compute-side view of the same kernel (it is instruction-issue / latency bound, not HBM
@@ -59,7 +61,8 @@ WORKLOADS = {
     # the 256 MB MALL), the case in which image bytes really come from HBM
     "s1_50v_4k_1e6_level1": (50, 3840, 2160, 1_000_000, 1, "weak"),
 }
-DEFAULT_WORKLOAD = "c2_50v_4k_1e6"
+DEFAULT_WORKLOAD = "c2_50v_4k_1e6"              # N = 1
+DEFAULT_WORKLOAD_MULTI = "c3_50v_4k_1e6_sharded"  # N > 1: the same batch cut across the ranks (BASELINE configs[3])
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 RECORD_BYTES = dd.RECORD_BYTES  # all-gathered refined-patch record
 
@@ -104,12 +107,104 @@ def check_record_ranges(t):
         raise ValueError(f"a patch has {nmax} images but only {min(t['images'].shape[1], dd.MAX_RECORD_IMAGES)} ids can travel")
 
 
-def main():
+class Plan:
+    """What this rank refines in one step.  Pure arithmetic on (workload, scaling, patches, rank, world): covered at
+    world size 2 by tests/test_cpu_distributed.py without a GPU."""
+
+    def __init__(self, workload, scaling, patches, rank, world):
+        self.workload = workload
+        self.views, self.W, self.H, n_total, self.start_level, default_scaling = WORKLOADS[workload]
+        self.scaling = scaling or default_scaling
+        if patches > 0:
+            n_total = patches
+        self.n_total, self.rank, self.world = n_total, rank, world
+        if self.scaling == "strong":
+            # one batch, the same on every rank; rank r refines [lo, hi) of it
+            self.lo, self.hi = dd.shard_range(n_total, rank, world)
+            self.counts = [dd.shard_range(n_total, r, world)[1] - dd.shard_range(n_total, r, world)[0] for r in range(world)]
+            self.seed_value = synth.SEED
+            self.n_job = n_total
+        else:
+            self.lo, self.hi = 0, n_total
+            self.counts = [n_total] * world
+            self.seed_value = synth.SEED + 977 * rank
+            self.n_job = world * n_total
+        self.n_seeds = self.hi - self.lo  # patches this rank refines per step
+
+    def my_slice(self, gathered):
+        """This rank's own records inside the gathered round."""
+        if self.scaling == "strong":
+            return gathered[self.lo:self.hi]
+        off = sum(self.counts[:self.rank])
+        return gathered[off:off + self.n_seeds]
+
+
+def default_workload(world):
+    return DEFAULT_WORKLOAD if world <= 1 else DEFAULT_WORKLOAD_MULTI
+
+
+class GpuBackend:
+    """The product path: HBM-resident scene, hpmvs_optimize_batch + hpmvs_pack_records through the C ABI, RCCL."""
+    name = "hip"
+    dist_backend = "nccl"
+
+    def __init__(self, local_rank):
+        if not torch.cuda.is_available() or api.device_count() < 1:
+            raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        self.local_rank = local_rank
+        self.device = torch.device("cuda", local_rank)
+        self.L = api.lib()
+        self.opts = api.default_options()
+
+    def init_dist(self):
+        dist.init_process_group("nccl", device_id=self.device)  # RCCL over xGMI
+
+    def make_scene(self, plan):
+        scene = synth.make_scene(plan.views, plan.W, plan.H, n_waves=24, device=self.device)
+        self.gpu_scene = api.Scene(scene, device=self.local_rank)
+        torch.cuda.synchronize()
+        return scene
+
+    def stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def mark(self):
+        """A point in time on the stream the kernels are launched on (HIP event)."""
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    @staticmethod
+    def ms_between(a, b):
+        return a.elapsed_time(b)
+
+    def refine(self, work, n, max_images):
+        b = c_batch(work, n, max_images)
+        rc = self.L.hpmvs_optimize_batch(self.gpu_scene.h, C.byref(self.opts), C.byref(b), 1, C.c_void_p(self.stream()))
+        if rc != 0:
+            raise RuntimeError(self.L.hpmvs_last_error().decode())
+
+    def pack(self, work, n, max_images, records):
+        # the product path of INTEGRATION.md: hpmvs_pack_records (kernel) fills the round's exchange buffer
+        b = c_batch(work, n, max_images)
+        rc = self.L.hpmvs_pack_records(C.byref(b), C.c_void_p(records.data_ptr()), C.c_void_p(self.stream()))
+        if rc != 0:
+            raise RuntimeError(self.L.hpmvs_last_error().decode())
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+
+def main(argv=None, backend=None):
+    """`backend` (tests only): an object with GpuBackend's interface; tests/test_cpu_distributed.py runs this very
+    function at world size 2 on gloo with the kernel call stubbed, to execute the shard / gather / timing logic."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=list(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=list(WORKLOADS),
+                    help=f"default: {DEFAULT_WORKLOAD} at N = 1, {DEFAULT_WORKLOAD_MULTI} (the same batch, sharded) at N > 1")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="weak: seeds per GPU fixed; strong: one batch cut across the ranks (default: the workload's)")
     ap.add_argument("--patches", type=int, default=0, help="override the workload's seed count")
@@ -121,47 +216,30 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--check-gather", action="store_true",
                     help="after the timed steps: compare the gathered records with the un-gathered results (tests)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available() or api.device_count() < 1:
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    be = backend if backend is not None else GpuBackend(local_rank)
+    dev = be.device
     use_dist = world > 1 or os.environ.get("HPMVS_BENCH_FORCE_DIST") == "1"  # the latter: 1-GPU test of the RCCL path
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        be.init_dist()
 
-    views, W, H, n_total, start_level, scaling = WORKLOADS[args.workload]
-    if args.scaling:
-        scaling = args.scaling
-    if args.patches > 0:
-        n_total = args.patches
+    workload = args.workload or default_workload(world)
+    plan = Plan(workload, args.scaling, args.patches, rank, world)
+    views, W, H, start_level, scaling = plan.views, plan.W, plan.H, plan.start_level, plan.scaling
+    n_total, n_seeds, n_job, lo, hi, counts = plan.n_total, plan.n_seeds, plan.n_job, plan.lo, plan.hi, plan.counts
     max_images = 32
-    if scaling == "strong":
-        # one batch, the same on every rank; rank r refines [lo, hi) of it
-        lo, hi = dd.shard_range(n_total, rank, world)
-        counts = [dd.shard_range(n_total, r, world)[1] - dd.shard_range(n_total, r, world)[0] for r in range(world)]
-        seed_value = synth.SEED
-        n_job = n_total
-    else:
-        lo, hi = 0, n_total
-        counts = [n_total] * world
-        seed_value = synth.SEED + 977 * rank
-        n_job = world * n_total
-    n_seeds = hi - lo  # patches this rank refines per step
 
     # ---- scene: rendered on the GPU, replicated on every rank, resident in HBM
     t0 = time.time()
-    scene = synth.make_scene(views, W, H, n_waves=24, device=dev)
-    gpu_scene = api.Scene(scene, device=local_rank)
-    torch.cuda.synchronize()
+    scene = be.make_scene(plan)
     t_scene = time.time() - t0
-    seeds = synth.make_seeds(scene, n_total, start_level=start_level, max_images=max_images, seed=seed_value)
+    seeds = synth.make_seeds(scene, n_total, start_level=start_level, max_images=max_images, seed=plan.seed_value)
     if scaling == "strong" and world > 1:
         seeds = synth.Seeds(center=seeds.center[lo:hi], normal=seeds.normal[lo:hi], scale=seeds.scale[lo:hi],
                             n_images=seeds.n_images[lo:hi], images=seeds.images[lo:hi], truth=seeds.truth[lo:hi])
@@ -172,43 +250,35 @@ def main():
                             n_images=seeds.n_images[perm], images=seeds.images[perm], truth=seeds.truth[perm])
     pristine = device_batch(seeds, dev, max_images)
     work = {k: v.clone() for k, v in pristine.items()}
-    opts = api.default_options()
-    L = api.lib()
-    stream = torch.cuda.current_stream().cuda_stream
     gathered = None
     # the round's exchange buffer: n_seeds records of 192 bytes, filled by the product's own packing kernel
     records = torch.empty((n_seeds, RECORD_BYTES), dtype=torch.uint8, device=dev) if use_dist else None
 
-    events = []
+    marks = []
 
     def step(timed=False):
         for k in ("center", "normal", "n_images", "images"):
             work[k].copy_(pristine[k])
-        b = c_batch(work, n_seeds, max_images)
         # HIP events on the stream the kernel is launched on (torch's current stream is handed to the C ABI)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rc = L.hpmvs_optimize_batch(gpu_scene.h, C.byref(opts), C.byref(b), 1, C.c_void_p(stream))
-        e1.record()
-        if rc != 0:
-            raise RuntimeError(L.hpmvs_last_error().decode())
-        if timed:
-            events.append((e0, e1))
+        m0 = be.mark()
+        be.refine(work, n_seeds, max_images)
+        m1 = be.mark()
+        m2 = None
         if use_dist:
-            # the product path of INTEGRATION.md: hpmvs_pack_records (kernel) -> ONE all-gather of the records
             nonlocal gathered
             if not timed:
                 check_record_ranges(work)
-            rc = L.hpmvs_pack_records(C.byref(b), C.c_void_p(records.data_ptr()), C.c_void_p(stream))
-            if rc != 0:
-                raise RuntimeError(L.hpmvs_last_error().decode())
-            gathered = dd.all_gather_records(records, counts)
+            be.pack(work, n_seeds, max_images, records)
+            gathered = dd.all_gather_records(records, counts)  # ONE collective per round
+            m2 = be.mark()
+        if timed:
+            marks.append((m0, m1, m2))
 
     def fence():
-        torch.cuda.synchronize()
+        be.sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        be.sync()
 
     for _ in range(args.warmup):
         step()
@@ -217,20 +287,32 @@ def main():
     for _ in range(args.steps):
         step(timed=True)
     fence()
-    elapsed = time.perf_counter() - t0
-    # average launch duration of the refinement kernel over the timed region
-    last_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
-    lib_ms = gpu_scene.last_kernel_ms()  # the library's own event pair around the last launch (cross-check)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    elapsed_rank = time.perf_counter() - t0
+    # average launch duration of the refinement kernel over the timed region (and of pack + all-gather behind it)
+    last_ms = float(np.mean([be.ms_between(a, b) for a, b, _ in marks]))
+    exch_ms = float(np.mean([be.ms_between(b, c) for _, b, c in marks])) if use_dist else 0.0
+    lib_ms = be.gpu_scene.last_kernel_ms() if hasattr(be, "gpu_scene") else last_ms  # the library's own event pair (cross-check)
+    elapsed = elapsed_rank
+    per_rank = None
     if use_dist:
+        # the job's time is the slowest rank's; every rank's own figures travel to rank 0 beside it
+        mine = torch.tensor([elapsed_rank, last_ms, exch_ms, float(n_seeds)], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        tmax = torch.tensor([elapsed_rank], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+        elapsed = float(tmax.item())
+        rows = [[float(v) for v in t.cpu()] for t in every]
+        per_rank = {"patches": [int(r[3]) for r in rows], "kernel_ms": [r[1] for r in rows],
+                    "pack_plus_allgather_ms": [r[2] for r in rows], "ms_per_step": [1e3 * r[0] / args.steps for r in rows],
+                    "what": "per rank: its shard, HIP-event time of its refinement kernel, of hpmvs_pack_records + the "
+                            "all-gather behind it, and its wall time per step between the barriers"}
 
     # ---- SURVEY 8d's wall definition ("seeds on host -> refined records on host"): the same step with the
     # seed arrays coming from pinned host memory and the refined fields copied back, timed separately (PCIe
-    # inclusive; reported beside `value`, never as `value`)
+    # inclusive; reported beside `value`, never as `value`: the bench contract times inputs resident in HBM)
     h2h = None
-    if not use_dist:
+    if not use_dist and backend is None:
         in_keys = ("center", "normal", "scale", "n_images", "images")
         out_keys = ("center", "normal", "n_images", "images", "ok", "color", "fmin")
         host_in = {k: pristine[k].cpu().pin_memory() for k in in_keys}
@@ -238,24 +320,22 @@ def main():
         def h2h_step():
             for k in in_keys:
                 work[k].copy_(host_in[k], non_blocking=True)
-            b = c_batch(work, n_seeds, max_images)
-            rc = L.hpmvs_optimize_batch(gpu_scene.h, C.byref(opts), C.byref(b), 1, C.c_void_p(stream))
-            if rc != 0:
-                raise RuntimeError(L.hpmvs_last_error().decode())
+            be.refine(work, n_seeds, max_images)
             for k in out_keys:
                 host_out[k].copy_(work[k], non_blocking=True)
         h2h_step()
-        torch.cuda.synchronize()
+        be.sync()
         reps = max(1, min(3, args.steps))
         th = time.perf_counter()
         for _ in range(reps):
             h2h_step()
-        torch.cuda.synchronize()
+        be.sync()
         th = (time.perf_counter() - th) / reps
         h2h = {"value": n_seeds / th, "unit": "patches/s", "ms_per_step": 1e3 * th, "steps": reps,
                "bytes_in": int(sum(host_in[k].numel() * host_in[k].element_size() for k in in_keys)),
                "bytes_out": int(sum(host_out[k].numel() * host_out[k].element_size() for k in out_keys)),
-               "what": "pinned host seeds -> H2D -> optimize_kernel -> D2H of the refined Patch3d fields, one stream"}
+               "what": "pinned host seeds -> H2D -> optimize_kernel -> D2H of the refined Patch3d fields, one stream "
+                       "(SURVEY 8d's wall definition)"}
 
     ok = work["ok"].cpu().numpy().astype(bool)
     ngrabs = work["ngrabs"].cpu().numpy().astype(np.int64)
@@ -268,7 +348,7 @@ def main():
 
     # which build of the kernel the library picked for this batch size (kernel_launch.hip: 58 slots per wavefront from
     # 1600 patches per CU upwards, unless HPMVS_SLOTS forces one)
-    n_cus_dev = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    n_cus_dev = int(torch.cuda.get_device_properties(dev).multi_processor_count) if dev.type == "cuda" else 256
     forced = os.environ.get("HPMVS_SLOTS", "")
     kernel_name = "optimize_kernel_big" if (forced == "58" or (forced != "29" and n_seeds >= 1600 * n_cus_dev)) else "optimize_kernel"
     out = {
@@ -284,16 +364,19 @@ def main():
         "vs_baseline": None,
         "dtype": "f32 textures / f64 optimiser",
         "data": "synthetic",
-        "config": {"workload": args.workload, "views": views, "image": f"{W}x{H}", "pyramid_levels": 6,
+        "config": {"workload": workload, "views": views, "image": f"{W}x{H}", "pyramid_levels": 6,
                    "seeds_per_gpu": n_seeds, "seeds_per_step_all_gpus": n_job, "start_level": start_level,
                    "max_images": max_images, "order": args.order,
                    "parallelism": f"patch-shard x{world} + all-gather of {RECORD_BYTES} B records"},
+        "value_is": "inputs resident in HBM when the timed region starts (the bench contract: a PCIe-inclusive rate is "
+                    "never `value`); SURVEY 8d's host -> host rate of the same step is host_to_host.value",
         "host_to_host": h2h,
+        "per_rank": per_rank,
         "successes_per_sec_rank0_extrapolated": n_job * float(ok.mean()) * args.steps / elapsed,
         "success_fraction": float(ok.mean()),
         "mean_evals_per_refined_patch": float(nevals[nevals > 0].mean()) if (nevals > 0).any() else 0.0,
         "mean_grabs_per_patch": float(ngrabs.mean()),
-        "scene_bytes_hbm": int(gpu_scene.bytes()),
+        "scene_bytes_hbm": int(be.gpu_scene.bytes()) if hasattr(be, "gpu_scene") else 0,
         "scene_setup_s": t_scene,
         "roofline": {"bound": "hbm", "kernel": kernel_name, "slots_per_wavefront": 58 if kernel_name.endswith("_big") else 29,
                      "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -305,7 +388,7 @@ def main():
     if use_dist and args.check_gather and rank == 0:
         # the gathered bytes of this rank's shard against (a) the torch packer applied to the results and (b) the
         # result fields themselves
-        mine = gathered[lo:hi] if scaling == "strong" else gathered[:n_seeds]
+        mine = plan.my_slice(gathered)
         ref = dd.pack_records(work["center"], work["normal"], work["color"], work["scale"], work["fmin"], work["ok"],
                               work["n_images"], work["images"], check=True)
         u = dd.unpack_records(mine)
@@ -313,33 +396,27 @@ def main():
         fields = (np.array_equal(u["center"], work["center"].cpu().numpy()) and np.array_equal(u["ok"], okb) and
                   np.array_equal(u["n_images"], work["n_images"].cpu().numpy()) and
                   np.array_equal(u["fmin"], work["fmin"].cpu().numpy()))
-        out["gather_check"] = {"collective": f"all_gather_into_tensor over RCCL ({world} rank{'s' if world > 1 else ''})",
+        coll = "RCCL" if getattr(be, "dist_backend", "nccl") == "nccl" else getattr(be, "dist_backend", "?")
+        out["gather_check"] = {"collective": f"all_gather_into_tensor over {coll} ({world} rank{'s' if world > 1 else ''})",
                                "records": int(mine.shape[0]), "gathered_total": int(gathered.shape[0]),
                                "bytes_equal_python_packer": bool(torch.equal(mine, ref)), "fields_equal_results": bool(fields)}
+    if backend is not None:  # tests: hand the gathered round back with the line
+        out["_gathered"] = gathered
 
     # counters of a PMC pass over this very workload (profiles/collect.sh): only if they were collected from the
     # library build that is loaded now
-    build_id = api.build_id()
+    build_id = api.build_id() if backend is None else "stub"
     out["library_build_id"] = build_id
-    out["n_cus"] = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    out["n_cus"] = n_cus_dev
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and backend is None:
         try:
-            rec = json.load(open(pmc)).get(args.workload)
+            rec = json.load(open(pmc)).get(workload if world == 1 else "")
             if rec and rec.get("seeds_per_gpu") == n_seeds and rec.get("library_build_id") == build_id:
                 out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = rec.get("source")
                 if "valu_thread_cycles" in rec and "kernel_cycles" in rec:
-                    # lane-cycles: SQ_THREAD_CYCLES_VALU counts active lanes x 4-cycle issue slots; the machine
-                    # offers CUs x 4 SIMDs x 16 lanes per cycle
-                    peak = float(rec["n_cus"]) * 4 * 16 * float(rec["kernel_cycles"])
-                    used = float(rec["valu_thread_cycles"])
-                    out["roofline_issue"] = {"bound": "valu", "lane_cycles_used": used, "lane_cycles_peak": peak,
-                                             "frac": used / peak,
-                                             "valu_insts_per_patch": rec.get("valu_insts_per_patch"),
-                                             "valu_lane_utilization": rec.get("valu_lane_utilization"),
-                                             "issue_slot_frac": rec.get("valu_issue_slot_frac"),
-                                             "source": rec.get("source")}
+                    out["roofline_issue"] = issue_roofline(rec)
             elif rec:
                 out["roofline"]["traffic_note"] = ("profiles/pmc_traffic.json holds counters of another build "
                                                    f"({rec.get('library_build_id')}); not reported")
@@ -347,15 +424,46 @@ def main():
             out["roofline"]["traffic_note"] = f"pmc_traffic.json unreadable: {e}"
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only)
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and backend is None:
         try:
             cpu_leg(out, args, scene, seeds, n_seeds, work, ok, nevals, stage)
         except Exception as e:  # the GPU line must survive a box without the checker
             out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
-    if rank == 0:
+    if rank == 0 and backend is None:
         print(json.dumps(out))
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+def issue_roofline(rec):
+    """The compute-side view of the refinement kernel from a PMC record: VALU lane-cycles used / what the machine
+    offers in the kernel's time.  What the machine offers per SIMD and clock is MEASURED (tools/valu_calibrate.hip ->
+    profiles/calibration/valu_rates.json: dense independent v_fma_f32 at two wavefronts per SIMD), not assumed."""
+    lanes_per_clk, src = 16.0, "assumed: 16 lanes per SIMD per clock (no calibration record found)"
+    cal = os.path.join(ROOT, "profiles", "calibration", "valu_rates.json")
+    try:
+        tests = json.load(open(cal))["tests"]
+        f32 = [t for t in tests if t["instruction"] == "v_fma_f32" and t["waves_per_simd"] == 2]
+        if f32:
+            lanes_per_clk = float(f32[0]["lanes_per_cycle_per_simd"])
+            src = "measured: profiles/calibration/valu_rates.json (v_fma_f32, 2 wavefronts per SIMD)"
+    except Exception:
+        pass
+    # SQ_THREAD_CYCLES_VALU over CUs x 4 SIMDs x 16 x cycles is (active lanes per VALU instruction / 64) x (share of
+    # 4-cycle issue slots with a VALU instruction): lane-cycles of a SIMD that issues 16 lanes per clock.  A SIMD that
+    # really issues `lanes_per_clk` offers lanes_per_clk / 16 times as many.
+    used = float(rec["valu_thread_cycles"])
+    peak16 = float(rec["n_cus"]) * 4 * 16 * float(rec["kernel_cycles"])
+    peak = peak16 * lanes_per_clk / 16.0
+    return {"bound": "valu", "lane_cycles_used": used, "lane_cycles_peak": peak, "frac": used / peak,
+            "lanes_per_simd_per_clock": lanes_per_clk, "peak_source": src,
+            "frac_if_16_lanes_per_clock": used / peak16,
+            "valu_insts_per_patch": rec.get("valu_insts_per_patch"),
+            "valu_lane_utilization": rec.get("valu_lane_utilization"),
+            "issue_slot_frac": rec.get("valu_issue_slot_frac"),
+            "source": rec.get("source")}
 
 
 def cpu_leg(out, args, scene, seeds, n_seeds, work, ok, nevals, stage):
@@ -397,7 +505,7 @@ def cpu_leg(out, args, scene, seeds, n_seeds, work, ok, nevals, stage):
     cen_g = work["center"][:m].cpu().numpy()
     nor_g = work["normal"][:m].cpu().numpy()
     unrob = lambda f: f / (1.0 - 3.0 * f)
-    dncc, basin, ident = [], [], []
+    dncc, basin, ident, ddepth, dangle = [], [], [], [], []
     col_g = work["color"][:m].cpu().numpy()
     nim_g = work["n_images"][:m].cpu().numpy()
     img_g = work["images"][:m].cpu().numpy()
@@ -411,7 +519,9 @@ def cpu_leg(out, args, scene, seeds, n_seeds, work, ok, nevals, stage):
         dncc.append(abs(unrob(p.fmin) - unrob(fmin_g[k])))
         ddist = np.linalg.norm(np.array(p.center[:3]) - cen_g[k, :3]) / float(seeds.scale[k])
         cs = float(np.clip(np.dot(np.array(p.normal[:3]), nor_g[k, :3]), -1, 1))
-        basin.append(ddist < 0.25 and np.degrees(np.arccos(cs)) < 2.0)
+        ang = float(np.degrees(np.arccos(cs)))
+        ddepth.append(ddist); dangle.append(ang)
+        basin.append(ddist < 0.25 and ang < 2.0)
     out["cpu_baseline"] = {
         "value": mt / tc, "unit": "patches/s", "cores": cores,
         "kind": "port",
@@ -429,6 +539,14 @@ def cpu_leg(out, args, scene, seeds, n_seeds, work, ok, nevals, stage):
         "same_basin_fraction": float(np.mean(basin)) if basin else None,
         "bit_identical_patch_fraction": float(np.mean(ident)) if ident else None,
         "stage_agreement": float((np.array([p.stage for p in P]) == stage[:m]).mean()),
+        # success-set agreement and the geometric deltas of the patches both paths refined
+        "success_set_jaccard": float((okc & okg).sum() / max(1, (okc | okg).sum())),
+        "abs_ddepth_over_scale": {"median": float(np.median(ddepth)) if ddepth else None,
+                                  "p95": float(np.percentile(ddepth, 95)) if ddepth else None,
+                                  "max": float(np.max(ddepth)) if ddepth else None},
+        "normal_angle_deg": {"median": float(np.median(dangle)) if dangle else None,
+                             "p95": float(np.percentile(dangle, 95)) if dangle else None,
+                             "max": float(np.max(dangle)) if dangle else None},
     }
 
 

@@ -115,3 +115,140 @@ def test_records_refuse_what_they_cannot_carry():
         dd.pack_records(*base(1), t(np.array([1], np.int32)), t(np.array([[65535] + [0] * 31], np.int32)))
     with pytest.raises(ValueError):  # wider than the ABI's 64
         dd.pack_records(*base(1), t(np.array([1], np.int32)), t(np.zeros((1, 65), np.int32)))
+
+
+# ---- bench.py's own multi-rank logic: Plan (workload default, counts, lo/hi), the slicing of the seed
+# arrays, pack -> all-gather -> my_slice, the per-rank figures and the MAX over ranks -- executed at world size 2 on
+# gloo by calling bench.main() itself with a backend whose kernel call is the CPU oracle.
+class _OracleBackend:
+    """bench.GpuBackend's interface on CPU tensors: refine = the oracle, pack = the torch packer, marks = wall clock."""
+    name = "oracle-stub"
+    dist_backend = "gloo"
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.calls = 0
+
+    def init_dist(self):
+        dist.init_process_group("gloo")
+
+    def make_scene(self, plan):
+        from hpmvs_amd import synth
+        from oracle import oracle as orc
+        scene = synth.make_scene(plan.views, plan.W, plan.H, n_waves=24)
+        self.osc = orc.OracleScene(scene)
+        return scene
+
+    def mark(self):
+        import time
+        return time.perf_counter()
+
+    @staticmethod
+    def ms_between(a, b):
+        return 1e3 * (b - a)
+
+    def refine(self, work, n, max_images):
+        from oracle import oracle as orc
+        self.calls += 1
+        P = (orc.Patch * n)()
+        cen, nor, sca = work["center"].numpy(), work["normal"].numpy(), work["scale"].numpy()
+        nim, img = work["n_images"].numpy(), work["images"].numpy()
+        for k in range(n):
+            P[k].center[:] = cen[k].tolist(); P[k].normal[:] = nor[k].tolist(); P[k].scale = float(sca[k])
+            P[k].n_images = int(nim[k])
+            for j in range(int(nim[k])):
+                P[k].images[j] = int(img[k, j])
+        orc.optimize_batch(self.osc, P, n_threads=2)
+        for k in range(n):
+            okk = P[k].stage == 0
+            work["ok"][k] = 1 if okk else 0
+            work["stage"][k] = P[k].stage; work["nevals"][k] = P[k].nevals; work["ngrabs"][k] = P[k].ngrabs
+            work["fmin"][k] = P[k].fmin
+            if okk:
+                work["center"][k] = torch.tensor(list(P[k].center)); work["normal"][k] = torch.tensor(list(P[k].normal))
+                work["color"][k] = torch.tensor(list(P[k].color)); work["n_images"][k] = P[k].n_images
+                work["images"][k, :P[k].n_images] = torch.tensor(list(P[k].images[:P[k].n_images]), dtype=torch.int32)
+
+    def pack(self, work, n, max_images, records):
+        from hpmvs_amd import distributed as dd
+        records.copy_(dd.pack_records(work["center"], work["normal"], work["color"], work["scale"], work["fmin"], work["ok"],
+                                      work["n_images"], work["images"], check=True))
+
+    def sync(self):
+        pass
+
+
+def _bench_worker(rank, world, port, argv, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    if world == 1:
+        os.environ["HPMVS_BENCH_FORCE_DIST"] = "1"
+    import bench
+    out = bench.main(argv, backend=_OracleBackend())
+    g = out.pop("_gathered")
+    q.put((rank, out, g.numpy().copy()))
+
+
+def _run_bench(world, argv):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, argv, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(world):
+        r, out, g = q.get(timeout=600)
+        got[r] = (out, g)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return got
+
+
+def test_bench_plan_defaults_and_shards():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.default_workload(1) == "c2_50v_4k_1e6" and bench.default_workload(8) == "c3_50v_4k_1e6_sharded"
+    n = 0
+    for r in range(8):
+        p = bench.Plan(bench.default_workload(8), None, 0, r, 8)
+        assert p.scaling == "strong" and p.n_job == 1_000_000 and p.n_total == 1_000_000 and p.lo == n
+        assert p.counts == [125_000] * 8 and p.n_seeds == 125_000
+        n = p.hi
+    assert n == 1_000_000
+    p1 = bench.Plan(bench.default_workload(1), None, 0, 0, 1)
+    assert p1.scaling == "weak" and p1.n_seeds == 1_000_000 and p1.n_job == 1_000_000   # N = 1: the same 1e6 seeds
+    pw = bench.Plan("c2_50v_4k_1e6", "weak", 0, 3, 4)
+    assert pw.n_job == 4_000_000 and pw.n_seeds == 1_000_000 and pw.seed_value != bench.Plan("c2_50v_4k_1e6", "weak", 0, 2, 4).seed_value
+    pr = bench.Plan("c0_tiny", "strong", 31, 1, 2)   # ragged
+    assert (pr.lo, pr.hi, pr.counts) == (16, 31, [16, 15])
+
+
+def test_bench_main_two_ranks_on_gloo_equals_one_rank():
+    """bench.main() itself at world size 2 (strong scaling of a 31-seed tiny round, ragged shards): every rank ends with
+    the same full round, equal to the 1-rank round byte for byte; rank 0's line carries per-rank figures and the job's
+    time is the maximum over the ranks."""
+    from hpmvs_amd import distributed as dd
+    argv = ["--gpus", "2", "--workload", "c0_tiny", "--scaling", "strong", "--patches", "31", "--steps", "2", "--warmup", "1",
+            "--no-cpu", "--check-gather"]
+    two = _run_bench(2, argv)
+    one = _run_bench(1, ["--gpus", "1"] + argv[2:])
+    out0, g0 = two[0]
+    out1, g1 = two[1]
+    assert g0.shape == (31, dd.RECORD_BYTES) and np.array_equal(g0, g1)
+    assert np.array_equal(g0, one[0][1])
+    assert out0["n_gpus"] == 2 and out0["scaling"] == "strong" and out0["config"]["workload"] == "c0_tiny"
+    assert out0["config"]["seeds_per_gpu"] == 16 and out0["config"]["seeds_per_step_all_gpus"] == 31
+    assert out1["config"]["seeds_per_gpu"] == 15
+    pr = out0["per_rank"]
+    assert pr["patches"] == [16, 15] and len(pr["kernel_ms"]) == 2 and all(v > 0 for v in pr["kernel_ms"])
+    assert all(v >= 0 for v in pr["pack_plus_allgather_ms"])
+    # the job's step time is the slowest rank's, and `value` is the whole round over it
+    assert abs(out0["ms_per_step"] - max(pr["ms_per_step"])) < 1e-6 and out0["ms_per_step"] == out1["ms_per_step"]
+    assert abs(out0["value"] - 31 * 2 / (out0["ms_per_step"] * 2e-3)) < 1e-6 * out0["value"]
+    gc = out0["gather_check"]
+    assert gc["records"] == 16 and gc["gathered_total"] == 31 and gc["bytes_equal_python_packer"] and gc["fields_equal_results"]
+    u = dd.unpack_records(torch.from_numpy(g0))
+    assert u["ok"].sum() >= 10
