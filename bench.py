@@ -351,6 +351,11 @@ def main(argv=None, backend=None):
     n_cus_dev = int(torch.cuda.get_device_properties(dev).multi_processor_count) if dev.type == "cuda" else 256
     forced = os.environ.get("HPMVS_SLOTS", "")
     kernel_name = "optimize_kernel_big" if (forced == "58" or (forced != "29" and n_seeds >= 1600 * n_cus_dev)) else "optimize_kernel"
+    # HPMVS_SUMS=tree: the opt-in throughput build of the kernel (row sums first; NOT bit-identical to the oracle, and
+    # never the default: a line measured in that mode says so here and in config.sums)
+    sums_mode = "tree" if os.environ.get("HPMVS_SUMS") == "tree" else "exact"
+    if sums_mode == "tree":
+        kernel_name += "_tree"
     out = {
         "metric": "refined_patches_per_sec",
         "value": n_job * args.steps / elapsed,
@@ -366,7 +371,7 @@ def main(argv=None, backend=None):
         "data": "synthetic",
         "config": {"workload": workload, "views": views, "image": f"{W}x{H}", "pyramid_levels": 6,
                    "seeds_per_gpu": n_seeds, "seeds_per_step_all_gpus": n_job, "start_level": start_level,
-                   "max_images": max_images, "order": args.order,
+                   "max_images": max_images, "order": args.order, "sums": sums_mode,
                    "parallelism": f"patch-shard x{world} + all-gather of {RECORD_BYTES} B records"},
         "value_is": "inputs resident in HBM when the timed region starts (the bench contract: a PCIe-inclusive rate is "
                     "never `value`); SURVEY 8d's host -> host rate of the same step is host_to_host.value",

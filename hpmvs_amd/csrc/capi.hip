@@ -250,35 +250,46 @@ int hpmvs_scene_set_view(hpmvs_scene* s, int view, int width, int height, const 
     if (cam->n_levels < 1 || cam->n_levels > HPMVS_MAX_LEVELS) return fail(HPMVS_ERR_ARG, "scene_set_view: bad n_levels");
     HIPCHK(hipSetDevice(s->device));
     DevView& V = s->hviews[view];
-    if (s->view_set[view]) {  // set again: release the previous pyramid of this view
-        for (int l = 0; l < V.n_levels; l++) {
-            void* old = (void*)V.pix[l];
-            for (size_t k = 0; k < s->allocs.size(); k++)
-                if (s->allocs[k] == old) { s->allocs.erase(s->allocs.begin() + k); break; }
-            if (old) { hipFree(old); s->bytes -= (size_t)V.w[l] * V.h[l] * 3 + 16; }
-            V.pix[l] = nullptr;
-        }
-        s->view_set[view] = 0;
-    }
     // Image::init/load: max(1, MAXLEVEL) + 1 pyramid levels (reference Image.cpp:33-57); the camera has
     // MAXLEVEL + 1 projection levels (Camera.cpp:36).  Both are MAXLEVEL + 1 for MAXLEVEL >= 1.
     const int levels = cam->n_levels < 2 ? 2 : cam->n_levels;
+    // one allocation per view: level l at a 256-byte aligned offset, 16 B of padding behind every level
+    size_t off[HPMVS_MAX_LEVELS] = {}, total = 0;
+    {
+        int w = width, h = height;
+        for (int l = 0; l < levels; l++) {
+            if (w < 1 || h < 1) return fail(HPMVS_ERR_ARG, "scene_set_view: image too small for the pyramid depth");
+            off[l] = total;
+            total += ((size_t)w * h * 3 + 16 + 255) & ~(size_t)255;
+            w /= 2; h /= 2;
+        }
+        if (total > 0xffffffffull) return fail(HPMVS_ERR_ARG, "scene_set_view: image too large (a view's pyramid must stay below 4 GB)");
+    }
+    uint8_t* slab = nullptr;
+    HIPCHK(hipMalloc((void**)&slab, total));
+    if (s->view_set[view]) {  // set again: release the previous pyramid of this view
+        void* old = (void*)V.pix[0];
+        for (size_t k = 0; k < s->allocs.size(); k++)
+            if (s->allocs[k] == old) { s->allocs.erase(s->allocs.begin() + k); break; }
+        if (old) { hipFree(old); s->bytes -= V.slab_bytes; }
+        for (int l = 0; l < HPMVS_MAX_LEVELS; l++) V.pix[l] = nullptr;
+        s->view_set[view] = 0;
+    }
+    s->allocs.push_back(slab);
+    s->bytes += total;
+    V.slab_bytes = (uint32_t)total;
+    HIPCHK(hipMemset(slab, 0, total));
     int w = width, h = height;
     for (int l = 0; l < levels; l++) {
-        if (w < 1 || h < 1) return fail(HPMVS_ERR_ARG, "scene_set_view: image too small for the pyramid depth");
-        uint8_t* d = nullptr;
+        uint8_t* d = slab + off[l];
         const size_t nb = (size_t)w * h * 3;
-        HIPCHK(hipMalloc((void**)&d, nb + 16));
-        HIPCHK(hipMemset(d + nb, 0, 16));
-        s->allocs.push_back(d);
-        s->bytes += nb + 16;
         if (l == 0) {
             HIPCHK(hipMemcpy(d, rgb_l0, nb, rgb_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
         } else {
             launch_half_resize(V.pix[l - 1], V.w[l - 1], V.h[l - 1], d, nullptr);
             HIPCHK(hipGetLastError());
         }
-        V.pix[l] = d; V.w[l] = w; V.h[l] = h;
+        V.pix[l] = d; V.off[l] = (uint32_t)off[l]; V.w[l] = w; V.h[l] = h;
         w /= 2; h /= 2;
     }
     HIPCHK(hipDeviceSynchronize());

@@ -10,10 +10,14 @@ constexpr int kTex = 7;          // PatchTex = Patch2d<7,float> (reference Patch
 constexpr int kTexPix = 49;
 
 // One view: what PatchOptimizer reads of mo3d::Camera + mo3d::Image
-// (reference Camera.h:87-105, Image.h:63-64,89-115).  Pyramid levels are separate allocations of
-// interleaved u8 RGB, 3*(y*W+x)+c, padded by 16 B so the 8-byte tap loads never leave the buffer.
+// (reference Camera.h:87-105, Image.h:63-64,89-115).  The pyramid levels of a view are ONE allocation: level l of
+// interleaved u8 RGB, 3*(y*W+x)+c, starts at pix[0] + off[l] (256-byte aligned) and is followed by at least 16 B of
+// padding, so the 8-byte tap loads never leave the buffer.  pix[l] = pix[0] + off[l] is kept for the host and for
+// kernels that want one level; the evaluator loads pix[0] and the offsets together with the rest of the view's table
+// and selects by level, which leaves it without a load that depends on the level (prep_from_view).
 struct alignas(16) DevView {
     const uint8_t* pix[kMaxLevels];
+    uint32_t off[kMaxLevels];
     int32_t w[kMaxLevels];
     int32_t h[kMaxLevels];
     float P0[12];      // level 0; level l = diag(2^-l, 2^-l, 1) * P0 (Camera.cpp:55-63)
@@ -23,7 +27,8 @@ struct alignas(16) DevView {
     float zaxis[4];
     float fsum;        // kMat_[0](0,0) + kMat_[0](1,1)
     int32_t n_levels;  // projection_.size()
-    int32_t pad[2];
+    uint32_t slab_bytes;  // size of the view's pyramid allocation (host bookkeeping)
+    int32_t pad[1];
 };
 
 // One view's depth maps (reference Scene.h:74-76, Scene.cpp:74-80): per pyramid level an Eigen::MatrixXf(rows, cols),

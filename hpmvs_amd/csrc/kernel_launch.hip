@@ -1,19 +1,33 @@
-// kernel_launch.hip -- which build of the refinement kernel a batch launch gets (kernel_optimize.hip is compiled
-// twice: see kernel_optimize_big.hip), and the workspace that fits both.
+// kernel_launch.hip -- which build of the refinement kernel a batch launch gets (kernel_optimize.hip is compiled four
+// times: see kernel_optimize_big.hip and kernel_optimize_tree.hip), and the workspace that fits all of them.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 #include "launch.h"
 
 namespace hpmvs {
 
-size_t optimize_workspace_bytes_std(int n_cus);
-size_t optimize_workspace_bytes_big(int n_cus);
-void launch_optimize_std(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus, hipStream_t st);
-void launch_optimize_big(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus, hipStream_t st);
+#define HPMVS_DECLARE(sfx)                                                                                             \
+    size_t optimize_workspace_bytes##sfx(int n_cus);                                                                   \
+    void launch_optimize##sfx(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus, hipStream_t st);
+HPMVS_DECLARE(_std)
+HPMVS_DECLARE(_big)
+HPMVS_DECLARE(_tree)
+HPMVS_DECLARE(_big_tree)
+#undef HPMVS_DECLARE
 
 size_t optimize_workspace_bytes(int n_cus) {
-    const size_t a = optimize_workspace_bytes_std(n_cus), b = optimize_workspace_bytes_big(n_cus);
-    return a > b ? a : b;
+    size_t m = optimize_workspace_bytes_std(n_cus);
+    const size_t o[3] = {optimize_workspace_bytes_big(n_cus), optimize_workspace_bytes_tree(n_cus), optimize_workspace_bytes_big_tree(n_cus)};
+    for (size_t v : o) m = v > m ? v : m;
+    return m;
+}
+
+// HPMVS_SUMS=tree: the throughput-mode window sums (photometric.hpp, HPMVS_FAST_SUMS).  Anything else, or nothing: the
+// reference's sequential order (parity mode, the default; what `exact` spells out).
+int optimize_sums_mode() {
+    static const int mode = [] { const char* e = getenv("HPMVS_SUMS"); return (e && strcmp(e, "tree") == 0) ? 1 : 0; }();
+    return mode;
 }
 
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus,
@@ -22,6 +36,11 @@ void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b,
     // (409 600 on an MI355X), where its lower cost per patch has paid for its longer ramp-down
     static const int forced = [] { const char* e = getenv("HPMVS_SLOTS"); return e ? atoi(e) : 0; }();
     const bool big = forced == 58 || (forced != 29 && (long long)b.n >= 1600ll * n_cus);
+    if (optimize_sums_mode() == 1) {
+        if (big) launch_optimize_big_tree(sc, o, b, workspace, n_cus, st);
+        else launch_optimize_tree(sc, o, b, workspace, n_cus, st);
+        return;
+    }
     if (big) launch_optimize_big(sc, o, b, workspace, n_cus, st);
     else launch_optimize_std(sc, o, b, workspace, n_cus, st);
 }

@@ -57,11 +57,15 @@
 #ifndef HPMVS_WG_REGIONS
 #define HPMVS_WG_REGIONS 4
 #endif
-// This file is compiled twice (kernel_optimize_big.hip includes it with HPMVS_VARIANT_BIG, 58 slots per wavefront and 2
-// regions): the externally visible names of the second copy carry a suffix, and it has no open-batch kernel.
-#ifdef HPMVS_VARIANT_BIG
-#define HPMVS_V(name) name##_big
-#define HPMVS_VK(name) name##_big
+// This file is compiled four times: as it is (29 slots per wavefront, 4 regions), from kernel_optimize_big.hip (58
+// slots, 2 regions), and twice more with the throughput-mode window sums (kernel_optimize_tree.hip,
+// kernel_optimize_big_tree.hip: photometric.hpp, HPMVS_FAST_SUMS).  The externally visible names of the other copies carry
+// HPMVS_VARIANT_SUFFIX, and only this copy has the open-batch kernel.
+#ifdef HPMVS_VARIANT_SUFFIX
+#define HPMVS_CAT2(a, b) a##b
+#define HPMVS_CAT(a, b) HPMVS_CAT2(a, b)
+#define HPMVS_V(name) HPMVS_CAT(name, HPMVS_VARIANT_SUFFIX)
+#define HPMVS_VK(name) HPMVS_CAT(name, HPMVS_VARIANT_SUFFIX)
 #else
 #define HPMVS_VK(name) name  /* the standard kernel keeps its name (profiles, rocprof summaries) */
 #define HPMVS_V(name) name##_std
@@ -165,6 +169,10 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
     uint16_t* lists = (uint16_t*)((char*)queue + kCounterBytes) + (size_t)gw * kP * kRow;
     uint16_t* row = &lists[(lane < kP ? lane : 0) * kRow];
     uint4* park = (uint4*)((char*)queue + kCounterBytes + (size_t)W * n_wgs * kP * kRow * sizeof(uint16_t)) + (size_t)gw * kPark16;
+    // ... and its result rows: per slot one row of kRow floats, where the photometric service leaves a request's per-image
+    // values until the requesting lane adds them up (wave_eval_rows, step 7)
+    const GlobalRows erows{(float*)((char*)queue + kCounterBytes + (size_t)W * n_wgs * kP * kRow * sizeof(uint16_t) +
+                                    (size_t)W * n_wgs * kPark16 * 16) + (size_t)gw * kP * kRow, kRow};
 
     // ---- per-lane slot state
     // Small batches are spread over as many workgroups as possible (a wavefront with fewer busy slots has shorter
@@ -496,6 +504,9 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
             __builtin_amdgcn_s_setprio(HPMVS_BQ_PRIO);  // the region is the contended resource: hold it as briefly as possible
 #endif
             int ret = BQ_DONE;
+#ifdef HPMVS_HOLD_DELAY  /* experiment: how sensitive is the launch to the time a state region is held? */
+            for (int dly = 0; dly < HPMVS_HOLD_DELAY; dly++) __builtin_amdgcn_s_sleep(127);
+#endif
             if (op == OPQ_START) ret = bq_start(B, x0, lbv, ubv, dx, 1.e-7, 1000);
             if (op == OPQ_STEP) ret = bq_step(B, res_f);
             double xe[3] = {0, 0, 0};
@@ -583,7 +594,7 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
             PackedRes r;
             r.obj = 2.0; r.keep = 0ull; r.incc_sum = 0.0f; r.ngrabs = 0;
             __builtin_amdgcn_s_setprio(0);
-            wave_eval_rows<false>(sc, o, (const uint16_t*)row, pending, q, r, nullptr);
+            wave_eval_rows<false>(sc, o, (const uint16_t*)row, pending, q, r, erows);
             __builtin_amdgcn_s_setprio(HPMVS_A_PRIO);
             if (op != OP_NONE) {
                 res_f = r.obj;
@@ -615,7 +626,7 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
 __global__ void __launch_bounds__(64 * HPMVS_WG_WAVES, HPMVS_WAVES_PER_EU) HPMVS_VK(optimize_kernel)(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
     optimize_body<false, HPMVS_WG_WAVES, HPMVS_WG_REGIONS>(sc, o, b, queue);
 }
-#ifndef HPMVS_VARIANT_BIG
+#ifndef HPMVS_VARIANT_SUFFIX
 __global__ void __launch_bounds__(128, HPMVS_WAVES_PER_EU) optimize_service_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* queue) {
     optimize_body<true, 2, 1>(sc, o, b, queue);
 }
@@ -636,15 +647,16 @@ static int max_workgroups(int n_cus, int waves, int regions) {
 }
 
 size_t HPMVS_V(optimize_workspace_bytes)(int n_cus) {
-    // counter block + per wavefront: kP image-list rows and one parking buffer for the optimiser states
+    // counter block + per wavefront: kP image-list rows, one parking buffer for the optimiser states, kP result rows
     const size_t waves = (size_t)HPMVS_WG_WAVES * max_workgroups(n_cus, HPMVS_WG_WAVES, HPMVS_WG_REGIONS);
-    return kCounterBytes + waves * kP * kRow * sizeof(uint16_t) + waves * (size_t)kPark16 * 16;
+    return kCounterBytes + waves * kP * kRow * sizeof(uint16_t) + waves * (size_t)kPark16 * 16 + waves * kP * kRow * sizeof(float);
 }
 
-#ifndef HPMVS_VARIANT_BIG
+#ifndef HPMVS_VARIANT_SUFFIX
 // open batch (b.svc_ctrl set): a fixed grid of `wgs` two-wavefront workgroups (one per CU leaves room for batch launches beside it)
 size_t optimize_workspace_bytes_for(int wgs) {
-    return kCounterBytes + (size_t)2 * wgs * kP * kRow * sizeof(uint16_t) + (size_t)2 * wgs * (size_t)kPark16 * 16;
+    return kCounterBytes + (size_t)2 * wgs * kP * kRow * sizeof(uint16_t) + (size_t)2 * wgs * (size_t)kPark16 * 16 +
+           (size_t)2 * wgs * kP * kRow * sizeof(float);
 }
 size_t optimize_stage_bytes_for(int wgs) { return (size_t)2 * wgs * kP * kSvcOutDwords * sizeof(uint32_t); }
 void launch_optimize_service(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int wgs,

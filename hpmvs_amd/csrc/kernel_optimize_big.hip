@@ -7,5 +7,5 @@
 // from 1600 patches per CU upwards.
 #define BQ_P 58
 #define HPMVS_WG_REGIONS 2
-#define HPMVS_VARIANT_BIG 1
+#define HPMVS_VARIANT_SUFFIX _big
 #include "kernel_optimize.hip"

@@ -68,6 +68,7 @@ __global__ void __launch_bounds__(64) objective_kernel(DevScene sc, DevOptions o
                                                        const double* __restrict__ xs, double* __restrict__ f_out,
                                                        int32_t* __restrict__ ngrabs_out) {
     const int lane = lane_id();
+    __shared__ float erow_s[kGroups * kMaxImages];  // the requests' result rows (wave_eval_rows)
     for (int base = blockIdx.x * kGroups; base < b.n; base += gridDim.x * kGroups) {
         const int p = base + lane;
         const bool mine = lane < kGroups && p < b.n;
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(64) objective_kernel(DevScene sc, DevOptions o
         }
         PackedRes r;
         r.obj = 2.0; r.keep = 0ull; r.incc_sum = 0.0f; r.ngrabs = 0;
-        wave_eval_rows<false>(sc, o, list, __ballot(mine && ok), q, r, nullptr);
+        wave_eval_rows<false>(sc, o, list, __ballot(mine && ok), q, r, LdsRows{erow_s, kMaxImages});
         if (mine) {
             f_out[p] = ok ? r.obj : 2.0;
             if (ngrabs_out) ngrabs_out[p] = ok ? r.ngrabs : 0;
@@ -140,7 +141,8 @@ __global__ void __launch_bounds__(64) inccs_kernel(DevScene sc, DevOptions o, De
         }
         PackedRes r;
         r.obj = 2.0; r.keep = 0ull; r.incc_sum = 0.0f; r.ngrabs = 0;
-        wave_eval_rows<true>(sc, o, list, __ballot(mine && ok), q, r, row);
+        // the requests' result rows are the output rows themselves: requesting lane r <-> patch base + r
+        wave_eval_rows<true>(sc, o, list, __ballot(mine && ok), q, r, GlobalRows{out + (size_t)base * b.max_images, b.max_images});
         if (mine) {
             // the evaluator stored the grabbed images' values and the reference image's 0 (r.keep = grabbed mask);
             // the rest is 2.0

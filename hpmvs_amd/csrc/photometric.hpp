@@ -133,14 +133,16 @@ struct Prep {
 // before it computes any of them: load_view issues the view's table loads, prep_from_view does the arithmetic
 // (branch-free: the gates only decide `ok` at the end, exactly as sampleTexture's early returns do;
 //  level sizes as w0 >> l: the pyramid halves with integer division, Image.cpp:55-63).  The pointer of the chosen
-// level is the one dependent load left.
-struct ViewRegs { float P[12]; float cx, cy, cz, fsum; int w0, h0; const DevView* vp; };
+// level comes from the table too: a view's levels are one allocation and their offsets travel with the view's row.
+constexpr int kGrabLevels = 5;  // sampleTexture clamps its level to MAXLEVEL - 1 <= 4 (HpmvsOptions.h: MAXLEVEL = 5); deeper options take the load
+struct ViewRegs { float P[12]; float cx, cy, cz, fsum; int w0, h0; const uint8_t* pix0; const DevView* vp; };
 __device__ __forceinline__ ViewRegs load_view(const DevView& V) {
     ViewRegs r;
 #pragma unroll
     for (int k = 0; k < 12; k++) r.P[k] = V.P0[k];
     r.cx = V.center[0]; r.cy = V.center[1]; r.cz = V.center[2];
     r.fsum = V.fsum; r.w0 = V.w[0]; r.h0 = V.h[0];
+    r.pix0 = V.pix[0];
     r.vp = &V;
     return r;
 }
@@ -155,7 +157,17 @@ __device__ __forceinline__ Prep prep_from_view(const ViewRegs& V, const DevOptio
     const float g = (n2 > 0.0f) ? g_unit : g_raw;
     const bool angle_ok = !((double)g < o.cos_max_d);
     const int lvl = level_clamped(scale, V.fsum, nn, o.MAXLEVEL - 1);
-    r.pix = V.vp->pix[lvl];
+    {   // the chosen level's pixels: pix[0] + off[lvl].  A view's levels are one allocation, level k + 1 behind level k
+        // at the next multiple of 256 bytes past its 3 * w * h + 16 bytes (capi.hip, scene_set_view): the offset is
+        // arithmetic on the level-0 size, so no load depends on the level
+        unsigned ofs = 0u;
+#pragma unroll
+        for (int k = 0; k < kGrabLevels - 1; k++) {
+            const unsigned nb = (3u * (unsigned)(V.w0 >> k) * (unsigned)(V.h0 >> k) + 16u + 255u) & ~255u;
+            ofs += (k < lvl) ? nb : 0u;
+        }
+        r.pix = (lvl < kGrabLevels) ? V.pix0 + ofs : V.vp->pix[lvl];
+    }
     float cu, cv, xu, xv, yu, yv;
     project0(V.P, c[0], c[1], c[2], cu, cv);
     project0(V.P, c[0] + pxa[0], c[1] + pxa[1], c[2] + pxa[2], xu, xv);
@@ -305,6 +317,7 @@ constexpr int kGroups = 9;               // grabs per pass: nine 7-lane groups, 
 #endif
 constexpr int kJobSets = HPMVS_JOB_SETS;  // job lanes are used this many times over: up to 64 * kJobSets (request, image) pairs per batch
 constexpr int kRowVals = 3 * kTex;       // 21 float32 values (7 texels x RGB) per lane
+constexpr int kFinChunk = 8;             // images per step of the requesting lanes' accumulation (most requests have <= 8)
 
 // value held by lane - 1 (lane 0 receives 0): DPP wave_shr:1, folded by the compiler into the consuming add
 __device__ __forceinline__ float lane_prev(float v) {
@@ -348,23 +361,95 @@ __device__ __forceinline__ void row_chain_pair(const float (&va)[N], const float
     outa = out.x; outb = out.y;
 }
 
+// The three window sums of a grab.  Parity mode (the default, what every test runs): Patch2d's sequential order through
+// the lane chains above.  HPMVS_FAST_SUMS (an opt-in THROUGHPUT build of the kernel, `HPMVS_SUMS=tree`): every lane sums
+// its own row first and the seven row sums are added in row order -- 7 (or 21) + 6 adds where the chains need 49 (147),
+// the same mathematical sum with a different rounding order, i.e. one more member of the family of orders a real
+// hpmvs binary may have (Eigen's reductions already differ between ISAs).  Not bit-identical to the
+// oracle; profiles/r04/sums_modes.json holds what it costs in agreement and buys in time.
+#ifndef HPMVS_FAST_SUMS
+#define HPMVS_FAST_SUMS 0
+#endif
+#ifndef HPMVS_TAKE_OVER
+#define HPMVS_TAKE_OVER 1  // idle groups take over images of the busiest ones (wave_eval_rows, step 1b)
+#endif
+template <int N>
+__device__ __forceinline__ float window_sum(const float (&v)[N]) {
+#if HPMVS_FAST_SUMS
+    float a = v[0];
+#pragma unroll
+    for (int i = 1; i < N; i++) a += v[i];
+    float out = a;
+#pragma unroll
+    for (int s = 1; s < kTex; s++) out = lane_prev(out) + a;  // after step s the lanes with yy >= s hold rows yy-s .. yy
+    return out;
+#else
+    return row_chain<N>(v);
+#endif
+}
+__device__ __forceinline__ void mean_chains(const float (&vr)[kTex], const float (&vg)[kTex], const float (&vb)[kTex],
+                                            float& s0, float& s1, float& s2) {
+#if HPMVS_FAST_SUMS
+    s0 = window_sum<kTex>(vr); s1 = window_sum<kTex>(vg); s2 = window_sum<kTex>(vb);
+#else
+    // the red and green chains run in the two halves of one register pair (v_pk_add_f32), the blue one beside them
+    row_chain_pair<kTex>(vr, vg, s0, s1);
+    s2 = row_chain<kTex>(vb);
+#endif
+}
+
+// maximum over the lanes of `v`
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    return v;
+}
+
+// Where the per-image results of a batch's requests wait until the requesting lanes add them up in the reference's
+// order: one row of floats per requesting lane (row of lane p = base + p * stride).  Global memory in the refinement
+// kernel (the launch workspace, L2 resident: a CU's own stores and loads are coherent through its vector cache) and in
+// the stand-alone setINCCs kernel (its output rows); LDS in the stand-alone objective kernel.
+struct GlobalRows {
+    float* base; int stride;
+    typedef __attribute__((address_space(1))) float gfloat;
+    __device__ __forceinline__ void store(int p, int k, float v) const { ((gfloat*)(unsigned long long)(base + (size_t)p * stride))[k] = v; }
+    __device__ __forceinline__ float load(int p, int k) const { return ((const gfloat*)(unsigned long long)(base + (size_t)p * stride))[k]; }
+};
+struct LdsRows {
+    float* base; int stride;
+    typedef __attribute__((address_space(3))) float lfloat;
+    __device__ __forceinline__ void store(int p, int k, float v) const { ((lfloat*)base)[p * stride + k] = v; }
+    __device__ __forceinline__ float load(int p, int k) const { return ((const lfloat*)base)[p * stride + k]; }
+};
+
 // list: the calling lane's own image list (ids; read only for lanes with a pending request).  Must be called by
-// all 64 lanes.  WRITE_INCCS (the stand-alone setINCCs kernel): `incc_out` is the requesting lane's output row;
-// the values of the usable images and the 0 of the reference image are stored there, and out.keep returns the
-// mask of the grabbed images instead of the thresholded one.
-template <bool WRITE_INCCS, typename ListT>
+// all 64 lanes.  rows: see above (the row of a requesting lane holds at least min(its image count, stride) floats).
+// WRITE_INCCS (the stand-alone setINCCs kernel): the rows ARE the output -- the values of the usable images and the 0 of
+// the reference image stay there, and out.keep returns the mask of the grabbed images instead of the thresholded one.
+//
+// Round 4: a grab's result is no longer accumulated inside the group that computed it.  The group's first lane stores it
+// (1 - ncc, or its robust form) at [request][image] of `rows`, and when the batch's passes are over every requesting lane
+// adds up its own row in index order -- objective_fn's float64 sum (PatchOptimizer.cpp:299-309), setINCCs' values and
+// std::accumulate over them (:462-472, :161-167) -- lane-parallel over the batch's requests.  Since the ORDER of the
+// reference's accumulations now lives in that last step only, any group may compute any image of any request whose
+// normalised reference texels it holds: a group that runs out of work takes the upper half of the images the busiest
+// group still has to do (with a copy of its reference texels: 21 ds_bpermute), instead of idling until the batch's
+// longest request is through.  At BASELINE configs[2] 12.5 % of the group-passes were idle that way; for a lone patch
+// (the ramp-down of a launch, single-patch callers) the images of its one request now run side by side.
+template <bool WRITE_INCCS, typename ListT, typename Rows>
 __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOptions& o, const ListT* list,
                                                unsigned long long pending, const PackedReq& q, PackedRes& out,
-                                               float* incc_out) {
+                                               const Rows rows) {
     const int lane = lane_id();
     const int grp = lane / kTex;            // 0..9; 9 = the spare lane
     const int yy = lane - grp * kTex;       // window row of this lane
     const bool glane = grp < kGroups;
     const int last = glane ? grp * kTex + (kTex - 1) : lane;  // lane that ends the group's chains
+    const int gl0 = lane - yy;              // first lane of my group
     const int q_refsel = q.obj_mode ? 0 : q.ref;
+    const int q_userob = (q.obj_mode || q.robust) ? 1 : 0;
     const unsigned long long listbits = (unsigned long long)list;
     const int list_lo = (int)(listbits & 0xffffffffull), list_hi = (int)(listbits >> 32);
-    const unsigned long long outbits = (unsigned long long)incc_out;
 
     unsigned long long rem = pending;
     while (rem) {
@@ -477,53 +562,77 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
             }
         }
 #endif
-        if (inbatch && !refok) {  // sampleTexture false for the reference image: plateau value / all 2.0
-            if (q.obj_mode) out.obj = 2.0;
-            else {
-                float s = 0.0f;
-                for (int k = 0; k < q.nimg; k++) s += 2.0f;
-                out.keep = 0ull;
-                out.incc_sum = s;
-            }
-        }
         PH_T(t2);
         PH_ADD(t1, t2, 13);
 
-        // OBJ results are parked on the requesting lane and divided once, lane-parallel, after the last pass
-        double d_val = 0.0;
-        int d_nok = -1;
-
-        // ---- state of the request my group serves (identical on the 7 lanes of a group)
-        int g_req = -1, g_off = 0, g_ref = 0, g_mode = 0, g_rob = 0, g_cur = 0, g_nok = 0, g_ngr = 0, g_nextk = 0, g_np = 0;
+        // ---- the grab my group is on (identical on the 7 lanes of a group)
+        int g_req = -1, g_off = 0, g_ref = 0, g_userob = 0, g_cur = 0;
         bool g_isref = false;
-        unsigned long long g_ok = 0ull, g_okall = 0ull, g_keep = 0ull, g_out = 0ull;
-        float g_thr = 0.0f, g_sum = 0.0f;
-        double g_val = 0.0;
+        unsigned long long g_ok = 0ull;  // images of the request this group still has to do after the current one
         float refn[kRowVals];  // my row of the normalised reference texture
 #pragma unroll
         for (int i = 0; i < kRowVals; i++) refn[i] = 0.0f;
 
         for (;;) {
             PH_T(t3);
-            // ---- 1. idle groups take the next pending requests, in request order
+            // ---- 1. idle groups take the next pending requests, long requests first (fewest idle group-passes at the
+            //         end of the batch): three length classes
             {
                 unsigned long long idle = __ballot(glane && yy == 0 && g_req < 0);
                 while (todo && idle) {
-                    // long requests first (fewest idle group-passes at the end of the round): three length classes
                     const unsigned long long c6 = todo & len6, c4 = todo & len4;
                     const int p = __ffsll((long long)(c6 ? c6 : (c4 ? c4 : todo))) - 1;
                     todo &= ~(1ull << p);
                     const int gl = __ffsll((long long)idle) - 1;  // first lane of the group
                     idle &= idle - 1ull;
-                    const int r_off = bcast_i(myoff, p), r_np = bcast_i(q.nimg, p), r_ref = bcast_i(q_refsel, p);
-                    const int r_mode = bcast_i(q.obj_mode, p), r_rob = bcast_i(q.robust, p);
-                    const float r_thr = bcast_f(q.thr, p);
+                    const int r_off = bcast_i(myoff, p), r_ref = bcast_i(q_refsel, p), r_rob = bcast_i(q_userob, p);
                     const unsigned long long r_ok = bcast_u64(myok, p);
-                    const unsigned long long r_out = WRITE_INCCS ? bcast_u64(outbits, p) : 0ull;
-                    if (lane - yy == gl) {
-                        g_req = p; g_off = r_off; g_np = r_np; g_ref = r_ref; g_mode = r_mode; g_rob = r_rob; g_thr = r_thr;
-                        g_okall = r_ok; g_ok = r_ok & ~(1ull << r_ref); g_out = r_out;
+                    if (gl0 == gl) {
+                        g_req = p; g_off = r_off; g_ref = r_ref; g_userob = r_rob;
+                        g_ok = r_ok & ~(1ull << r_ref);
                         g_cur = r_ref; g_isref = true;
+                    }
+                }
+                // ---- 1b. nothing left to hand out and groups are idle: they take over the upper half of what the
+                //          busiest groups still have to do (see the header comment).  The batch ends with the group that
+                //          has the most images left, so a round of take-overs pays only if EVERY group at that maximum
+                //          gets a helper; the search is scalar code over the nine group leaders (no cross-lane traffic),
+                //          the reference texels of all take-overs of a round travel in one set of 21 ds_bpermute.
+                while (HPMVS_TAKE_OVER && idle) {  // (only reached with todo == 0)
+                    const int left = (glane && g_req >= 0) ? __popcll(g_ok) : 0;   // identical on a group's lanes
+                    int best = 0, n_best = 0, any_ref = 0;
+                    unsigned long long vmask = 0ull;  // leaders of the groups at the maximum
+#pragma unroll
+                    for (int g = 0; g < kGroups; g++) {
+                        const int l = bcast_i(left, g * kTex);
+                        if (l > best) { best = l; n_best = 0; vmask = 0ull; }
+                        if (l == best && l > 0) { n_best++; vmask |= 1ull << (g * kTex); }
+                    }
+                    if (best < 1 || __popcll(idle) < n_best) break;
+                    for (unsigned long long t = vmask; t; t &= t - 1ull) any_ref |= bcast_i(g_isref ? 1 : 0, __ffsll((long long)t) - 1);
+                    if (any_ref && best < 2) break;  // a group that has not sampled its reference image yet cannot hand its texels over
+                    int src = lane;  // lane my reference texels come from (thieves of groups that have theirs: the victim's lane)
+                    bool moved = false;
+                    for (unsigned long long t = vmask; t; t &= t - 1ull) {
+                        const int vl = __ffsll((long long)t) - 1;  // the victim's first lane
+                        const int tl = __ffsll((long long)idle) - 1;
+                        idle &= idle - 1ull;
+                        const int v_isref = bcast_i(g_isref ? 1 : 0, vl);
+                        const int take = v_isref ? best / 2 : (best + 1) / 2;
+                        unsigned long long hi = bcast_u64(g_ok, vl);
+                        for (int i = 0; i < best - take; i++) hi &= hi - 1ull;  // the victim keeps its lowest images
+                        const int r_req = bcast_i(g_req, vl), r_off = bcast_i(g_off, vl), r_ref = bcast_i(g_ref, vl), r_rob = bcast_i(g_userob, vl);
+                        if (gl0 == vl) g_ok &= ~hi;
+                        if (gl0 == tl && glane) {
+                            g_req = r_req; g_off = r_off; g_ref = r_ref; g_userob = r_rob;
+                            if (v_isref) { g_cur = r_ref; g_isref = true; g_ok = hi; }
+                            else { g_cur = __ffsll((long long)hi) - 1; g_ok = hi & (hi - 1ull); g_isref = false; src = vl + yy; }
+                        }
+                        moved |= !v_isref;
+                    }
+                    if (moved) {  // (wave-uniform) the victims' normalised reference texels, row by row
+#pragma unroll
+                        for (int i = 0; i < kRowVals; i++) refn[i] = shfl_f(refn[i], src);
                     }
                 }
             }
@@ -608,10 +717,8 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
                 float vr[kTex], vg[kTex], vb[kTex];
 #pragma unroll
                 for (int xx = 0; xx < kTex; xx++) { vr[xx] = t[3 * xx]; vg[xx] = t[3 * xx + 1]; vb[xx] = t[3 * xx + 2]; }
-                // the red and green chains run in the two halves of one register pair (v_pk_add_f32), the blue one beside them
-            float s0, s1;
-            row_chain_pair<kTex>(vr, vg, s0, s1);
-            const float s2 = row_chain<kTex>(vb);
+                float s0, s1, s2;
+                mean_chains(vr, vg, vb, s0, s1, s2);
                 a0 = div_by(shfl_f(s0, last), 1.0 / 49.0);
                 a1 = div_by(shfl_f(s1, last), 1.0 / 49.0);
                 a2 = div_by(shfl_f(s2, last), 1.0 / 49.0);
@@ -624,7 +731,7 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
                     const float f0 = a0 - t[3 * xx], f1 = a1 - t[3 * xx + 1], f2 = a2 - t[3 * xx + 2];
                     sq[xx] = f0 * f0 + f1 * f1 + f2 * f2;
                 }
-                float v2 = sqrtf(div_by(shfl_f(row_chain<kTex>(sq), last), 1.0 / 147.0));
+                float v2 = sqrtf(div_by(shfl_f(window_sum<kTex>(sq), last), 1.0 / 147.0));
                 if (v2 == 0.0f) v2 = 1.0f;
                 iv = recip64(v2);
             }
@@ -646,71 +753,84 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
                 float pr[kRowVals];
 #pragma unroll
                 for (int i = 0; i < kRowVals; i++) pr[i] = refn[i] * t[i];
-                raw = 1.0f - div_by(shfl_f(row_chain<kRowVals>(pr), last), 1.0 / 147.0);
+                raw = 1.0f - div_by(shfl_f(window_sum<kRowVals>(pr), last), 1.0 / 147.0);
                 rob = robustincc(raw);
             }
             PH_T(t7);
             PH_ADD(t6, t7, 21);
-            PH_T(t7b);
 
-            // ---- 6. the request's accumulations, in the reference's loop order (identical on the group's lanes)
+            // ---- 6. the grab's result goes to its place in the request's row; next image of the request, or idle
             if (act) {
-                if (g_isref) {
-                    g_ngr = 1; g_val = 0.0; g_nok = 0; g_keep = 0ull; g_sum = 0.0f; g_nextk = 0;
-                    if (WRITE_INCCS) { if (yy == 0 && g_out) ((float*)g_out)[g_ref] = 0.0f; }
-                } else {
-                    g_ngr++;
-                    if (g_mode) {  // objective_fn (PatchOptimizer.cpp:299-309)
-                        g_val += (double)rob;
-                        g_nok++;
-                    } else {       // setINCCs (PatchOptimizer.cpp:462-472)
-                        const float e = g_rob ? rob : raw;
-                        if (e < 1.0f - g_thr) g_keep |= 1ull << g_cur;
-                        // std::accumulate over inccs in index order: the images between the previous usable one
-                        // and this one hold 2.0 (or 0.0 for the reference image: adding it changes nothing)
-                        const unsigned long long below = (1ull << g_cur) - 1ull, done = (1ull << g_nextk) - 1ull;
-                        const int gap = __popcll(~g_okall & ~(1ull << g_ref) & below & ~done);
-                        for (int r = 0; r < gap; r++) g_sum += 2.0f;
-                        g_sum += e;
-                        g_nextk = g_cur + 1;
-                        if (WRITE_INCCS) { if (yy == 0 && g_out) ((float*)g_out)[g_cur] = e; }
-                    }
-                }
-            }
-            // ---- 7. next image of the request, or hand the results to the requesting lane
-            bool fin = false;
-            if (act) {
+                if (!g_isref && yy == 0) rows.store(g_req, g_cur, g_userob ? rob : raw);
                 if (g_ok) { g_cur = __ffsll((long long)g_ok) - 1; g_ok &= g_ok - 1ull; g_isref = false; }
-                else {
-                    fin = true;
-                    if (!g_mode) {
-                        const unsigned long long all = (g_np >= 64) ? ~0ull : ((1ull << g_np) - 1ull);
-                        const unsigned long long done = (g_nextk >= 64) ? ~0ull : ((1ull << g_nextk) - 1ull);
-                        const int gap = __popcll(~g_okall & ~(1ull << g_ref) & all & ~done);
-                        for (int r = 0; r < gap; r++) g_sum += 2.0f;
-                        if (0.0f < 1.0f - g_thr) g_keep |= 1ull << g_ref;          // inccs[ref] = 0
-                        if (2.0f < 1.0f - g_thr) g_keep |= ~g_okall & all;          // failed grabs hold 2.0
-                    }
-                }
+                else g_req = -1;
             }
-            for (unsigned long long fm = __ballot(fin && yy == 0); fm; fm &= fm - 1ull) {
-                const int gl = __ffsll((long long)fm) - 1;
-                const int p = bcast_i(g_req, gl);
-                const int r_mode = bcast_i(g_mode, gl), r_nok = bcast_i(g_nok, gl), r_ngr = bcast_i(g_ngr, gl);
-                const double r_val = bcast_d(g_val, gl);
-                const unsigned long long r_keep = bcast_u64(WRITE_INCCS ? g_okall : g_keep, gl);  // WRITE_INCCS: which images were grabbed
-                const float r_sum = bcast_f(g_sum, gl);
-                if (lane == p) {
-                    out.ngrabs += r_ngr;
-                    if (r_mode) { d_val = r_val; d_nok = r_nok; }
-                    else { out.keep = r_keep; out.incc_sum = r_sum; }
-                }
-            }
-            if (fin) g_req = -1;
             PH_T(t8);
-            PH_ADD(t7b, t8, 22);
+            PH_ADD(t7, t8, 22);
         }
-        if (d_nok >= 0) out.obj = (d_nok < o.MIN_IMAGES_PER_PATCH - 1) ? 2.0 : d_val / (double)d_nok;
+
+        // ---- 7. the reference's accumulations, in index order, on the requesting lanes (lane-parallel over the batch's
+        //         requests): objective_fn (PatchOptimizer.cpp:299-309), setINCCs + filterImagesNCC / std::accumulate
+        //         (:462-472, :144-151, :161-167).  A failed grab holds 2.0, the reference image 0 (adding it changes
+        //         nothing: the running sums are never -0).
+        PH_T(t9);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the groups' stores are out
+        __builtin_amdgcn_wave_barrier();
+        if (inbatch && !refok) {  // sampleTexture false for the reference image: plateau value / all 2.0
+            if (q.obj_mode) out.obj = 2.0;
+            else {
+                float s = 0.0f;
+                for (int k = 0; k < q.nimg; k++) s += 2.0f;
+                out.keep = 0ull;
+                out.incc_sum = s;
+            }
+        }
+        {
+            const bool fin = inbatch && refok;
+            const float thr1 = 1.0f - q.thr;
+            double val = 0.0;
+            int nok = 0;
+            float s = 0.0f;
+            unsigned long long keep = 0ull;
+            const int kmax = rows.stride - 1;
+            for (int k0 = 0; __any(fin && k0 < q.nimg); k0 += kFinChunk) {
+                float e[kFinChunk];
+#pragma unroll
+                for (int j = 0; j < kFinChunk; j++) e[j] = 2.0f;
+                if (fin && k0 < q.nimg) {
+#pragma unroll
+                    for (int j = 0; j < kFinChunk; j++) { const int kk = k0 + j < kmax ? k0 + j : kmax; e[j] = rows.load(lane, kk); }
+                }
+#pragma unroll
+                for (int j = 0; j < kFinChunk; j++) {
+                    const int k = k0 + j;
+                    const bool in = fin && k < q.nimg;
+                    const bool okk = (myok >> (k & 63)) & 1ull;
+                    const bool isref = k == q_refsel;
+                    const unsigned long long bit = 1ull << (k & 63);
+                    // objective_fn: the usable images other than the reference
+                    const bool add_o = in && okk && !isref;
+                    val += add_o ? (double)e[j] : 0.0;
+                    nok += add_o ? 1 : 0;
+                    // setINCCs: every image; inccs[ref] = 0
+                    const float v = okk ? e[j] : 2.0f;
+                    s += (in && !isref) ? v : 0.0f;
+                    const bool kp = in && (isref ? (0.0f < thr1) : (v < thr1));
+                    keep |= kp ? bit : 0ull;
+                }
+            }
+            if (fin) {
+                out.ngrabs += mylen;
+                if (q.obj_mode) out.obj = (nok < o.MIN_IMAGES_PER_PATCH - 1) ? 2.0 : val / (double)nok;
+                else {
+                    out.keep = WRITE_INCCS ? myok : keep;
+                    out.incc_sum = s;
+                    if (WRITE_INCCS) rows.store(lane, q_refsel, 0.0f);
+                }
+            }
+        }
+        PH_T(t10);
+        PH_ADD(t9, t10, 16);
     }
 }
 

@@ -419,3 +419,61 @@ def test_batch_launch_while_single_patch_callers_keep_an_open_batch_busy(tiny_se
     assert before > 0 and after > before, (before, after)
     assert np.array_equal(big.ok.reshape(100, n), np.tile(ref.ok, (100, 1)))
     assert np.array_equal(big.center.reshape(100, n, 4)[37], ref.center)
+
+
+def test_tree_sums_mode_is_opt_in_and_stays_inside_the_stated_tolerance(tiny_scene, tiny_seeds, oracle_scene, tmp_path):
+    """HPMVS_SUMS=tree selects the throughput build of the kernel (every lane sums its window row first, the seven row
+    sums are added in row order: photometric.hpp, HPMVS_FAST_SUMS).  It is NOT bit-identical to the oracle -- the
+    sequential order of Patch2d.hpp:37-84 is what the default build keeps -- so it is held to the DISTRIBUTIONAL tolerance
+    SURVEY 8d states for refinement against an arbitrary hpmvs binary: decisions >= 99 % equal on this
+    200-seed scene, mean |d ncc| <= 5e-3, >= 80 % of the patches in the same basin.  The default (no variable, or
+    `exact`) must be byte-identical to the in-process run that every other test compares with the oracle."""
+    import os, subprocess, sys
+    from hpmvs_amd import api
+    from oracle import oracle as orc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from hpmvs_amd import api, synth
+scene = synth.make_scene(3, 640, 480, n_waves=24)
+seeds = synth.make_seeds(scene, 200, start_level=2)
+g = api.Scene(scene)
+b = api.Batch.from_seeds(seeds)
+api.optimize_batch(g, b)
+big = api.Batch.from_seeds(seeds, np.tile(np.arange(len(seeds.scale)), 40))   # 8000 patches: several wavefronts per workgroup
+api.optimize_batch(g, big)
+np.savez(sys.argv[1], ok=b.ok, center=b.center, normal=b.normal, fmin=b.fmin, nevals=b.nevals, stage=b.stage,
+         big_ok=big.ok, big_center=big.center)
+''' % root
+    outs = {}
+    for mode in ("exact", "tree"):
+        f = str(tmp_path / f"sums_{mode}.npz")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, HPMVS_SUMS=mode), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = np.load(f)
+    n = len(tiny_seeds.scale)
+    P = orc.patches_from_seeds(tiny_seeds)
+    orc.optimize_batch(oracle_scene, P, n_threads=8)
+    ok_cpu = np.array([p.stage == 0 for p in P])
+    ex, tr = outs["exact"], outs["tree"]
+    # exact: the oracle's decisions and bits
+    assert np.array_equal(ex["ok"].astype(bool), ok_cpu)
+    for k in np.nonzero(ok_cpu)[0]:
+        assert np.array_equal(np.array(P[k].center[:], dtype=np.float32), ex["center"][k]), k
+    # tree: inside the distributional tolerance
+    ok_t = tr["ok"].astype(bool)
+    agree = float((ok_t == ok_cpu).mean())
+    both = np.nonzero(ok_t & ok_cpu)[0]
+    unrob = lambda f: f / (1.0 - 3.0 * f)
+    dncc = float(np.mean([abs(unrob(P[k].fmin) - unrob(tr["fmin"][k])) for k in both]))
+    basin = []
+    for k in both:
+        dd = np.linalg.norm(np.array(P[k].center[:3]) - tr["center"][k, :3]) / float(tiny_seeds.scale[k])
+        cs = float(np.clip(np.dot(np.array(P[k].normal[:3]), tr["normal"][k, :3]), -1, 1))
+        basin.append(dd < 0.25 and np.degrees(np.arccos(cs)) < 2.0)
+    assert agree >= 0.99 and dncc <= 5e-3 and np.mean(basin) >= 0.80, (agree, dncc, float(np.mean(basin)))
+    assert not np.array_equal(tr["fmin"], ex["fmin"])  # it really is another build
+    # the mode is deterministic across batch compositions, like the exact one
+    assert np.array_equal(tr["big_ok"].reshape(40, n), np.tile(tr["ok"], (40, 1)))
+    assert np.array_equal(tr["big_center"].reshape(40, n, 4)[23], tr["center"])
