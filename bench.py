@@ -471,6 +471,37 @@ def issue_roofline(rec):
             "source": rec.get("source")}
 
 
+def usable_cores(hw_threads):
+    """How many cores this process may really use: the affinity mask and the cgroup CPU quota.  The GPU boxes of this
+    pool are 2 x 64-core EPYC (256 hardware threads visible) behind a CFS quota of 16 CPUs (cpu.max = "1600000 100000"):
+    256 OpenMP threads then share 16 cores' worth of time and are throttled in bursts -- the CPU leg of rounds 1-3 ran
+    that way and 'scaled' 9x (profiles/r04/cpu_scaling_c1.txt: linear to 16 threads, 25x at 32, falling beyond).  The
+    baseline is timed with as many threads as the quota grants and says so."""
+    n = hw_threads
+    note = "none found"
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            lim = max(1, int(float(q) / float(per) + 0.5))
+            note = f"cgroup cpu.max = {q} {per}: {lim} CPUs"
+            n = min(n, lim)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                lim = max(1, int(q / per + 0.5))
+                note = f"cgroup cfs quota {q}/{per}: {lim} CPUs"
+                n = min(n, lim)
+        except Exception:
+            pass
+    return max(1, n), note
+
+
 def cpu_leg(out, args, scene, seeds, n_seeds, work, ok, nevals, stage):
     """CPU baseline + parity on a bounded sample of the same seeds (the oracle is the checker, never the product)."""
     from oracle import oracle as orc
@@ -478,7 +509,8 @@ def cpu_leg(out, args, scene, seeds, n_seeds, work, ok, nevals, stage):
     idx = np.arange(m)
     osc = orc.OracleScene(scene)
     P = orc.patches_from_seeds(seeds, idx)
-    cores = os.cpu_count() or 1
+    hw_threads = os.cpu_count() or 1
+    cores, quota_note = usable_cores(hw_threads)
     which = orc.best_optimizer()
     orc.optimize_batch(osc, P, which=which, n_threads=cores)   # parity sample
     # timing: a bigger bounded sample so that thread start-up does not dominate (a few seconds of all-core work)
@@ -530,13 +562,16 @@ def cpu_leg(out, args, scene, seeds, n_seeds, work, ok, nevals, stage):
     out["cpu_baseline"] = {
         "value": mt / tc, "unit": "patches/s", "cores": cores,
         "kind": "port",
-        "sample": f"first {mt} seeds of the same workload, OpenMP schedule(dynamic,64) over patches like "
+        "sample": f"first {mt} seeds of the same workload, {cores} OpenMP threads (all this container may use), schedule(dynamic,64) over patches like "
                   f"Scene::initPatches; photometric path = oracle/ C restatement, optimiser = "
                   f"{'genuine NLopt 2.4.2 BOBYQA (oracle/_ref)' if which == orc.OPT_REF else 'oracle BOBYQA port'}",
         "seconds": tc, "successes": okt,
         "optimizer_is_reference_nlopt": bool(which == orc.OPT_REF),
-        "cpu_model": cpu_model, "sockets": sockets, "hardware_threads": cores,
+        "cpu_model": cpu_model, "sockets": sockets, "hardware_threads": hw_threads,
+        "threads_used": cores, "cpu_quota": quota_note,
         "one_core": {"value": m1 / t1, "unit": "patches/s", "cores": 1, "sample": f"first {m1} seeds", "seconds": t1},
+        # the loop over independent patches must scale with the cores it names
+        "parallel_efficiency": (mt / tc) / (cores * (m1 / t1)),
     }
     out["parity"] = {
         "sample": m, "decision_agreement": float((okc == okg).mean()),

@@ -543,6 +543,24 @@ int copy_outputs(hpmvs_patch_batch* b, const DevBatch& D) {
 DevScene dev_scene(const hpmvs_scene* s) {
     DevScene sc;
     sc.views = s->dviews; sc.covis_off = s->dcovis_off; sc.covis = s->dcovis; sc.n_views = s->n_views;
+    // level thresholds (dev_types.h): smallest double r with (float)log2(r) >= k + 0.5, by bisection on the bit pattern
+    static const std::vector<double> thr = [] {
+        std::vector<double> t(kMaxLevels);
+        for (int k = 0; k < kMaxLevels; k++) {
+            const float target = (float)k + 0.5f;
+            double lo = std::ldexp(1.0, k), hi = std::ldexp(1.0, k + 1);  // (float)log2(lo) = k < target <= k + 1 = (float)log2(hi)
+            unsigned long long a, b;
+            memcpy(&a, &lo, 8); memcpy(&b, &hi, 8);
+            while (b - a > 1) {
+                const unsigned long long m = a + (b - a) / 2;
+                double r; memcpy(&r, &m, 8);
+                if ((float)std::log2(r) >= target) b = m; else a = m;
+            }
+            memcpy(&t[k], &b, 8);
+        }
+        return t;
+    }();
+    for (int k = 0; k < kMaxLevels; k++) sc.lvl_thr[k] = thr[k];
     return sc;
 }
 

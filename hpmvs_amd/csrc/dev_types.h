@@ -44,6 +44,11 @@ struct DevScene {
     const int32_t* covis_off;  // n_views + 1
     const int32_t* covis;
     int32_t n_views;
+    // Camera::getLeveli (Camera.cpp:92-99) rounds log2(r) to FLOAT before std::round: level > k <=> (float)log2(r) >= k + 0.5.
+    // lvl_thr[k] = the smallest double r for which the host's log2 says so (bisection at start-up, capi.hip): the
+    // device counts r >= lvl_thr[k] and needs no log2 -- and agrees with the reference in the ~1e-8-wide band below
+    // 2^(k+1/2) where the float rounding of the logarithm already reaches k + 0.5.
+    double lvl_thr[kMaxLevels];
 };
 
 // HpmvsOptions (reference HpmvsOptions.h:29-58) + host-precomputed thresholds so device and host

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) set_depths_kernel(DevScene sc, const DevD
     const float c[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
     const float scale = b.scale[p];
     const float d0 = c[0] - V.center[0], d1 = c[1] - V.center[1], d2 = c[2] - V.center[2];
-    const int level = level_clamped(scale, V.fsum, sqrtf((d0 * d0 + d1 * d1) + d2 * d2), V.n_levels - 1);
+    const int level = level_clamped(sc, scale, V.fsum, sqrtf((d0 * d0 + d1 * d1) + d2 * d2), V.n_levels - 1);
     float m[3];
     mult_level(V, c, level, m);
     const int x = sub_index((int)((double)(m[0] / m[2]) + 0.5)), y = sub_index((int)((double)(m[1] / m[2]) + 0.5));

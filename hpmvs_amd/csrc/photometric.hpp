@@ -105,17 +105,17 @@ __device__ __forceinline__ void project0(const float* P, float X0, float X1, flo
     v = behind ? -65535.0f : vv;
 }
 
-// Camera::getLeveli (Camera.cpp:92-99): clamp(round(log2(scale*fsum/(2*fz))), 0, max_level),
-// evaluated as a count of thresholds r >= 2^(k+1/2) in float64 (no log, no division).
-__device__ __forceinline__ int level_clamped(float scale, float fsum, float fz, int max_level) {
-    const double num = (double)(scale * fsum);
-    const double den = 2.0 * (double)fz;
+// Camera::getLeveli (Camera.cpp:92-99): clamp(round((float)log2(r)), 0, max_level) with r = (double)(scale*fsum) / (2.0*fz),
+// evaluated as a count of thresholds r >= lvl_thr[k] (DevScene: the smallest double whose logarithm, rounded to float as
+// the reference's `float getLevel()` rounds it, reaches k + 0.5): no logarithm on the device, and the same level as the
+// reference also for the r a hair below 2^(k+1/2) whose float-rounded log2 is already k + 0.5 (rounds 1-3
+// compared r with 2^(k+1/2) itself and gave k there; tests/test_gpu_photometric.py walks scales across those bands).
+__device__ __forceinline__ int level_clamped(const DevScene& sc, float scale, float fsum, float fz, int max_level) {
+    const double r = (double)(scale * fsum) / (2.0 * (double)fz);
     int lvl = 0;
-    double t = 1.4142135623730951;  // 2^(0+1/2)
-    for (int k = 0; k < kMaxLevels - 1; k++) {
-        if (k < max_level && num >= t * den) lvl++;
-        t *= 2.0;
-    }
+#pragma unroll
+    for (int k = 0; k < kMaxLevels - 1; k++)
+        if (k < max_level && r >= sc.lvl_thr[k]) lvl++;
     return lvl;
 }
 
@@ -146,7 +146,7 @@ __device__ __forceinline__ ViewRegs load_view(const DevView& V) {
     r.vp = &V;
     return r;
 }
-__device__ __forceinline__ Prep prep_from_view(const ViewRegs& V, const DevOptions& o, const float* c, float scale,
+__device__ __forceinline__ Prep prep_from_view(const DevScene& sc, const ViewRegs& V, const DevOptions& o, const float* c, float scale,
                                                const float* pxa, const float* pya, const float* zax) {
     Prep r;
     const float d0 = V.cx - c[0], d1 = V.cy - c[1], d2 = V.cz - c[2];
@@ -156,7 +156,7 @@ __device__ __forceinline__ Prep prep_from_view(const ViewRegs& V, const DevOptio
     const float g_raw = (d0 * zax[0] + d1 * zax[1]) + d2 * zax[2];
     const float g = (n2 > 0.0f) ? g_unit : g_raw;
     const bool angle_ok = !((double)g < o.cos_max_d);
-    const int lvl = level_clamped(scale, V.fsum, nn, o.MAXLEVEL - 1);
+    const int lvl = level_clamped(sc, scale, V.fsum, nn, o.MAXLEVEL - 1);
     {   // the chosen level's pixels: pix[0] + off[lvl].  A view's levels are one allocation, level k + 1 behind level k
         // at the next multiple of 256 bytes past its 3 * w * h + 16 bytes (capi.hip, scene_set_view): the offset is
         // arithmetic on the level-0 size, so no load depends on the level
@@ -521,7 +521,7 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
             for (int k = 0; k < kJobSets; k++) VR[k] = load_view(sc.views[jid[k]]);
 #pragma unroll
             for (int k = 0; k < kJobSets; k++) {
-                PS[k] = prep_from_view(VR[k], o, jc[k], jscale[k], jx[k], jy[k], jz[k]);
+                PS[k] = prep_from_view(sc, VR[k], o, jc[k], jscale[k], jx[k], jy[k], jz[k]);
                 PS[k].ok = (J > 64 * k && jp[k] >= 0) ? PS[k].ok : 0;
                 okS[k] = __ballot(PS[k].ok != 0);
                 const unsigned long long pb = (unsigned long long)PS[k].pix;

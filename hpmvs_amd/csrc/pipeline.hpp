@@ -196,10 +196,10 @@ __device__ __forceinline__ int coop_filter_images_by_angle(const DevScene& sc, c
 
 // Scene::getColor(const Patch3d&) (Scene.cpp:300-327): bilinear colour at the projected centre in
 // every attached image, median by norm (darkest if the median is brighter than 250).
-__device__ __forceinline__ void colour_at(const DevView& V, const float* c, float scale, float* rgb) {
+__device__ __forceinline__ void colour_at(const DevScene& sc, const DevView& V, const float* c, float scale, float* rgb) {
     const float dd[3] = {c[0] - V.center[0], c[1] - V.center[1], c[2] - V.center[2]};
     const float fz = sqrtf(dot3f(dd, dd));
-    const int lvl = level_clamped(scale, V.fsum, fz, V.n_levels - 1);
+    const int lvl = level_clamped(sc, scale, V.fsum, fz, V.n_levels - 1);
     float P[12];
     for (int k = 0; k < 12; k++) P[k] = V.P0[k];
     float x, y;
@@ -224,7 +224,7 @@ __device__ __forceinline__ U3 coop_patch_colour(const DevScene& sc, int id, int 
     const int lane = lane_id();
     float rgb[3] = {0.0f, 0.0f, 0.0f}, norm = 0.0f;
     if (lane < nimg) {
-        colour_at(sc.views[id], c, scale, rgb);
+        colour_at(sc, sc.views[id], c, scale, rgb);
         norm = sqrtf(dot3f(rgb, rgb));
     }
     // rank selection instead of std::sort: element of rank nimg/2 and the minimum

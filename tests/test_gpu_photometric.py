@@ -133,3 +133,50 @@ def test_pyramid_matches_the_genuine_cimg():
         for l in range(1, len(ref)):
             cur = api.build_pyramid(cur)
             assert np.array_equal(cur, ref[l]), (h, w, l)
+
+
+def test_level_choice_in_the_float_rounding_band_of_log2(tiny_scene, tiny_seeds, oracle_scene, gpu_scene):
+    """Camera::getLeveli (Camera.cpp:92-99) rounds log2(r) to float BEFORE std::round: an r a hair below 2^(k+1/2) whose
+    logarithm rounds up to exactly k + 0.5f gets level k + 1, not k.  The device counts thresholds instead of taking a
+    logarithm; its thresholds are the smallest doubles for which the host's (float)log2 reaches k + 0.5 (DevScene::lvl_thr),
+    so it must agree inside that band too (VERDICT r3 asked for the edge to be argued or tested).  For a few patches and
+    each of their images the patch scale walks, float by float, across 2^(1.5) and 2^(2.5): setINCCs on the GPU equals the
+    oracle (whose cam_get_level is the reference's expression) at every one of them, and the walk really contains scales
+    inside the band (where comparing r with 2^(k+1/2) itself would have chosen the other level)."""
+    from hpmvs_amd import api
+    from oracle import oracle as orc
+    f32 = np.float32
+    idx = np.nonzero(tiny_seeds.n_images >= 3)[0][:3]
+    in_band = 0
+    for p in idx:
+        c = tiny_seeds.center[p].astype(f32)
+        scales = []
+        for j in range(int(tiny_seeds.n_images[p])):
+            cam = oracle_scene.camera(int(tiny_seeds.images[p, j]))
+            d = c - np.array(cam.center[:], dtype=f32)
+            fz = np.sqrt(f32(f32(f32(d[0] * d[0]) + f32(d[1] * d[1])) + f32(d[2] * d[2])) + f32(d[3] * d[3]))
+            fsum = f32(f32(cam.K0[0]) + f32(cam.K0[4]))
+            for k in (1, 2):
+                s0 = f32(2.0 ** (k + 0.5) * 2.0 * float(fz) / float(fsum))
+                s = np.nextafter(s0, f32(0), dtype=f32)
+                for _ in range(60):
+                    s = np.nextafter(s, f32(0), dtype=f32)
+                for _ in range(120):
+                    s = np.nextafter(s, f32(np.inf), dtype=f32)
+                    r = float(f32(s * fsum)) / (2.0 * float(fz))
+                    lvl_ref = int(np.round(f32(np.log2(r))))
+                    lvl_naive = sum(1 for kk in range(5) if r >= 2.0 ** (kk + 0.5))
+                    in_band += int(lvl_ref != lvl_naive)
+                    scales.append(s)
+        scales = np.array(scales, dtype=f32)
+        n = len(scales)
+        rep = np.full(n, p)
+        batch = api.Batch(tiny_seeds.center[rep], tiny_seeds.normal[rep], scales, tiny_seeds.n_images[rep], tiny_seeds.images[rep])
+        got = api.inccs_batch(gpu_scene, batch, 0, 0)
+        P = orc.patches_from_seeds(tiny_seeds, rep)
+        m = int(tiny_seeds.n_images[p])
+        for t in range(n):
+            P[t].scale = float(scales[t])
+            want = orc.inccs(oracle_scene, P[t], 0, 0)
+            assert np.array_equal(got[t, :m], want), (p, t, float(scales[t]), got[t, :m], want)
+    assert in_band >= 1, "the walk never entered the band: the test would not see the edge"
