@@ -1071,3 +1071,81 @@ void orc_depth_gates(const orc_scene *s, const orc_depths *D, const orc_patch *p
     }
     *n_visible = vis; *n_blocking = blk; *n_free = fre;
 }
+
+/* ------------------------------------------------------------------------- */
+/* One priority level of the expansion, sequentially, as the reference runs it.
+ *
+ * main.cpp:146-181 pops the leaves of one priority value and calls CellProcessor::extend on each
+ * (src/hpmvs/CellProcessor.cpp:84-178): six hexagon candidates at the leaf's width; a candidate whose octree leaf is
+ * already occupied is skipped BEFORE optimize (:118-122); the refined candidate has to pass the scale and drift gates
+ * (:130-133), the three depth-map counts (:134-142: depthTests >= MIN_IMAGES_PER_PATCH, viewBlockTest <
+ * MIN_IMAGES_PER_PATCH, pixelFreeTests >= MIN_IMAGES_PER_PATCH - 1 and > 75 % of its images), and
+ * DynOctTree::addConditional (doctree.h:397-419: the leaf at the REFINED centre must be empty); then its depths are
+ * entered (:165, Scene::setDepths) and it joins the next priority level (:171-175).  Everything a later candidate reads
+ * -- occupancy and depth maps -- already contains what the earlier ones of the same level wrote.
+ *
+ * The octree is replaced by a caller-owned occupancy set over the uniform grid of the level's leaf width (the leaves of
+ * one priority level have one width; the root contains everything): the cell of a point is floor(p / width) per axis.
+ *
+ * frozen_gates != 0: the three counts read a copy of the depth maps taken when the round starts -- what a
+ * frontier-batched round sees (every candidate of the level refined and gated in one launch) -- while
+ * insertion, occupancy and setDepths stay ordered.  The difference between the two modes IS the interaction between the
+ * candidates of one level.
+ *
+ * out[6 n]: every candidate as extend() left it (stage 0 accepted; 20 skipped before optimize; 1-9 / 100 optimize();
+ * 21 scale gate; 22 drift gate; 23 depthTests; 24 viewBlockTest; 25 pixelFreeTests; 26 addConditional).
+ * counts[3 * 6 n]: the three counts of the candidates that reached them (-1 otherwise).  Returns the number accepted. */
+typedef struct { long long *keys; int n, cap; } orc_occ;
+static long long occ_key(const float *p, float width) {
+    const long long ix = (long long)floorf(p[0] / width), iy = (long long)floorf(p[1] / width), iz = (long long)floorf(p[2] / width);
+    return ((ix + (1 << 20)) << 42) | ((iy + (1 << 20)) << 21) | (iz + (1 << 20));
+}
+static int occ_has(const orc_occ *o, long long k) {
+    for (int i = 0; i < o->n; i++) if (o->keys[i] == k) return 1;
+    return 0;
+}
+long long orc_cell_key(const float *p, float width) { return occ_key(p, width); }
+
+int orc_extend_round(const orc_scene *s, const orc_options *o, orc_depths *D, int n_leaves, const orc_patch *parents,
+                     float width, float margin, int abs_int, long long *occ_keys, int *n_occ, int occ_cap,
+                     int frozen_gates, orc_patch *out, int *counts, int which) {
+    orc_occ occ = {occ_keys, *n_occ, occ_cap};
+    orc_depths *G = D;  /* the maps the gates read */
+    if (frozen_gates) {
+        G = orc_depths_create(s);
+        for (int k = 0; k < D->n_views * ORC_MAX_LEVELS; k++)
+            if (D->d[k]) memcpy(G->d[k], D->d[k], sizeof(float) * (size_t)D->rows[k] * D->cols[k]);
+    }
+    int accepted = 0;
+    const float cc[3] = {0, 0, 0};
+    for (int i = 0; i < n_leaves; i++) {
+        for (int ii = 0; ii < 6; ii++) {
+            unsigned char skip[6] = {1, 1, 1, 1, 1, 1};
+            orc_patch six[6];
+            int *cnt = counts + 3 * (6 * i + ii);
+            cnt[0] = cnt[1] = cnt[2] = -1;
+            /* the candidate before optimize: its leaf must be empty (CellProcessor.cpp:118-122) */
+            orc_expand(s, o, 0, &parents[i], cc, width, skip, six, which);  /* (constructs; optimizes nothing) */
+            orc_patch *q = &out[6 * i + ii];
+            if (occ_has(&occ, occ_key(six[ii].center, width))) { *q = six[ii]; q->stage = 20; continue; }
+            skip[ii] = 0;
+            orc_expand(s, o, 0, &parents[i], cc, width, skip, six, which);  /* optimize() + the scale and drift gates */
+            *q = six[ii];
+            if (q->stage != 0) continue;
+            int v, b, f;
+            orc_depth_gates(s, G, q, margin, abs_int, &v, &b, &f);
+            cnt[0] = v; cnt[1] = b; cnt[2] = f;
+            if (!(v >= o->MIN_IMAGES_PER_PATCH)) { q->stage = 23; continue; }
+            if (!(b < o->MIN_IMAGES_PER_PATCH)) { q->stage = 24; continue; }
+            if (!(f >= o->MIN_IMAGES_PER_PATCH - 1 && f * 1.0 / q->n_images > 0.75)) { q->stage = 25; continue; }
+            const long long key = occ_key(q->center, width);
+            if (occ_has(&occ, key) || occ.n >= occ.cap) { q->stage = 26; continue; }  /* addConditional */
+            occ.keys[occ.n++] = key;
+            orc_set_depths(s, D, q);
+            accepted++;
+        }
+    }
+    if (frozen_gates) orc_depths_destroy(G);
+    *n_occ = occ.n;
+    return accepted;
+}

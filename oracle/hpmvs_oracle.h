@@ -163,6 +163,14 @@ void orc_set_depths(const orc_scene *s, orc_depths *D, const orc_patch *p);
 void orc_depth_gates(const orc_scene *s, const orc_depths *D, const orc_patch *p, float margin, int abs_int,
                      int *n_visible, int *n_blocking, int *n_free);
 
+/* One priority level of the expansion, sequentially (main.cpp:146-181 -> CellProcessor::extend, CellProcessor.cpp:84-178)
+ * over a caller-owned occupancy set instead of the octree; frozen_gates: the depth-map counts read the round-start maps
+ * (what a frontier-batched round sees).  See hpmvs_oracle.c. */
+long long orc_cell_key(const float *p, float width);
+int orc_extend_round(const orc_scene *s, const orc_options *o, orc_depths *D, int n_leaves, const orc_patch *parents,
+                     float width, float margin, int abs_int, long long *occ_keys, int *n_occ, int occ_cap,
+                     int frozen_gates, orc_patch *out, int *counts, int which);
+
 /* test-only switch: evaluation order of Eigen's 4-float reductions (0 left-to-right = default, 1 SSE2, 2 SSE3) */
 void orc_set_dot4_order(int order);
 /* Eigen's vector / scalar: 0 true division (Eigen >= 3.2, the default and what the HIP path restates), 1 multiply by the

@@ -91,6 +91,11 @@ def lib():
     L.orc_depths_level.restype = C.POINTER(C.c_float)
     L.orc_depths_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.orc_set_depths.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Patch)]
+    L.orc_cell_key.restype = C.c_longlong
+    L.orc_cell_key.argtypes = [C.POINTER(C.c_float), C.c_float]
+    L.orc_extend_round.argtypes = [C.c_void_p, C.POINTER(Options), C.c_void_p, C.c_int, C.POINTER(Patch), C.c_float, C.c_float,
+                                   C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(Patch),
+                                   C.POINTER(C.c_int), C.c_int]
     L.orc_depth_gates.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Patch), C.c_float, C.c_int, C.POINTER(C.c_int),
                                   C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.orc_bobyqa_minimize.argtypes = [C.c_int, C.c_int, OBJ_FN, C.c_void_p, C.POINTER(C.c_double),
@@ -330,3 +335,29 @@ def cimg_pyramid(img: np.ndarray, n_levels: int):
     for l in range(n_levels):
         assert (ws[l], hs[l]) == (outs[l].shape[1], outs[l].shape[0]), "CImg level size differs from floor(w/2) x floor(h/2)"
     return outs
+
+
+def cell_key(p, width) -> int:
+    """Occupancy key of the grid cell (floor(p / width) per axis) that holds the point p."""
+    a = (C.c_float * 3)(float(p[0]), float(p[1]), float(p[2]))
+    return int(lib().orc_cell_key(a, float(width)))
+
+
+def extend_round(scene: OracleScene, depths: OracleDepths, parents, width, occupied, margin=1.0, abs_int=0, frozen_gates=False,
+                 which=None, options=None):
+    """One priority level of the expansion, sequentially (CellProcessor::extend over the leaves in order, reference
+    CellProcessor.cpp:84-178), on a caller-owned occupancy set (a Python set of cell keys, updated in place) and the
+    depth maps `depths` (updated in place).  Returns (candidates[6 n], counts[6 n, 3])."""
+    which = best_optimizer() if which is None else which
+    o = options or default_options()
+    n = len(parents)
+    cap = len(occupied) + 6 * n + 1
+    keys = (C.c_longlong * cap)(*sorted(occupied))
+    n_occ = C.c_int(len(occupied))
+    out = (Patch * (6 * n))()
+    counts = (C.c_int * (18 * n))()
+    lib().orc_extend_round(scene.h, C.byref(o), depths.h, n, parents, float(width), float(margin), int(abs_int), keys,
+                           C.byref(n_occ), cap, 1 if frozen_gates else 0, out, counts, which)
+    occupied.clear()
+    occupied.update(int(keys[i]) for i in range(n_occ.value))
+    return out, np.array(counts[:], dtype=np.int32).reshape(6 * n, 3)

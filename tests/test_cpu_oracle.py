@@ -559,3 +559,54 @@ def test_oracle_depth_gates_known_answers(tiny_scene, tiny_seeds):
     v_f, _, _ = D.gates(half, 1.0, 0)
     v_i, _, _ = D.gates(half, 1.0, 1)
     assert v_i >= v_f
+
+
+def test_oracle_extend_round_bookkeeping():
+    """orc_extend_round (one priority level of CellProcessor::extend, reference CellProcessor.cpp:84-178, on an occupancy set
+    instead of the octree): stage codes, occupancy and depth maps move together; a fully occupied neighbourhood skips every
+    candidate before optimize (:118-122); the frozen-gates mode differs from the live one only through the depth maps."""
+    from helpers import golden_scene
+    from oracle import oracle as orc
+    scene, seeds, _ = golden_scene()
+    osc = orc.OracleScene(scene)
+    P = orc.patches_from_seeds(seeds, list(range(40)))
+    orc.optimize_batch(osc, P, n_threads=4)
+    good = [p for p in P if p.stage == 0][:12]
+    assert len(good) >= 6
+    parents = (orc.Patch * len(good))(*good)
+    width = float(np.float32(2.0 * np.median([p.scale for p in good]) / 0.9))
+    occ0 = {orc.cell_key(p.center, width) for p in good}
+    res = {}
+    for mode in ("live", "frozen"):
+        D = orc.OracleDepths(osc)
+        for p in good:
+            D.set_depths(p)
+        before = [D.level(v, l).copy() for v in range(osc.n_views) for l in range(6)]
+        occ = set(occ0)
+        out, counts = orc.extend_round(osc, D, parents, width, occ, frozen_gates=(mode == "frozen"))
+        st = np.array([out[t].stage for t in range(6 * len(good))])
+        assert set(st.tolist()) <= {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 20, 21, 22, 23, 24, 25, 26, 100}
+        acc = np.nonzero(st == 0)[0]
+        assert len(occ) == len(occ0) + len(acc)                     # one new cell per accepted candidate
+        assert all(orc.cell_key(out[t].center, width) in occ for t in acc)
+        reached = np.isin(st, [0, 23, 24, 25, 26])
+        assert np.all(counts[reached] >= 0) and np.all(counts[~reached] == -1)
+        after = [D.level(v, l) for v in range(osc.n_views) for l in range(6)]
+        changed = sum(int((a != b).sum()) for a, b in zip(after, before))
+        assert (changed > 0) == (len(acc) > 0)
+        assert all(np.all(a <= b) for a, b in zip(after, before))    # setDepths only ever lowers a cell
+        res[mode] = (st, counts)
+    # the two modes agree up to the first candidate whose counts an earlier insertion of the same level changed
+    d = np.nonzero(res["live"][0] != res["frozen"][0])[0]
+    if len(d):
+        assert not np.array_equal(res["live"][1][d[0]], res["frozen"][1][d[0]])
+    # every neighbouring cell occupied: nothing is optimized
+    D = orc.OracleDepths(osc)
+    full = set(occ0)
+    for p in good:
+        for dx in np.linspace(-1.5, 1.5, 7):
+            for dy in np.linspace(-1.5, 1.5, 7):
+                for dz in np.linspace(-1.5, 1.5, 7):
+                    full.add(orc.cell_key([p.center[0] + dx * width, p.center[1] + dy * width, p.center[2] + dz * width], width))
+    out, counts = orc.extend_round(osc, D, parents, width, full)
+    assert all(out[t].stage == 20 and out[t].nevals == 0 for t in range(6 * len(good)))
