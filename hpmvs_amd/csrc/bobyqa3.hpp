@@ -206,20 +206,91 @@ enum {  // int32 slots
 #ifndef BQ_SLOTS
 #define BQ_SLOTS BQ_P
 #endif
+// BQ_COLD_GLOBAL (round 4): the three big matrices of the updating formula -- bmat (30), zmat (21), vlag (10), the
+// contiguous index range [O_bmat, O_wsuma), 61 of the 164 float64 values -- live in GLOBAL memory, [index][slot] like the
+// LDS part (one block per wavefront in the launch workspace, never paged), and only the other 103 values + 13 ints take
+// LDS.  Five blocks touch them (update, the two denominator blocks, the model update, altmov), each reading them once at
+// its top and writing once at its end, so the price is a handful of L2 round trips per optimiser step -- and a state
+// region shrinks from 79 KB to 50 KB for 58 patches: THREE regions per CU instead of two.  The regions are what a
+// launch queues for (profiles/r04/hold_sensitivity.txt: every cycle a region is held costs two cycles of a wavefront's
+// round).  The accesses are BUFFER loads / stores -- resource descriptor in scalar registers, one 32-bit lane offset,
+// the element's offset as the instruction's immediate -- through an lvalue proxy (bq_cold_ref): with flat or global
+// addressing every element cost a 64-bit address register pair, which the blocks (at the register limit already) paid
+// for in spills; that first attempt ran at 340 ms against 229 (profiles/r04/hold_sensitivity.txt).
+#if defined(BQ_COLD_GLOBAL)
+#ifndef BQ_COLD_LO
+#define BQ_COLD_LO 77   /* O_bmat; 36 = O_xpt: xpt, fval, pq, hq as well (the range is contiguous up to O_wsuma) */
+#endif
+#define BQ_COLD_HI 138  /* O_wsuma */
+#define BQ_NCOLD (BQ_COLD_HI - BQ_COLD_LO)
+#define BQ_ND_LDS (164 - BQ_NCOLD)
+#ifndef BQ_CSTRIDE
+#define BQ_CSTRIDE BQ_P   /* slots per cold block */
+#endif
+#else
+#define BQ_ND_LDS 164
+#endif
 #if defined(BQ_STATE_LDS_EXTERN)
 // the including kernel owns the LDS buffer (shared with its other phases) and defines bq_lds_d / bq_lds_i
 // as pointer expressions into it before including this header
 #else
-__shared__ double bq_lds_d[BQ_ND * BQ_SLOTS];
-__shared__ int bq_lds_i[BQ_NI * BQ_SLOTS];
+__shared__ double bq_lds_d[BQ_ND_LDS * BQ_SLOTS];
+__shared__ int bq_lds_i[13 * BQ_SLOTS];
 #endif
+#if defined(BQ_COLD_GLOBAL)
+typedef unsigned int bq_u2 __attribute__((ext_vector_type(2)));
+struct bq_cold_ref {  // one float64 of the cold block: reads convert, assignments store
+    __amdgpu_buffer_rsrc_t r; unsigned voff; int soff;
+    __device__ __forceinline__ operator double() const { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, 0)); }
+    __device__ __forceinline__ void operator=(double v) const { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bq_u2, v), r, (int)voff, soff, 0); }
+    __device__ __forceinline__ void operator=(const bq_cold_ref& o) const { *this = (double)o; }
+    __device__ __forceinline__ void operator+=(double v) const { *this = (double)*this + v; }
+    __device__ __forceinline__ void operator-=(double v) const { *this = (double)*this - v; }
+};
+// cold: this wavefront's block of the cold arrays (the same on all its lanes: coldp is its address, kept so that a real
+// function can rebuild the descriptor in scalar registers, BQ_UNIFORM), coff: byte offset of my column
+struct Bobyqa3 { int slot; int slot_i; unsigned coff; char* coldp; __amdgpu_buffer_rsrc_t cold; };
+__device__ __forceinline__ bq_cold_ref bq_cold_at(const Bobyqa3& B, int i) {  // i: state index in [BQ_COLD_LO, BQ_COLD_HI)
+    const bool c = __builtin_constant_p(i);
+    const int byte = (i - BQ_COLD_LO) * (BQ_CSTRIDE * 8);
+    return bq_cold_ref{B.cold, B.coff + (c ? 0u : (unsigned)byte), c ? byte : 0};
+}
+#define BQ_HOTIDX(i) ((i) < BQ_COLD_LO ? (i) : (i) - BQ_NCOLD)
+#define BQ_D(i) bq_lds_d[BQ_HOTIDX(i) * BQ_SLOTS + B.slot]
+#define BQ_C(i) bq_cold_at(B, (i))
+#if BQ_COLD_LO <= 36
+#define BQ_M(i) bq_cold_at(B, (i))   /* xpt, fval, pq, hq are cold too */
+#else
+#define BQ_M(i) BQ_D(i)
+#endif
+#else
 struct Bobyqa3 { int slot; int slot_i; };  // slot: index into the float64 array, slot_i: into the int32 array (they differ when the including kernel keeps several state regions)
 #define BQ_D(i) bq_lds_d[(i) * BQ_SLOTS + B.slot]
+#define BQ_C(i) BQ_D(i)
+#define BQ_M(i) BQ_D(i)
+#endif
 #define BQ_I(i) bq_lds_i[(i) * BQ_SLOTS + B.slot_i]
+#if defined(BQ_COLD_GLOBAL)
+// A real call hands the handle over in vector registers; a buffer descriptor there would make every access a
+// waterfall loop.  Every real function rebuilds it from the block's address read as a scalar.
+__device__ __forceinline__ Bobyqa3 bq_uniform(Bobyqa3 b) {
+    const unsigned long long a = (unsigned long long)b.coldp;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(a & 0xffffffffull)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32));
+    b.coldp = (char*)(((unsigned long long)hi << 32) | lo);
+    b.cold = __builtin_amdgcn_make_buffer_rsrc(b.coldp, 0, BQ_NCOLD * BQ_CSTRIDE * 8, 0x00020000);
+    return b;
+}
+#define BQ_UNIFORM(Bin) bq_uniform(Bin)
+#else
+#define BQ_UNIFORM(Bin) (Bin)
+#endif
 #else
 struct Bobyqa3 { double dd[BQ_ND]; int ii[BQ_NI]; };
 #define BQ_D(i) B.dd[(i)]
+#define BQ_C(i) B.dd[(i)]
+#define BQ_M(i) B.dd[(i)]
 #define BQ_I(i) B.ii[(i)]
+#define BQ_UNIFORM(Bin) (Bin)
 #endif
 
 // How the state handle travels through function calls.  On the device it is just the slot index and is
@@ -236,13 +307,21 @@ typedef Bobyqa3& BqRef;
 #define BQS(name) BQ_D(O_##name)                // float64 scalar
 #define BQN(name) BQ_I(I_##name)                // int scalar
 // 1-based accessors like the mathematics
-#define BQ_XPT(k, i) BQ_D(O_xpt + ((k) - 1) * 3 + ((i) - 1))
-#define BQ_BMAT(k, i) BQ_D(O_bmat + ((k) - 1) * 3 + ((i) - 1))
-#define BQ_ZMAT(k, j) BQ_D(O_zmat + ((k) - 1) * 3 + ((j) - 1))
-#define BQ_FVAL(k) BQ_D(O_fval + (k) - 1)
-#define BQ_PQ(k) BQ_D(O_pq + (k) - 1)
-#define BQ_HQ(ih) BQ_D(O_hq + (ih) - 1)
+#define BQ_XPT(k, i) BQ_M(O_xpt + ((k) - 1) * 3 + ((i) - 1))
+#define BQ_BMAT(k, i) BQ_C(O_bmat + ((k) - 1) * 3 + ((i) - 1))
+#define BQ_ZMAT(k, j) BQ_C(O_zmat + ((k) - 1) * 3 + ((j) - 1))
+#define BQ_FVAL(k) BQ_M(O_fval + (k) - 1)
+#define BQ_PQ(k) BQ_M(O_pq + (k) - 1)
+#define BQ_HQ(ih) BQ_M(O_hq + (ih) - 1)
 #define BQ_V(a, i) BQ_D(O_##a + (i) - 1)
+#define BQ_VLAG(i) BQ_C(O_vlag + (i) - 1)
+#if defined(BQ_STATE_LDS) && defined(BQ_COLD_GLOBAL)
+#define BQ_EITHER(i) (((i) >= BQ_COLD_LO && (i) < BQ_COLD_HI) ? (double)bq_cold_at(B, (i)) : (double)BQ_D(i))
+#else
+#define BQ_EITHER(i) BQ_D(i)
+#endif
+#define BQ_COLDA(name, idx) BQ_C(O_##name + (idx))
+#define BQ_MA(name, idx) BQ_M(O_##name + (idx))      // 0-based element of xpt / fval / pq / hq: hot or cold by configuration  // 0-based element of one of the cold arrays (bmat, zmat, vlag)
 #define BQ_PA(i, j) BQ_D(O_ptsaux + ((j) - 1) * 2 + ((i) - 1))  // PTSAUX(i,j) of rescue_
 #define BQ_PTSID(k) BQ_D(O_ptsid + (k) - 1)
 
@@ -277,7 +356,7 @@ enum { L20 = 0, L60, L90, L210, L230, L360, L650, L680, L720, L190, LRET_CONT, L
 // exactly as bobyqb_ does before each calfun (bobyqa.c:2560-2575, 1871-1883)
 BQ_HD void set_x_from(BqRef B, int p_off) {  // p_off: state offset of the 3-vector p
     for (int i = 1; i <= 3; i++) {
-        const double pi = BQ_D(p_off + i - 1);
+        const double pi = BQ_EITHER(p_off + i - 1);
         double v = mn(mx(BQ_V(xl, i), BQ_V(xbase, i) + pi), BQ_V(xu, i));
         if (pi == BQ_V(sl, i)) v = BQ_V(xl, i);
         if (pi == BQ_V(su, i)) v = BQ_V(xu, i);
@@ -352,16 +431,16 @@ BQ_HD void hess_mul(BqRef B, const double* s, double* hs) {
         hs[j - 1] = 0.0;
         for (int i = 1; i <= j; i++) {
             ++ih;
-            if (i < j) hs[j - 1] += BQA(hq, ih - 1) * s[i - 1];
-            hs[i - 1] += BQA(hq, ih - 1) * s[j - 1];
+            if (i < j) hs[j - 1] += BQ_MA(hq, ih - 1) * s[i - 1];
+            hs[i - 1] += BQ_MA(hq, ih - 1) * s[j - 1];
         }
     }
     for (int k = 1; k <= 7; k++) {
-        if (BQA(pq, k - 1) != 0.0) {
+        if (BQ_MA(pq, k - 1) != 0.0) {
             double temp = 0.0;
-            for (int j = 1; j <= 3; j++) temp += BQA(xpt, (k - 1) * 3 + j - 1) * s[j - 1];
-            temp *= BQA(pq, k - 1);
-            for (int i = 1; i <= 3; i++) hs[i - 1] += temp * BQA(xpt, (k - 1) * 3 + i - 1);
+            for (int j = 1; j <= 3; j++) temp += BQ_MA(xpt, (k - 1) * 3 + j - 1) * s[j - 1];
+            temp *= BQ_MA(pq, k - 1);
+            for (int i = 1; i <= 3; i++) hs[i - 1] += temp * BQ_MA(xpt, (k - 1) * 3 + i - 1);
         }
     }
 }
@@ -406,9 +485,9 @@ BQ_HD_BLOCK void trsbox(BqRef B) {
     // (one batch of LDS reads at entry, one write-back of d / gnew / xnew at exit)
     double xopt_[3], sl_[3], su_[3], d_[3], gnew_[3], hq_[6], pq_[7], xpt_[21];
     for (int i = 0; i < 3; i++) { xopt_[i] = BQA(xopt, i); sl_[i] = BQA(sl, i); su_[i] = BQA(su, i); }
-    for (int i = 0; i < 6; i++) hq_[i] = BQA(hq, i);
-    for (int i = 0; i < 7; i++) pq_[i] = BQA(pq, i);
-    for (int i = 0; i < 21; i++) xpt_[i] = BQA(xpt, i);
+    for (int i = 0; i < 6; i++) hq_[i] = BQ_MA(hq, i);
+    for (int i = 0; i < 7; i++) pq_[i] = BQ_MA(pq, i);
+    for (int i = 0; i < 21; i++) xpt_[i] = BQ_MA(xpt, i);
     int iterc = 0, nact = 0, itermax = 0, iact = 0, isav, iu;
     double delsq, qred = 0.0, crvmin = -1.0, beta = 0.0, stepsq, gredsq = 0.0, resid, ds, shs, temp, blen, stplen,
                   sdec, ggsav = 0.0, dredsq = 0.0, dredg = 0.0, sredg = 0.0, angbd = 0.0, xsav = 0.0, ssq, tempa,
@@ -817,10 +896,10 @@ BQ_HD_BLOCK void update(BqRef B) {
     for (int k = 0; k < 7; k++)
         for (int j = 0; j < 3; j++) z[k][j] = BQ_ZMAT(k + 1, j + 1);
     for (int j = 0; j < 3; j++) { zk[j] = BQ_ZMAT(knew, j + 1); bk[j] = BQ_BMAT(knew, j + 1); }
-    for (int i = 0; i < 10; i++) vl[i] = BQ_V(vlag, i + 1);
+    for (int i = 0; i < 10; i++) vl[i] = BQ_VLAG(i + 1);
     for (int i = 0; i < 10; i++)
         for (int j = 0; j < 3; j++) bm[i][j] = BQ_BMAT(i + 1, j + 1);
-    const double tau = BQ_V(vlag, knew);
+    const double tau = BQ_VLAG(knew);
     const double denom = BQS(denom), beta = BQS(beta);
     double w[10];
     double ztest = 0.0;
@@ -864,7 +943,7 @@ BQ_HD_BLOCK void update(BqRef B) {
         for (int j = 0; j < 3; j++) BQ_ZMAT(k + 1, j + 1) = z[k][j];
     for (int i = 0; i < 10; i++)
         for (int j = 0; j < 3; j++) BQ_BMAT(i + 1, j + 1) = bm[i][j];
-    BQ_V(vlag, knew) = tau - 1.0;
+    BQ_VLAG(knew) = tau - 1.0;
 }
 
 // pick_knew on per-point quantities the caller formed from its register copies: hdiag[k] = sum_j zmat(k,j)^2 and
@@ -899,8 +978,8 @@ BQ_HD void pick_knew(BqRef B, int from_off, bool skip_kopt, double& scaden, doub
         double z[7][3], xp[7][3], from[3];
         for (int k = 0; k < 7; k++)
             for (int j = 0; j < 3; j++) { z[k][j] = BQ_ZMAT(k + 1, j + 1); xp[k][j] = BQ_XPT(k + 1, j + 1); }
-        for (int k = 0; k < 7; k++) vl[k] = BQ_V(vlag, k + 1);
-        for (int j = 0; j < 3; j++) from[j] = BQ_D(from_off + j);
+        for (int k = 0; k < 7; k++) vl[k] = BQ_VLAG(k + 1);
+        for (int j = 0; j < 3; j++) from[j] = BQ_EITHER(from_off + j);
         for (int k = 0; k < 7; k++) {
             double h = 0.0, ds = 0.0;
             for (int j = 0; j < 3; j++) h += z[k][j] * z[k][j];
@@ -933,7 +1012,8 @@ BQ_HD int rescue_finish(BqRef B, int rc2) {  // bobyqa.c:2340-2365
 }
 
 // the L260 loop of rescue_ (bobyqa.c:560-651): next provisional point that still needs a value
-BQ_HD_NOINLINE int rescue_next(BqRef B) {
+BQ_HD_NOINLINE int rescue_next(BqRef B_in) {
+    BqRef B = BQ_UNIFORM(B_in);
     for (; BQN(kpt) <= 7; BQN(kpt)++) {
         const int kpt = BQN(kpt);
         if (BQ_PTSID(kpt) == 0.0) continue;
@@ -988,7 +1068,8 @@ BQ_HD_NOINLINE int rescue_next(BqRef B) {
 }
 
 // after the evaluation of provisional point kpt (bobyqa.c:652-700)
-BQ_HD_NOINLINE int rescue_consume(BqRef B, double f) {
+BQ_HD_NOINLINE int rescue_consume(BqRef B_in, double f) {
+    BqRef B = BQ_UNIFORM(B_in);
     const int kpt = BQN(kpt);
     BQ_FVAL(kpt) = f;
     if (f < BQ_FVAL(BQN(kopt))) BQN(kopt) = kpt;
@@ -1028,7 +1109,8 @@ BQ_HD_NOINLINE int rescue_consume(BqRef B, double f) {
 #ifndef BQ_ON_RESCUE
 #define BQ_ON_RESCUE() do { } while (0)  // test hook (tests/native/bq_host.cpp counts the calls)
 #endif
-BQ_HD_NOINLINE int rescue_begin(BqRef B) {
+BQ_HD_NOINLINE int rescue_begin(BqRef B_in) {
+    BqRef B = BQ_UNIFORM(B_in);
     BQ_ON_RESCUE();
     const double sfrac = 0.5 / 4.0;
     BQN(nfsav) = BQN(nevals);
@@ -1100,9 +1182,9 @@ BQ_HD_NOINLINE int rescue_begin(BqRef B) {
             wd[knew] = 0.0;
             --nrem;
             if (knew != kopt) {
-                const double temp = BQ_V(vlag, kold);
-                BQ_V(vlag, kold) = BQ_V(vlag, knew);
-                BQ_V(vlag, knew) = temp;
+                const double temp = BQ_VLAG(kold);
+                BQ_VLAG(kold) = BQ_VLAG(knew);
+                BQ_VLAG(knew) = temp;
                 BQN(knew) = knew;  // update() reads knew / beta / denom from the state
                 update(B);
                 if (nrem == 0) break;  // label 350
@@ -1139,14 +1221,14 @@ BQ_HD_NOINLINE int rescue_begin(BqRef B) {
         for (int k = 1; k <= 7; k++) {
             double sum = 0.0;
             for (int j = 1; j <= 3; j++) sum += BQ_BMAT(k, j) * wv[j];
-            BQ_V(vlag, k) = sum;
+            BQ_VLAG(k) = sum;
         }
         double beta = 0.0;
         for (int j = 1; j <= 3; j++) {
             double sum = 0.0;
             for (int k = 1; k <= 7; k++) sum += BQ_ZMAT(k, j) * ww[k];
             beta -= sum * sum;
-            for (int k = 1; k <= 7; k++) BQ_V(vlag, k) += sum * BQ_ZMAT(k, j);
+            for (int k = 1; k <= 7; k++) BQ_VLAG(k) += sum * BQ_ZMAT(k, j);
         }
         double bsum = 0.0, distsq = 0.0;
         for (int j = 1; j <= 3; j++) {
@@ -1156,20 +1238,20 @@ BQ_HD_NOINLINE int rescue_begin(BqRef B) {
             bsum += sum * wv[j];
             for (int ip = 8; ip <= 10; ip++) sum += BQ_BMAT(ip, j) * wv[ip - 7];
             bsum += sum * wv[j];
-            BQ_V(vlag, jp) = sum;
+            BQ_VLAG(jp) = sum;
             distsq += BQ_XPT(knew, j) * BQ_XPT(knew, j);
         }
         beta = 0.5 * distsq * distsq + beta - bsum;
-        BQ_V(vlag, kopt) += 1.0;
+        BQ_VLAG(kopt) += 1.0;
         double denom = 0.0, vlmxsq = 0.0;
         for (int k = 1; k <= 7; k++) {
             if (BQ_PTSID(k) != 0.0) {
                 double hdiag = 0.0;
                 for (int j = 1; j <= 3; j++) hdiag += BQ_ZMAT(k, j) * BQ_ZMAT(k, j);
-                const double den = beta * hdiag + BQ_V(vlag, k) * BQ_V(vlag, k);
+                const double den = beta * hdiag + BQ_VLAG(k) * BQ_VLAG(k);
                 if (den > denom) { kold = k; denom = den; }
             }
-            vlmxsq = mx(vlmxsq, BQ_V(vlag, k) * BQ_V(vlag, k));
+            vlmxsq = mx(vlmxsq, BQ_VLAG(k) * BQ_VLAG(k));
         }
         if (denom <= vlmxsq * .01) {
             wd[knew] = -wd[knew] - winc;
@@ -1335,7 +1417,7 @@ BQ_HD_BLOCK int label230(BqRef B) {
     }
     beta = dx * dx + dsq * (xoptsq + dx + dx + 0.5 * dsq) + beta - bsum;
     for (int k = 1; k <= 7; k++) if (k == kopt) vl[k - 1] += 1.0;
-    for (int i = 0; i < 10; i++) BQ_V(vlag, i + 1) = vl[i];
+    for (int i = 0; i < 10; i++) BQ_VLAG(i + 1) = vl[i];
     BQS(beta) = beta;
     BQS(dsq) = dsq;
     if (ntrits == 0) {
@@ -1807,8 +1889,9 @@ BQ_HD void bq_default_step(const double* x, const double* lb, const double* ub, 
 
 // bobyqa() front end (bobyqa.c:3073-3268) + the start of prelim_.  Returns BQ_CONTINUE with the
 // first point in B.xeval, or BQ_DONE with BQN(rc) = BQ_INVALID_ARGS.
-BQ_HD_NOINLINE int bq_start(BqRef B, const double* x0, const double* lb, const double* ub, const double* dx,
+BQ_HD_NOINLINE int bq_start(BqRef B_in, const double* x0, const double* lb, const double* ub, const double* dx,
                    double xtol_rel, int maxeval) {
+    BqRef B = BQ_UNIFORM(B_in);
     BQN(nevals) = 0; BQN(rc) = BQ_SUCCESS; BQS(minf) = HUGE_VAL; BQN(maxeval) = maxeval; BQN(phase) = bq::PH_PRELIM;
     for (int i = 0; i < 3; i++) { BQA(xfinal, i) = x0[i]; BQA(xeval, i) = x0[i]; }
     for (int i = 0; i < 3; i++)
@@ -1841,11 +1924,11 @@ BQ_HD_NOINLINE int bq_start(BqRef B, const double* x0, const double* lb, const d
     }
     // prelim_ initialisation (bobyqa.c:1790-1822)
     for (int j = 0; j < 3; j++) { BQA(xbase, j) = xs[j]; BQA(xopt, j) = 0; BQA(gopt, j) = 0; BQA(xnew, j) = 0; BQA(xalt, j) = 0; BQA(d, j) = 0; BQA(gnew, j) = 0; }
-    for (int k = 0; k < 21; k++) { BQA(xpt, k) = 0.0; BQA(zmat, k) = 0.0; }
-    for (int k = 0; k < 30; k++) BQA(bmat, k) = 0.0;
-    for (int k = 0; k < 6; k++) BQA(hq, k) = 0.0;
-    for (int k = 0; k < 7; k++) { BQA(pq, k) = 0.0; BQA(fval, k) = 0.0; BQA(wsuma, k) = 0.0; }
-    for (int k = 0; k < 10; k++) BQA(vlag, k) = 0.0;
+    for (int k = 0; k < 21; k++) { BQ_MA(xpt, k) = 0.0; BQ_COLDA(zmat, k) = 0.0; }
+    for (int k = 0; k < 30; k++) BQ_COLDA(bmat, k) = 0.0;
+    for (int k = 0; k < 6; k++) BQ_MA(hq, k) = 0.0;
+    for (int k = 0; k < 7; k++) { BQ_MA(pq, k) = 0.0; BQ_MA(fval, k) = 0.0; BQA(wsuma, k) = 0.0; }
+    for (int k = 0; k < 10; k++) BQ_COLDA(vlag, k) = 0.0;
     BQS(rho) = BQS(delta) = BQS(diffa) = BQS(diffb) = BQS(diffc) = BQS(dsq) = BQS(crvmin) = BQS(dnorm) = BQS(xoptsq) = BQS(ratio) = BQS(adelt) = 0.0;
     BQS(alpha) = BQS(cauchy) = BQS(beta) = BQS(denom) = BQS(fsave) = BQS(distsq) = BQS(fbeg) = BQS(stepa) = BQS(stepb) = 0.0;
     BQN(kopt) = 1; BQN(knew) = 0; BQN(kbase) = 1; BQN(ntrits) = 0; BQN(itest) = 0; BQN(nresc) = 0; BQN(nfsav) = 0; BQN(nf) = 0;
@@ -1863,7 +1946,10 @@ BQ_HD int bq_step(BqRef B, double f) {
 }
 // everything bq_step does before the label loop: consumes f, returns the label to continue at
 BQ_HD_BLOCK int bq_step_entry(BqRef B, double f);
-BQ_HD_NOINLINE int bq_step_(BqRef B, double f) { return bq::run(B, bq_step_entry(B, f)); }
+BQ_HD_NOINLINE int bq_step_(BqRef B_in, double f) {
+    BqRef B = BQ_UNIFORM(B_in);
+    return bq::run(B, bq_step_entry(B, f));
+}
 BQ_HD_BLOCK int bq_step_entry(BqRef B, double f) {
     int label = bq::LRET_DONE;
     if (BQN(phase) == bq::PH_PRELIM) {

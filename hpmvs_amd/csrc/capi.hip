@@ -689,8 +689,10 @@ extern "C" int hpmvs_selftest_bobyqa(int device, int n, const int32_t* kind, con
     if ((rc = stage_in(sg, dne, (const int*)nevals, N, false))) return rc;
     if ((rc = stage_in(sg, dres, (const int*)rescue_calls, N, false))) return rc;
     if (trace && (rc = stage_in(sg, dtr, (const double*)trace, 4 * N * (size_t)trace_cap, false))) return rc;
+    double* dcold = nullptr;
+    if ((rc = stage_in(sg, dcold, (const double*)xfinal /* (any non-null host pointer: zero-filled) */, selftest_cold_doubles(n), false))) return rc;
     if ((rc = stage_flush(sg))) return rc;
-    launch_selftest(n, dkind, dpar, dx0, dlb, dub, maxeval, dxf, dmin, drc, dne, dres, dtr, trace_cap, nullptr);
+    launch_selftest(n, dkind, dpar, dx0, dlb, dub, maxeval, dxf, dmin, drc, dne, dres, dtr, trace_cap, dcold, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     if ((rc = stage_out(xfinal, dxf, 3 * N))) return rc;

@@ -41,7 +41,21 @@
 // compare-and-swap locks), pages its states in from its parking buffer in global memory with LDS-DMA, runs bq_step
 // kP lanes wide, pages out and releases.  Several times the lanes per optimiser block at the same occupancy.
 #define BQ_SLOTS BQ_P
+// The 58-slot build keeps the optimiser states' big matrices in global memory (kernel_optimize_big.hip sets this): a
+// third state region per CU is worth far more there than the L2 round trips cost (C2: 232 -> 221 ms).  With 29 slots
+// (four regions of 40 KB already) it is the other way round (C1: 24.3 -> 25.5 ms), so this build keeps everything in LDS.
+#ifndef HPMVS_COLD_GLOBAL
+#define HPMVS_COLD_GLOBAL 0
+#endif
+#if HPMVS_COLD_GLOBAL
+#define BQ_COLD_GLOBAL 1     // the big arrays of a state stay in global memory (bobyqa3.hpp): from BQ_COLD_LO = 77 (bmat, zmat, vlag:
+#ifndef BQ_COLD_LO           // 61 of the 164 float64 values) or 36 (xpt, fval, pq, hq as well: 102) up to index 138
+#define BQ_COLD_LO 77
+#endif
+#define HPMVS_STATE_ND (164 - (138 - BQ_COLD_LO))   // ... the others are what a state region holds per slot
+#else
 #define HPMVS_STATE_ND 164
+#endif
 #define HPMVS_STATE_NI 13
 #define HPMVS_REGION_BYTES (HPMVS_STATE_ND * 8 * BQ_P + HPMVS_STATE_NI * 4 * BQ_P)
 #define HPMVS_REGION_KIB ((HPMVS_REGION_BYTES + 1023) / 1024)  // paged in 1 KiB pieces (one LDS-DMA instruction each)
@@ -55,7 +69,11 @@
 #define HPMVS_WG_WAVES 8
 #endif
 #ifndef HPMVS_WG_REGIONS
+#if HPMVS_COLD_GLOBAL
+#define HPMVS_WG_REGIONS 6   // 29 slots x 876 B = 25 KiB per region
+#else
 #define HPMVS_WG_REGIONS 4
+#endif
 #endif
 // This file is compiled four times: as it is (29 slots per wavefront, 4 regions), from kernel_optimize_big.hip (58
 // slots, 2 regions), and twice more with the throughput-mode window sums (kernel_optimize_tree.hip,
@@ -80,7 +98,7 @@ extern __shared__ uint4 hpmvs_dyn[];
 
 namespace hpmvs {
 
-static_assert(BQ_ND == HPMVS_STATE_ND && BQ_NI == HPMVS_STATE_NI, "state region sized for another layout");
+static_assert(BQ_ND_LDS == HPMVS_STATE_ND && BQ_NI == HPMVS_STATE_NI, "state region sized for another layout");
 
 namespace {
 
@@ -171,6 +189,16 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
     uint4* park = (uint4*)((char*)queue + kCounterBytes + (size_t)W * n_wgs * kP * kRow * sizeof(uint16_t)) + (size_t)gw * kPark16;
     // ... and its result rows: per slot one row of kRow floats, where the photometric service leaves a request's per-image
     // values until the requesting lane adds them up (wave_eval_rows, step 7)
+#if HPMVS_COLD_GLOBAL
+    // ... and its block of the optimiser states' cold arrays (bobyqa3.hpp, BQ_COLD_GLOBAL): [index][slot], never paged
+    char* cold = (char*)queue + kCounterBytes + (size_t)W * n_wgs * kP * kRow * sizeof(uint16_t) + (size_t)W * n_wgs * kPark16 * 16 +
+                 (size_t)W * n_wgs * kP * kRow * sizeof(float) + (size_t)gw * BQ_NCOLD * kP * sizeof(double);
+    {   // the same on all lanes: kept in scalar registers
+        const unsigned long long a = (unsigned long long)cold;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(a & 0xffffffffull)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32));
+        cold = (char*)(((unsigned long long)hi << 32) | lo);
+    }
+#endif
     const GlobalRows erows{(float*)((char*)queue + kCounterBytes + (size_t)W * n_wgs * kP * kRow * sizeof(uint16_t) +
                                     (size_t)W * n_wgs * kPark16 * 16) + (size_t)gw * kP * kRow, kRow};
 
@@ -209,6 +237,11 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
     Bobyqa3 B;
     B.slot = lane < kP ? lane : 0;
     B.slot_i = B.slot;
+#if HPMVS_COLD_GLOBAL
+    B.coff = (unsigned)B.slot * 8u;
+    B.coldp = cold;
+    B.cold = __builtin_amdgcn_make_buffer_rsrc(cold, 0, BQ_NCOLD * BQ_CSTRIDE * 8, 0x00020000);  // (rebuilt as a scalar inside the optimiser's real functions)
+#endif
     // request posted to phase B (with the patch axes of calculatePatchAxis for the request's reference image)
     float ax[3] = {0, 0, 0}, ay[3] = {0, 0, 0}, az[3] = {0, 0, 1};
     int op = OP_NONE, req_ref = 0, req_robust = 0;
@@ -649,14 +682,15 @@ static int max_workgroups(int n_cus, int waves, int regions) {
 size_t HPMVS_V(optimize_workspace_bytes)(int n_cus) {
     // counter block + per wavefront: kP image-list rows, one parking buffer for the optimiser states, kP result rows
     const size_t waves = (size_t)HPMVS_WG_WAVES * max_workgroups(n_cus, HPMVS_WG_WAVES, HPMVS_WG_REGIONS);
-    return kCounterBytes + waves * kP * kRow * sizeof(uint16_t) + waves * (size_t)kPark16 * 16 + waves * kP * kRow * sizeof(float);
+    return kCounterBytes + waves * kP * kRow * sizeof(uint16_t) + waves * (size_t)kPark16 * 16 + waves * kP * kRow * sizeof(float) +
+           waves * (size_t)(HPMVS_COLD_GLOBAL ? (164 - HPMVS_STATE_ND) : 0) * kP * sizeof(double);
 }
 
 #ifndef HPMVS_VARIANT_SUFFIX
 // open batch (b.svc_ctrl set): a fixed grid of `wgs` two-wavefront workgroups (one per CU leaves room for batch launches beside it)
 size_t optimize_workspace_bytes_for(int wgs) {
     return kCounterBytes + (size_t)2 * wgs * kP * kRow * sizeof(uint16_t) + (size_t)2 * wgs * (size_t)kPark16 * 16 +
-           (size_t)2 * wgs * kP * kRow * sizeof(float);
+           (size_t)2 * wgs * kP * kRow * sizeof(float) + (size_t)2 * wgs * (size_t)(HPMVS_COLD_GLOBAL ? (164 - HPMVS_STATE_ND) : 0) * kP * sizeof(double);
 }
 size_t optimize_stage_bytes_for(int wgs) { return (size_t)2 * wgs * kP * kSvcOutDwords * sizeof(uint32_t); }
 void launch_optimize_service(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int wgs,

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #define BQ_STATE_LDS 1
+#define BQ_COLD_GLOBAL 1  // as in the product kernel: bmat, zmat, vlag in global memory
 #define BQ_P 32
 #define BQ_SLOTS 32
 namespace hpmvs { __shared__ int st_rescue_calls[BQ_SLOTS]; }
@@ -20,13 +21,16 @@ namespace hpmvs {
 __global__ void __launch_bounds__(64) selftest_kernel(int n, const int* kind, const double* params, const double* x0,
                                                       const double* lb, const double* ub, int maxeval, double* xfinal,
                                                       double* minf, int* rc, int* nevals, int* rescues, double* trace,
-                                                      int trace_cap) {
+                                                      int trace_cap, double* cold) {
     const int lane = (int)__lane_id();
     const int prob = (int)blockIdx.x * BQ_P + lane;
     const bool active = lane < BQ_P && prob < n;
     Bobyqa3 B;
     B.slot = lane < BQ_P ? lane : 0;
     B.slot_i = B.slot;
+    B.coff = (unsigned)B.slot * 8u;
+    B.coldp = (char*)(cold + (size_t)blockIdx.x * BQ_NCOLD * BQ_P);
+    B.cold = __builtin_amdgcn_make_buffer_rsrc(B.coldp, 0, BQ_NCOLD * BQ_CSTRIDE * 8, 0x00020000);
     if (lane < BQ_P) st_rescue_calls[lane] = 0;
     int st = BQ_DONE, k = 0, nt = 0;
     double p[ST_PARAMS];
@@ -64,10 +68,11 @@ __global__ void __launch_bounds__(64) selftest_kernel(int n, const int* kind, co
 
 void launch_selftest(int n, const int* kind, const double* params, const double* x0, const double* lb, const double* ub,
                      int maxeval, double* xfinal, double* minf, int* rc, int* nevals, int* rescues, double* trace,
-                     int trace_cap, hipStream_t st) {
+                     int trace_cap, double* cold, hipStream_t st) {
     if (n <= 0) return;
     hipLaunchKernelGGL(selftest_kernel, dim3((n + BQ_P - 1) / BQ_P), dim3(64), 0, st, n, kind, params, x0, lb, ub, maxeval,
-                       xfinal, minf, rc, nevals, rescues, trace, trace_cap);
+                       xfinal, minf, rc, nevals, rescues, trace, trace_cap, cold);
 }
+size_t selftest_cold_doubles(int n) { return (size_t)((n + BQ_P - 1) / BQ_P) * BQ_NCOLD * BQ_P; }
 
 }  // namespace hpmvs

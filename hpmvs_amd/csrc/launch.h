@@ -45,6 +45,7 @@ void launch_unpack_records(const void* records, int n, const DevBatch& b, hipStr
 // diagnostics: the BOBYQA state machine on analytic objectives (kernel_selftest.hip); device pointers
 void launch_selftest(int n, const int* kind, const double* params, const double* x0, const double* lb, const double* ub,
                      int maxeval, double* xfinal, double* minf, int* rc, int* nevals, int* rescues, double* trace,
-                     int trace_cap, hipStream_t st);
+                     int trace_cap, double* cold, hipStream_t st);
+size_t selftest_cold_doubles(int n);  // doubles of the `cold` scratch (the optimiser states' cold arrays) for n problems
 
 }  // namespace hpmvs
