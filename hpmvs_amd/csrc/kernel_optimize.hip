@@ -170,6 +170,9 @@ __device__ __forceinline__ unsigned long long ld_host64(const unsigned long long
 #ifndef HPMVS_BQ_PRIO
 #define HPMVS_BQ_PRIO 3  // s_setprio while the state region is held (C2: 308 -> 302 ms)
 #endif
+#ifndef HPMVS_LOCK_SLEEP
+#define HPMVS_LOCK_SLEEP 8
+#endif
 #ifndef HPMVS_A_PRIO
 #define HPMVS_A_PRIO 2   // ... and in the rest of phase A (serial per-lane code the whole wavefront waits for); the
                         // photometric service runs at 0 (C2: 300 -> 296.5 ms)
@@ -515,7 +518,7 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
                     for (;;) {
                         if (atomicCAS(&hpmvs_lock[r], 0, 1 + wv) == 0) break;
                         r = r + 1 == R ? 0 : r + 1;
-                        if (r == (R > 1 ? wv % R : 0)) __builtin_amdgcn_s_sleep(8);  // every region is taken
+                        if (r == (R > 1 ? wv % R : 0)) __builtin_amdgcn_s_sleep(HPMVS_LOCK_SLEEP);  // every region is taken
                     }
                     got = r;
                 }
