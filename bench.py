@@ -555,8 +555,8 @@ def cpu_leg(out, args, scene, seeds, n_seeds, work, ok, nevals, stage):
                      p.nevals == nev_g[k] and list(p.images[:p.n_images]) == list(img_g[k, :nim_g[k]]))
         dncc.append(abs(unrob(p.fmin) - unrob(fmin_g[k])))
         ddist = np.linalg.norm(np.array(p.center[:3]) - cen_g[k, :3]) / float(seeds.scale[k])
-        cs = float(np.clip(np.dot(np.array(p.normal[:3]), nor_g[k, :3]), -1, 1))
-        ang = float(np.degrees(np.arccos(cs)))
+        na, nb = np.array(p.normal[:3], dtype=np.float64), nor_g[k, :3].astype(np.float64)
+        ang = float(np.degrees(np.arctan2(np.linalg.norm(np.cross(na, nb)), np.dot(na, nb))))  # (0 for identical vectors; arccos of a float32 dot is not)
         ddepth.append(ddist); dangle.append(ang)
         basin.append(ddist < 0.25 and ang < 2.0)
     out["cpu_baseline"] = {

@@ -50,8 +50,8 @@ def compare(P, g, scale):
                      p.nevals == g["nevals"][k] and list(p.images[:p.n_images]) == list(g["images"][k, :g["n_images"][k]]))
         dncc.append(abs(unrob(p.fmin) - unrob(g["fmin"][k])))
         dd = np.linalg.norm(np.array(p.center[:3]) - g["center"][k, :3]) / float(scale[k])
-        cs = float(np.clip(np.dot(np.array(p.normal[:3]), g["normal"][k, :3]), -1, 1))
-        basin.append(dd < 0.25 and np.degrees(np.arccos(cs)) < 2.0)
+        na, nb = np.array(p.normal[:3], dtype=np.float64), g["normal"][k, :3].astype(np.float64)
+        basin.append(dd < 0.25 and np.degrees(np.arctan2(np.linalg.norm(np.cross(na, nb)), np.dot(na, nb))) < 2.0)
     return {"sample": len(okc), "decision_agreement": float((okc == okg).mean()),
             "success_set_jaccard": float((okc & okg).sum() / max(1, (okc | okg).sum())),
             "stage_agreement": float((np.array([p.stage for p in P]) == g["stage"]).mean()),
