@@ -1,6 +1,7 @@
 """The drop-in C++ interface (mo3d::PatchOptimizer::optimize / optimizeBatch, include/hpmvs/*.h) driven by a
 reference-style caller (tests/native/test_patchoptimizer.cpp) must give exactly what the C ABI gives."""
 import os
+import sys
 import struct
 import subprocess
 
@@ -138,18 +139,27 @@ def test_unchanged_callers_in_a_loop(tiny_scene, tmp_path):
         rows.append(row)
         assert row["mismatches"] == 0 and row["refined"] > n // 2
     # the CPU path on the same patches, all host threads (the oracle: restated photometric path + genuine NLopt)
+    # (on the cores this container may really use: the GPU boxes show 256 hardware threads behind a CFS quota of 16 CPUs,
+    #  and 256 OpenMP threads under that quota are SLOWER than 16 -- DESIGN 6.0; the callers above live under the same quota)
+    sys.path.insert(0, ROOT)
+    import bench
+    cores, quota = bench.usable_cores(nproc)
     osc = orc.OracleScene(tiny_scene)
     P = orc.patches_from_seeds(seeds)
     t0 = time.perf_counter()
-    orc.optimize_batch(osc, P, n_threads=nproc)
+    orc.optimize_batch(osc, P, n_threads=cores)
     cpu_rate = n / (time.perf_counter() - t0)
-    out = {"host_threads": nproc, "cpu_oracle_patches_per_s": cpu_rate, "rows": rows}
+    out = {"host_threads": nproc, "cpu_threads_used": cores, "cpu_quota": quota, "cpu_oracle_patches_per_s": cpu_rate, "rows": rows}
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(out, open("gpurun_out/callers.json", "w"), indent=1)
     print(out)
     at_nproc = [r for r in rows if r["path"] == "open batch" and r["threads"] == nproc][0]["calls_patches_per_s"]
     assert at_nproc >= 30000.0 or nproc < 128, (at_nproc, "unchanged callers at the box's thread count (VERDICT r2 #3)")
     assert at_nproc >= 0.5 * cpu_rate, (at_nproc, cpu_rate)
+    # with enough callers in flight the unchanged-caller loop beats the CPU path it replaces (a caller waits ~3 ms for its own
+    # patch, so the rate is threads / 3 ms until the host side saturates)
+    best = max(r["calls_patches_per_s"] for r in rows if r["path"] == "open batch")
+    assert best >= cpu_rate or nproc < 128, (best, cpu_rate)
 
 
 def test_cpp_host_round_with_rccl_allgather(tiny_scene, tiny_seeds, gpu_scene, tmp_path):
