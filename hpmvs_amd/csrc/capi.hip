@@ -77,6 +77,7 @@ struct hpmvs_scene {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t slot_done[kQueueSlots] = {};   // recorded behind the last launch that used workspace k
     mutable bool slot_used[kQueueSlots] = {};
+    mutable hipStream_t slot_stream[kQueueSlots] = {};   // the stream workspace k's last launch went to
     mutable std::recursive_mutex mu;  // (recursive: Exclusive scopes nest with the workspace hand-out)
     mutable bool timed = false;
     // Small host-pointer batches (the unchanged callers' optimize() = batch of 1, and what a combiner makes of
@@ -96,11 +97,15 @@ static void service_free(hpmvs_scene* s);
 // Workspace hand-out (call with s->mu held).  Before a workspace is reused the launch that used it last must
 // have finished: more than kQueueSlots launches in flight against one scene (e.g. 256 OpenMP threads each
 // calling optimize()) simply queue up here instead of sharing a counter / image-list rows.
-static int acquire_workspace(const hpmvs_scene* s, int32_t** q, int* slot) {
-    // A workspace whose last launch has finished is taken again; only when every allocated one is still in flight does
-    // the scene grow another (179 MB each: a scene driven by one scheduler thread never needs more than one or two),
-    // and with all kQueueSlots in flight the caller waits for the oldest.
+static int acquire_workspace(const hpmvs_scene* s, int32_t** q, int* slot, hipStream_t st) {
+    // The workspace whose last launch went to THIS stream is taken again without any wait: the counter-block memset and the
+    // kernel of the new launch are ordered behind the old one by the stream itself (a scheduler that enqueues round after
+    // round on one stream, like bench.py, never needs a second workspace).  Otherwise one whose last launch has finished;
+    // only when every allocated one is still in flight on OTHER streams does the scene grow another (~210 MB each), and
+    // with all kQueueSlots in flight the caller waits for the oldest.
     int k = -1;
+    for (int i = 0; i < s->n_queues && k < 0; i++)
+        if (s->slot_used[i] && s->slot_stream[i] == st) k = i;
     for (int i = 0; i < s->n_queues && k < 0; i++) {
         const int c = (int)((s->next_slot + i) % (unsigned)s->n_queues);
         if (!s->slot_used[c]) k = c;
@@ -121,6 +126,7 @@ static int acquire_workspace(const hpmvs_scene* s, int32_t** q, int* slot) {
         HIPCHK(hipEventSynchronize(s->slot_done[k]));
     }
     s->next_slot = (unsigned)k + 1;
+    s->slot_stream[k] = st;
     *q = s->dqueue[k];
     *slot = k;
     s->last_queue = *q;
@@ -578,7 +584,7 @@ static int enqueue_refinement(const hpmvs_scene* s, const DevOptions& d, const D
     {
         int32_t* q;
         int slot;
-        if ((rc = acquire_workspace(s, &q, &slot))) return rc;
+        if ((rc = acquire_workspace(s, &q, &slot, st))) return rc;
         // whatever happens below, the slot's event is recorded behind the work that was enqueued, so that the next
         // user of this workspace waits for it
         struct Release { const hpmvs_scene* s; int slot; hipStream_t st; ~Release() { hipEventRecord(s->slot_done[slot], st); s->slot_used[slot] = true; } } rel{s, slot, st};
