@@ -125,6 +125,9 @@ static int acquire_workspace(const hpmvs_scene* s, int32_t** q, int* slot, hipSt
         k = (int)(s->next_slot % kQueueSlots);
         HIPCHK(hipEventSynchronize(s->slot_done[k]));
     }
+    // whatever path chose it: the new launch is ordered behind the workspace's previous one on the device (a no-op for the
+    // same stream and for a finished launch; it also covers a stream handle that was destroyed and handed out again)
+    if (s->slot_used[k]) HIPCHK(hipStreamWaitEvent(st, s->slot_done[k], 0));
     s->next_slot = (unsigned)k + 1;
     s->slot_stream[k] = st;
     *q = s->dqueue[k];
