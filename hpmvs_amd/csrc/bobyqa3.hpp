@@ -221,7 +221,9 @@ enum {  // int32 slots
 #ifndef BQ_COLD_LO
 #define BQ_COLD_LO 77   /* O_bmat; 36 = O_xpt: xpt, fval, pq, hq as well (the range is contiguous up to O_wsuma) */
 #endif
-#define BQ_COLD_HI 138  /* O_wsuma */
+#ifndef BQ_COLD_HI
+#define BQ_COLD_HI 138  /* O_wsuma; 145 = O_minf: wsuma (and rescue_'s ptsid, which shares its slots) as well */
+#endif
 #define BQ_NCOLD (BQ_COLD_HI - BQ_COLD_LO)
 #define BQ_ND_LDS (164 - BQ_NCOLD)
 #ifndef BQ_CSTRIDE
@@ -258,6 +260,11 @@ __device__ __forceinline__ bq_cold_ref bq_cold_at(const Bobyqa3& B, int i) {  //
 #define BQ_HOTIDX(i) ((i) < BQ_COLD_LO ? (i) : (i) - BQ_NCOLD)
 #define BQ_D(i) bq_lds_d[BQ_HOTIDX(i) * BQ_SLOTS + B.slot]
 #define BQ_C(i) bq_cold_at(B, (i))
+#if BQ_COLD_HI >= 145
+#define BQ_W(i) bq_cold_at(B, (i))   /* wsuma / ptsid are cold too */
+#else
+#define BQ_W(i) BQ_D(i)
+#endif
 #if BQ_COLD_LO <= 36
 #define BQ_M(i) bq_cold_at(B, (i))   /* xpt, fval, pq, hq are cold too */
 #else
@@ -268,6 +275,7 @@ struct Bobyqa3 { int slot; int slot_i; };  // slot: index into the float64 array
 #define BQ_D(i) bq_lds_d[(i) * BQ_SLOTS + B.slot]
 #define BQ_C(i) BQ_D(i)
 #define BQ_M(i) BQ_D(i)
+#define BQ_W(i) BQ_D(i)
 #endif
 #define BQ_I(i) bq_lds_i[(i) * BQ_SLOTS + B.slot_i]
 #if defined(BQ_COLD_GLOBAL)
@@ -289,6 +297,7 @@ struct Bobyqa3 { double dd[BQ_ND]; int ii[BQ_NI]; };
 #define BQ_D(i) B.dd[(i)]
 #define BQ_C(i) B.dd[(i)]
 #define BQ_M(i) B.dd[(i)]
+#define BQ_W(i) B.dd[(i)]
 #define BQ_I(i) B.ii[(i)]
 #define BQ_UNIFORM(Bin) (Bin)
 #endif
@@ -320,10 +329,11 @@ typedef Bobyqa3& BqRef;
 #else
 #define BQ_EITHER(i) BQ_D(i)
 #endif
+#define BQ_WS(idx) BQ_W(O_wsuma + (idx))              // element of wsuma (rescue_'s ptsid shares the slots): hot or cold by configuration
 #define BQ_COLDA(name, idx) BQ_C(O_##name + (idx))
 #define BQ_MA(name, idx) BQ_M(O_##name + (idx))      // 0-based element of xpt / fval / pq / hq: hot or cold by configuration  // 0-based element of one of the cold arrays (bmat, zmat, vlag)
 #define BQ_PA(i, j) BQ_D(O_ptsaux + ((j) - 1) * 2 + ((i) - 1))  // PTSAUX(i,j) of rescue_
-#define BQ_PTSID(k) BQ_D(O_ptsid + (k) - 1)
+#define BQ_PTSID(k) BQ_W(O_ptsid + (k) - 1)
 
 namespace bq {
 
@@ -1378,7 +1388,7 @@ BQ_HD_BLOCK int label230(BqRef B) {
             }
             w[k - 1] = suma * (0.5 * suma + sumb);
             vl[k - 1] = sum;
-            BQA(wsuma, k - 1) = suma;
+            BQ_WS(k - 1) = suma;
             double ds = 0.0;  // pick_knew's distance of point k from xopt
             for (int j = 1; j <= 3; j++) { const double t = xp[k - 1][j - 1] - xo[j - 1]; ds += t * t; }
             distsq[k - 1] = ds;
@@ -1698,7 +1708,7 @@ BQ_HD_BLOCK int after_eval(BqRef B, double f) {
         double dd[3], go[3], hq[6], pq[7], ws[7];
         for (int j = 0; j < 3; j++) { dd[j] = BQ_V(d, j + 1); go[j] = BQ_V(gopt, j + 1); }
         for (int i = 0; i < 6; i++) hq[i] = BQ_HQ(i + 1);
-        for (int k = 0; k < 7; k++) { pq[k] = BQ_PQ(k + 1); ws[k] = BQA(wsuma, k); }
+        for (int k = 0; k < 7; k++) { pq[k] = BQ_PQ(k + 1); ws[k] = BQ_WS(k); }
         int ih = 0;
         for (int j = 1; j <= 3; j++) {
             vquad += dd[j - 1] * go[j - 1];
@@ -1927,7 +1937,7 @@ BQ_HD_NOINLINE int bq_start(BqRef B_in, const double* x0, const double* lb, cons
     for (int k = 0; k < 21; k++) { BQ_MA(xpt, k) = 0.0; BQ_COLDA(zmat, k) = 0.0; }
     for (int k = 0; k < 30; k++) BQ_COLDA(bmat, k) = 0.0;
     for (int k = 0; k < 6; k++) BQ_MA(hq, k) = 0.0;
-    for (int k = 0; k < 7; k++) { BQ_MA(pq, k) = 0.0; BQ_MA(fval, k) = 0.0; BQA(wsuma, k) = 0.0; }
+    for (int k = 0; k < 7; k++) { BQ_MA(pq, k) = 0.0; BQ_MA(fval, k) = 0.0; BQ_WS(k) = 0.0; }
     for (int k = 0; k < 10; k++) BQ_COLDA(vlag, k) = 0.0;
     BQS(rho) = BQS(delta) = BQS(diffa) = BQS(diffb) = BQS(diffc) = BQS(dsq) = BQS(crvmin) = BQS(dnorm) = BQS(xoptsq) = BQS(ratio) = BQS(adelt) = 0.0;
     BQS(alpha) = BQS(cauchy) = BQS(beta) = BQS(denom) = BQS(fsave) = BQS(distsq) = BQS(fbeg) = BQS(stepa) = BQS(stepb) = 0.0;

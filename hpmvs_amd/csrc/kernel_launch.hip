@@ -32,11 +32,11 @@ int optimize_sums_mode() {
 
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus,
                      hipStream_t st) {
-    // HPMVS_SLOTS=29 / 60 forces one build (measurements; 58, the big build's slot count until round 4, means it too);
-    // otherwise the 60-slot build from 480 patches per CU (122 880 on an MI355X), where its lower cost per patch has paid
+    // HPMVS_SLOTS=29 / 64 forces one build (measurements; 58 and 60, the big build's earlier slot counts, mean it too);
+    // otherwise the 64-slot build from 480 patches per CU (122 880 on an MI355X), where its lower cost per patch has paid
     // for its longer ramp-down (C2 scene, round 4: 250 k patches 64.4 ms against 66.7, 500 k 119 against 127)
     static const int forced = [] { const char* e = getenv("HPMVS_SLOTS"); return e ? atoi(e) : 0; }();
-    const bool big = forced == 58 || forced == 60 || (forced != 29 && (long long)b.n >= 480ll * n_cus);
+    const bool big = forced == 58 || forced == 60 || forced == 64 || (forced != 29 && (long long)b.n >= 480ll * n_cus);
     if (optimize_sums_mode() == 1) {
         if (big) launch_optimize_big_tree(sc, o, b, workspace, n_cus, st);
         else launch_optimize_tree(sc, o, b, workspace, n_cus, st);

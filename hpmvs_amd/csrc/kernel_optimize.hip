@@ -52,7 +52,10 @@
 #ifndef BQ_COLD_LO           // 61 of the 164 float64 values) or 36 (xpt, fval, pq, hq as well: 102) up to index 138
 #define BQ_COLD_LO 77
 #endif
-#define HPMVS_STATE_ND (164 - (138 - BQ_COLD_LO))   // ... the others are what a state region holds per slot
+#ifndef BQ_COLD_HI
+#define BQ_COLD_HI 138       // (145: wsuma as well)
+#endif
+#define HPMVS_STATE_ND (164 - (BQ_COLD_HI - BQ_COLD_LO))   // ... the others are what a state region holds per slot
 #else
 #define HPMVS_STATE_ND 164
 #endif

@@ -8,7 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #define BQ_STATE_LDS 1
-#define BQ_COLD_GLOBAL 1  // as in the product kernel: bmat, zmat, vlag in global memory
+#define BQ_COLD_GLOBAL 1  // as in the product kernel's 64-slot build: bmat, zmat, vlag, wsuma in global memory
+#define BQ_COLD_HI 145
 #define BQ_P 32
 #define BQ_SLOTS 32
 namespace hpmvs { __shared__ int st_rescue_calls[BQ_SLOTS]; }

@@ -338,7 +338,7 @@ def test_batch_order_does_not_matter(tiny_scene, tiny_seeds, gpu_scene):
 
 def test_both_builds_of_the_kernel_give_the_same_results(tiny_scene, tiny_seeds, gpu_scene, tmp_path):
     """The library holds two builds of the refinement kernel (29 patch slots per wavefront / 4 state regions per CU, all
-    optimiser state in LDS; and 60 slots / 3 regions with the optimiser's big matrices in global memory behind buffer
+    optimiser state in LDS; and 64 slots / 3 regions with the optimiser's big matrices and wsuma in global memory behind buffer
     loads, for batches from 480 patches per CU upwards, kernel_launch.hip).  The same seeds through each build,
     forced with HPMVS_SLOTS in separate processes: every output array is byte-identical, and equal to the in-process
     run (which the other tests compare with the oracle)."""
@@ -359,19 +359,19 @@ np.savez(sys.argv[1], ok=b.ok, center=b.center, normal=b.normal, n_images=b.n_im
          fmin=b.fmin, x=b.x, nevals=b.nevals, stage=b.stage, result=b.result)
 ''' % root
     outs = {}
-    for slots in ("29", "60"):
+    for slots in ("29", "64"):
         f = str(tmp_path / f"slots{slots}.npz")
         r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, HPMVS_SLOTS=slots), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[slots] = np.load(f)
     for k in outs["29"].files:
-        assert np.array_equal(outs["29"][k], outs["60"][k]), k
+        assert np.array_equal(outs["29"][k], outs["64"][k]), k
     assert outs["29"]["ok"].sum() > 1000
     b = api.Batch.from_seeds(tiny_seeds, np.arange(len(tiny_seeds.scale)))
     api.optimize_batch(gpu_scene, b)
     n = len(tiny_seeds.scale)
-    assert np.array_equal(outs["60"]["ok"][:n], b.ok) and np.array_equal(outs["60"]["center"][:n], b.center)
-    assert np.array_equal(outs["60"]["nevals"][:n], b.nevals) and np.array_equal(outs["60"]["x"][:n], b.x)
+    assert np.array_equal(outs["64"]["ok"][:n], b.ok) and np.array_equal(outs["64"]["center"][:n], b.center)
+    assert np.array_equal(outs["64"]["nevals"][:n], b.nevals) and np.array_equal(outs["64"]["x"][:n], b.x)
 
 
 def test_batch_launch_while_single_patch_callers_keep_an_open_batch_busy(tiny_seeds, gpu_scene):
