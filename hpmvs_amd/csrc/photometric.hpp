@@ -575,6 +575,8 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
 
         for (;;) {
             PH_T(t3);
+            int rsrc = lane;     // lane that holds (after step 4 of this pass at the latest) my row of the reference texels I correlate with
+            bool moved = false;  // (wave-uniform) groups took images over in this pass: their reference texels travel before step 5
             // ---- 1. idle groups take the next pending requests, long requests first (fewest idle group-passes at the
             //         end of the batch): three length classes
             {
@@ -600,7 +602,7 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
                 //          the reference texels of all take-overs of a round travel in one set of 21 ds_bpermute.
                 while (HPMVS_TAKE_OVER && idle) {  // (only reached with todo == 0)
                     const int left = (glane && g_req >= 0) ? __popcll(g_ok) : 0;   // identical on a group's lanes
-                    int best = 0, n_best = 0, any_ref = 0;
+                    int best = 0, n_best = 0;
                     unsigned long long vmask = 0ull;  // leaders of the groups at the maximum
 #pragma unroll
                     for (int g = 0; g < kGroups; g++) {
@@ -609,31 +611,22 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
                         if (l == best && l > 0) { n_best++; vmask |= 1ull << (g * kTex); }
                     }
                     if (best < 1 || __popcll(idle) < n_best) break;
-                    for (unsigned long long t = vmask; t; t &= t - 1ull) any_ref |= bcast_i(g_isref ? 1 : 0, __ffsll((long long)t) - 1);
-                    if (any_ref && best < 2) break;  // a group that has not sampled its reference image yet cannot hand its texels over
-                    int src = lane;  // lane my reference texels come from (thieves of groups that have theirs: the victim's lane)
-                    bool moved = false;
                     for (unsigned long long t = vmask; t; t &= t - 1ull) {
                         const int vl = __ffsll((long long)t) - 1;  // the victim's first lane
                         const int tl = __ffsll((long long)idle) - 1;
                         idle &= idle - 1ull;
-                        const int v_isref = bcast_i(g_isref ? 1 : 0, vl);
-                        const int take = v_isref ? best / 2 : (best + 1) / 2;
+                        const int take = (best + 1) / 2;
                         unsigned long long hi = bcast_u64(g_ok, vl);
                         for (int i = 0; i < best - take; i++) hi &= hi - 1ull;  // the victim keeps its lowest images
                         const int r_req = bcast_i(g_req, vl), r_off = bcast_i(g_off, vl), r_ref = bcast_i(g_ref, vl), r_rob = bcast_i(g_userob, vl);
+                        const int r_src = bcast_i(rsrc, vl);  // where the victim's reference texels are, or will be in this pass (its own lane unless it is a helper of this pass itself)
                         if (gl0 == vl) g_ok &= ~hi;
                         if (gl0 == tl && glane) {
                             g_req = r_req; g_off = r_off; g_ref = r_ref; g_userob = r_rob;
-                            if (v_isref) { g_cur = r_ref; g_isref = true; g_ok = hi; }
-                            else { g_cur = __ffsll((long long)hi) - 1; g_ok = hi & (hi - 1ull); g_isref = false; src = vl + yy; }
+                            g_cur = __ffsll((long long)hi) - 1; g_ok = hi & (hi - 1ull); g_isref = false; rsrc = r_src + yy;
                         }
-                        moved |= !v_isref;
                     }
-                    if (moved) {  // (wave-uniform) the victims' normalised reference texels, row by row
-#pragma unroll
-                        for (int i = 0; i < kRowVals; i++) refn[i] = shfl_f(refn[i], src);
-                    }
+                    moved = true;
                 }
             }
             const bool act = glane && g_req >= 0;
@@ -747,6 +740,11 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
             float raw = 0.0f, rob = 0.0f;
 #pragma unroll
             for (int i = 0; i < kRowVals; i++) refn[i] = g_isref ? t[i] : refn[i];
+            if (moved) {  // (wave-uniform) the helpers of this pass fetch their victims' normalised reference texels, row by row --
+                          // also those a victim has only just sampled: a request's reference image and its other images run side by side
+#pragma unroll
+                for (int i = 0; i < kRowVals; i++) refn[i] = shfl_f(refn[i], rsrc);
+            }
             PH_T(t6);
             PH_ADD(t5, t6, 20);
             if (__any(act && !g_isref)) {  // (wave-uniform) the first pass of a batch is all reference grabs: nothing to correlate
