@@ -20,5 +20,13 @@
 #ifndef HPMVS_WG_REGIONS
 #define HPMVS_WG_REGIONS 3   /* (2 regions of 84 KB without BQ_COLD_GLOBAL: pass -DHPMVS_COLD_GLOBAL=0 -DHPMVS_WG_REGIONS=2 -DHPMVS_BIG_P=58) */
 #endif
+// the lone-request shortcuts of the photometric service (photometric.hpp) stay out of this build: the extra code costs
+// its 64-slot rounds more registers (spills) than its short ramp-down gets back (round 4: C2 +1 %)
+#ifndef HPMVS_SPLIT_PREP
+#define HPMVS_SPLIT_PREP 0
+#endif
+#ifndef HPMVS_SINGLE_FAST
+#define HPMVS_SINGLE_FAST 0
+#endif
 #define HPMVS_VARIANT_SUFFIX _big
 #include "kernel_optimize.hip"

@@ -370,6 +370,12 @@ __device__ __forceinline__ void row_chain_pair(const float (&va)[N], const float
 #ifndef HPMVS_FAST_SUMS
 #define HPMVS_FAST_SUMS 0
 #endif
+#ifndef HPMVS_SPLIT_PREP
+#define HPMVS_SPLIT_PREP 1
+#endif
+#ifndef HPMVS_SINGLE_FAST
+#define HPMVS_SINGLE_FAST 1
+#endif
 #ifndef HPMVS_TAKE_OVER
 #define HPMVS_TAKE_OVER 1  // idle groups take over images of the busiest ones (wave_eval_rows, step 1b)
 #endif
@@ -518,10 +524,30 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
             }
             ViewRegs VR[kJobSets];
 #pragma unroll
-            for (int k = 0; k < kJobSets; k++) VR[k] = load_view(sc.views[jid[k]]);
+            for (int k = 0; k < kJobSets; k++) {
+                VR[k] = ViewRegs{};
+                if (k == 0 || J > 64) VR[k] = load_view(sc.views[jid[k]]);
+            }
+            // (wave-uniform branch: a lone request, or the last few of a round, fill the first set only; when the others are in
+            //  use the sets' arithmetic stays one straight block, so that the compiler interleaves their dependent chains)
+#if HPMVS_SPLIT_PREP == 2
 #pragma unroll
             for (int k = 0; k < kJobSets; k++) {
-                PS[k] = prep_from_view(sc, VR[k], o, jc[k], jscale[k], jx[k], jy[k], jz[k]);
+                PS[k] = Prep{};
+                if (k == 0 || J > 64) PS[k] = prep_from_view(sc, VR[k], o, jc[k], jscale[k], jx[k], jy[k], jz[k]);
+            }
+#else
+            if (kJobSets == 1 || !HPMVS_SPLIT_PREP || J > 64) {
+#pragma unroll
+                for (int k = 0; k < kJobSets; k++) PS[k] = prep_from_view(sc, VR[k], o, jc[k], jscale[k], jx[k], jy[k], jz[k]);
+            } else {
+                PS[0] = prep_from_view(sc, VR[0], o, jc[0], jscale[0], jx[0], jy[0], jz[0]);
+#pragma unroll
+                for (int k = 1; k < kJobSets; k++) PS[k] = Prep{};
+            }
+#endif
+#pragma unroll
+            for (int k = 0; k < kJobSets; k++) {
                 PS[k].ok = (J > 64 * k && jp[k] >= 0) ? PS[k].ok : 0;
                 okS[k] = __ballot(PS[k].ok != 0);
                 const unsigned long long pb = (unsigned long long)PS[k].pix;
@@ -573,6 +599,7 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
 #pragma unroll
         for (int i = 0; i < kRowVals; i++) refn[i] = 0.0f;
 
+        bool single = HPMVS_SINGLE_FAST && __popcll(todo) == 1;  // (wave-uniform)
         for (;;) {
             PH_T(t3);
             int rsrc = lane;     // lane that holds (after step 4 of this pass at the latest) my row of the reference texels I correlate with
@@ -593,6 +620,31 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
                         g_req = p; g_off = r_off; g_ref = r_ref; g_userob = r_rob;
                         g_ok = r_ok & ~(1ull << r_ref);
                         g_cur = r_ref; g_isref = true;
+                    }
+                }
+                // ---- 1a. the batch is ONE request (a lone patch: the ramp-down of a launch, a single-patch caller): its
+                //          reference image stays with the first group, the next eight usable images go to one group each --
+                //          what the take-over rounds below arrive at, without their searches
+                if (single) {  // (wave-uniform; first pass of the batch only)
+                    single = false;
+                    const unsigned long long nonref = bcast_u64(g_ok, 0);
+                    const int n_other = __popcll(nonref);
+                    const int nh = n_other < kGroups - 1 ? n_other : kGroups - 1;
+                    if (nh > 0) {
+                        const int r_req = bcast_i(g_req, 0), r_off = bcast_i(g_off, 0), r_ref = bcast_i(g_ref, 0), r_rob = bcast_i(g_userob, 0);
+                        unsigned long long mine = nonref, rest = nonref;
+#pragma unroll
+                        for (int i = 1; i < kGroups; i++) {
+                            if (i < grp) mine &= mine - 1ull;   // group g: the g-th lowest of the other images
+                            if (i <= nh) rest &= rest - 1ull;   // what stays with the first group
+                        }
+                        if (grp == 0) g_ok = rest;
+                        else if (glane && grp <= nh) {
+                            g_req = r_req; g_off = r_off; g_ref = r_ref; g_userob = r_rob;
+                            g_cur = __ffsll((long long)mine) - 1; g_ok = 0ull; g_isref = false; rsrc = yy;
+                        }
+                        moved = true;
+                        idle = 0ull;
                     }
                 }
                 // ---- 1b. nothing left to hand out and groups are idle: they take over the upper half of what the
