@@ -54,6 +54,7 @@ EXPORTS = [
     "hpmvs_pack_records", "hpmvs_unpack_records", "hpmvs_allgather_records",
     "hpmvs_scene_depth_reset", "hpmvs_scene_depth_set_level", "hpmvs_scene_depth_get_level",
     "hpmvs_set_depths_batch", "hpmvs_depth_gates_batch",
+    "hpmvs_host_alloc", "hpmvs_host_free", "hpmvs_last_staging",
 ]
 
 _lib = None
@@ -90,6 +91,11 @@ def lib():
     L.hpmvs_inccs_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(PatchBatch), C.c_int, C.c_int,
                                     C.c_void_p, C.c_int, C.c_void_p]
     L.hpmvs_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.hpmvs_host_alloc.argtypes = [C.c_size_t]
+    L.hpmvs_host_alloc.restype = C.c_void_p
+    L.hpmvs_host_free.argtypes = [C.c_void_p]
+    L.hpmvs_host_free.restype = None
+    L.hpmvs_last_staging.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.hpmvs_expand_batch.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.POINTER(PatchBatch), C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.POINTER(PatchBatch), C.c_int, C.c_void_p]
     L.hpmvs_expand_directions.argtypes = [C.c_int, C.c_void_p]
@@ -188,6 +194,12 @@ class Scene:
         _chk(lib().hpmvs_scene_get_level(self.h, view, level, out.ctypes.data, out.nbytes, C.byref(w), C.byref(h)))
         return out
 
+    def last_staging(self):
+        """(bytes copied through device buffers, bytes used in place) of the last host-pointer optimize_batch call."""
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        _chk(lib().hpmvs_last_staging(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         _chk(lib().hpmvs_last_kernel_ms(self.h, C.byref(ms)))
@@ -222,6 +234,35 @@ class Batch:
             idx = np.arange(len(seeds.scale))
         idx = np.asarray(idx)
         return cls(seeds.center[idx], seeds.normal[idx], seeds.scale[idx], seeds.n_images[idx], seeds.images[idx])
+
+    FIELDS = ("center", "normal", "scale", "n_images", "images", "ok", "color", "ncc", "fmin", "x", "result", "nevals",
+              "stage", "ngrabs")
+
+    def pin(self):
+        """Move every array into pinned host memory (hpmvs_host_alloc).  Host-pointer calls then use the arrays in place
+        (include/hpmvs_amd.h, "Host-pointer calls and pinned memory").  The arrays belong to this object: they are freed
+        with it."""
+        L = lib()
+        self._pins = getattr(self, "_pins", [])
+        for name in self.FIELDS:
+            a = getattr(self, name)
+            nbytes = max(int(a.nbytes), 1)
+            p = L.hpmvs_host_alloc(nbytes)
+            if not p:
+                raise MemoryError(f"hpmvs_host_alloc({nbytes})")
+            self._pins.append(p)
+            na = np.frombuffer((C.c_char * nbytes).from_address(p), dtype=a.dtype, count=a.size).reshape(a.shape)
+            na[...] = a
+            setattr(self, name, na)
+        return self
+
+    def __del__(self):
+        for p in getattr(self, "_pins", []):
+            try:
+                lib().hpmvs_host_free(p)
+            except Exception:  # noqa: BLE001 -- interpreter shutdown
+                pass
+        self._pins = []
 
     def c_struct(self) -> PatchBatch:
         b = PatchBatch()

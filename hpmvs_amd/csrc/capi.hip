@@ -73,6 +73,7 @@ struct hpmvs_scene {
     size_t ws_bytes = 0;
     mutable unsigned next_slot = 0;
     mutable int32_t* last_queue = nullptr;
+    mutable std::atomic<unsigned long long> last_staged_bytes{0}, last_mapped_bytes{0};  // of the last host-pointer optimize_batch call
     size_t bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t slot_done[kQueueSlots] = {};   // recorded behind the last launch that used workspace k
@@ -441,6 +442,7 @@ struct Staged {
     struct Fill { void* dst; const void* src; size_t bytes; };  // src == nullptr: zero-fill
     std::vector<Fill> fills;  // what stage_in allocated still has to be filled: stage_flush, outside the Exclusive scope
     bool staged = false;
+    size_t staged_bytes = 0, mapped_bytes = 0;  // arrays copied through device buffers / used in place (pinned host memory)
     const hpmvs_scene* scene = nullptr;  // set by calls against a scene: the buffers are freed in an Exclusive scope
     ~Staged() {
         if (tmp.empty()) return;
@@ -449,10 +451,39 @@ struct Staged {
     }
 };
 
+// Device address of [host, host + bytes) when the whole range lies in pinned host memory that is mapped into the GPU's
+// address space (hipHostMalloc / hipHostRegister; torch's pin_memory()), else nullptr.  Such an array of a host-pointer
+// call is used IN PLACE: the kernels read a patch's inputs once and write its outputs once, so they stream over PCIe while
+// the kernel runs instead of costing a hipMalloc, two copies and a hipFree around it (C2: 222.3 -> 213.1 ms host to host
+// against 212.1 ms of kernel).  HPMVS_ZERO_COPY=0 switches the detection off.
+static void* mapped_host(const void* host, size_t bytes) {
+    static const bool enabled = [] { const char* e = getenv("HPMVS_ZERO_COPY"); return !(e && e[0] == '0'); }();
+    if (!enabled || !host || bytes == 0) return nullptr;
+    void *d0 = nullptr, *d1 = nullptr;
+    if (hipHostGetDevicePointer(&d0, const_cast<void*>(host), 0) != hipSuccess ||
+        hipHostGetDevicePointer(&d1, const_cast<char*>((const char*)host + bytes - 1), 0) != hipSuccess) {
+        (void)hipGetLastError();  // pageable memory: not an error here
+        return nullptr;
+    }
+    return ((const char*)d1 - (const char*)d0 == (ptrdiff_t)(bytes - 1)) ? d0 : nullptr;
+}
+
+// copy: the array is an input (its contents travel to the device).  need_zero: an output the kernel may leave untouched for
+// some patches (e.g. `color` of a failed one), which a staged call returns as 0.  allow_mapped = false: `host` only stands
+// for "non-null", the range behind it is not the caller's.
 template <typename T>
-int stage_in(Staged& st, T*& dst, const T* host, size_t count, bool copy) {
+int stage_in(Staged& st, T*& dst, const T* host, size_t count, bool copy, bool need_zero = true, bool allow_mapped = true) {
     dst = nullptr;
     if (!host || count == 0) return HPMVS_OK;
+    if (allow_mapped) {
+        if (void* m = mapped_host(host, sizeof(T) * count)) {
+            dst = (T*)m;
+            if (!copy && need_zero) st.fills.push_back({m, nullptr, sizeof(T) * count});
+            st.mapped_bytes += sizeof(T) * count;
+            return HPMVS_OK;
+        }
+    }
+    st.staged_bytes += sizeof(T) * count;
     void* p = nullptr;
     HIPCHK(hipMalloc(&p, sizeof(T) * count));
     st.tmp.push_back(p);
@@ -476,6 +507,7 @@ int stage_flush(Staged& st) {
 template <typename T>
 int stage_out(T* host, const T* dev, size_t count) {
     if (!host || !dev || count == 0) return HPMVS_OK;
+    if ((const void*)dev == mapped_host(host, sizeof(T) * count)) return HPMVS_OK;  // used in place (stage_in)
     HIPCHK(hipMemcpy(host, dev, sizeof(T) * count, hipMemcpyDeviceToHost));
     return HPMVS_OK;
 }
@@ -500,7 +532,9 @@ int check_batch(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_patch_
     return HPMVS_OK;
 }
 
-int stage_batch(Staged& st, const hpmvs_patch_batch* b, bool on_device, bool outputs, bool copy_inputs = true) {
+// all_written: the kernel behind this call writes ok / fmin / x / result / nevals / stage / ngrabs of EVERY patch (the
+// refinement kernel does: fetch and finish stages), so arrays used in place need no zero fill first
+int stage_batch(Staged& st, const hpmvs_patch_batch* b, bool on_device, bool outputs, bool copy_inputs = true, bool all_written = false) {
     DevBatch& d = st.d;
     memset(&d, 0, sizeof(d));
     d.n = b->n; d.max_images = b->max_images;
@@ -519,15 +553,15 @@ int stage_batch(Staged& st, const hpmvs_patch_batch* b, bool on_device, bool out
     if ((rc = stage_in(st, d.n_images, b->n_images, n, copy_inputs))) return rc;
     if ((rc = stage_in(st, d.images, b->images, n * b->max_images, copy_inputs))) return rc;
     if (outputs) {
-        if ((rc = stage_in(st, d.ok, b->ok, n, false))) return rc;
+        if ((rc = stage_in(st, d.ok, b->ok, n, false, /*need_zero=*/!all_written))) return rc;
         if ((rc = stage_in(st, d.color, b->color, 3 * n, false))) return rc;
         if ((rc = stage_in(st, d.ncc, b->ncc, n, false))) return rc;
-        if ((rc = stage_in(st, d.fmin, b->fmin, n, false))) return rc;
-        if ((rc = stage_in(st, d.x, b->x, 3 * n, false))) return rc;
-        if ((rc = stage_in(st, d.result, b->result, n, false))) return rc;
-        if ((rc = stage_in(st, d.nevals, b->nevals, n, false))) return rc;
-        if ((rc = stage_in(st, d.stage, b->stage, n, false))) return rc;
-        if ((rc = stage_in(st, d.ngrabs, b->ngrabs, n, false))) return rc;
+        if ((rc = stage_in(st, d.fmin, b->fmin, n, false, /*need_zero=*/!all_written))) return rc;
+        if ((rc = stage_in(st, d.x, b->x, 3 * n, false, /*need_zero=*/!all_written))) return rc;
+        if ((rc = stage_in(st, d.result, b->result, n, false, /*need_zero=*/!all_written))) return rc;
+        if ((rc = stage_in(st, d.nevals, b->nevals, n, false, /*need_zero=*/!all_written))) return rc;
+        if ((rc = stage_in(st, d.stage, b->stage, n, false, /*need_zero=*/!all_written))) return rc;
+        if ((rc = stage_in(st, d.ngrabs, b->ngrabs, n, false, /*need_zero=*/!all_written))) return rc;
     }
     return HPMVS_OK;
 }
@@ -699,7 +733,7 @@ extern "C" int hpmvs_selftest_bobyqa(int device, int n, const int32_t* kind, con
     if ((rc = stage_in(sg, dres, (const int*)rescue_calls, N, false))) return rc;
     if (trace && (rc = stage_in(sg, dtr, (const double*)trace, 4 * N * (size_t)trace_cap, false))) return rc;
     double* dcold = nullptr;
-    if ((rc = stage_in(sg, dcold, (const double*)xfinal /* (any non-null host pointer: zero-filled) */, selftest_cold_doubles(n), false))) return rc;
+    if ((rc = stage_in(sg, dcold, (const double*)xfinal /* (any non-null host pointer: zero-filled) */, selftest_cold_doubles(n), false, true, /*allow_mapped=*/false))) return rc;
     if ((rc = stage_flush(sg))) return rc;
     launch_selftest(n, dkind, dpar, dx0, dlb, dub, maxeval, dxf, dmin, drc, dne, dres, dtr, trace_cap, dcold, nullptr);
     HIPCHK(hipGetLastError());
@@ -1082,7 +1116,8 @@ int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_pat
     sg.scene = s;
     if (!on_device) {
         Exclusive ex(s);  // the allocations of a host-staged call (see Exclusive; ~Staged frees in one of its own)
-        rc = stage_batch(sg, b, false, true);
+        rc = stage_batch(sg, b, false, true, true, /*all_written=*/true);
+        s->last_staged_bytes = sg.staged_bytes; s->last_mapped_bytes = sg.mapped_bytes;
     } else rc = stage_batch(sg, b, true, true);
     if (rc) return rc;
     if ((rc = stage_flush(sg))) return rc;
@@ -1444,6 +1479,25 @@ int hpmvs_debug_counters(const hpmvs_scene* s, unsigned long long* out4) {
     if (!s->last_queue) return fail(HPMVS_ERR_STATE, "debug_counters: no launch yet");
     HIPCHK(hipMemcpy(out4, (char*)s->last_queue + 16, 544, hipMemcpyDeviceToHost));
     return HPMVS_OK;
+}
+
+// how the arrays of the last host-pointer hpmvs_optimize_batch call of this scene (the path above the small-batch
+// thresholds) reached the device: bytes copied through device buffers, bytes used in place (pinned, mapped host memory)
+int hpmvs_last_staging(const hpmvs_scene* s, unsigned long long* staged_bytes, unsigned long long* in_place_bytes) {
+    if (!s || !staged_bytes || !in_place_bytes) return fail(HPMVS_ERR_ARG, "last_staging: null argument");
+    *staged_bytes = s->last_staged_bytes; *in_place_bytes = s->last_mapped_bytes;
+    return HPMVS_OK;
+}
+
+// pinned host memory mapped into the GPUs' address space, for callers without the HIP headers: arrays of a host-pointer
+// call that live in it are used in place (see mapped_host)
+void* hpmvs_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void hpmvs_host_free(void* p) {
+    if (p && hipHostFree(p) != hipSuccess) (void)hipGetLastError();
 }
 
 int hpmvs_last_kernel_ms(const hpmvs_scene* s, float* ms) {

@@ -556,6 +556,36 @@ bool PatchOptimizer::optimize(mo3d::Patch3d& patch) {
     return me.ok != 0;
 }
 
+namespace {
+// The structure-of-arrays copy of a batch lives in pinned host memory of the calling thread (hpmvs_host_alloc, grow-only,
+// kept between calls): the device uses such arrays in place (include/hpmvs_amd.h, "Host-pointer calls and pinned memory"), so
+// a batch above the small-batch threshold costs no device allocation, no staging copy and no free.  Pageable memory when
+// the allocation fails: the call then stages as before.
+struct PinnedArena {
+    char* base = nullptr;
+    size_t cap = 0;
+    ~PinnedArena() { if (base) hpmvs_host_free(base); }
+    char* reserve(size_t bytes) {
+        if (bytes > cap) {
+            if (base) hpmvs_host_free(base);
+            cap = bytes + bytes / 4;
+            base = (char*)hpmvs_host_alloc(cap);
+            if (!base) cap = 0;
+        }
+        return base;
+    }
+};
+thread_local PinnedArena tl_arena;
+struct Carver {  // consecutive 64-byte aligned arrays out of one block
+    char* p;
+    template <class T> T* take(size_t count) {
+        T* r = (T*)p;
+        p += (sizeof(T) * count + 63) & ~(size_t)63;
+        return r;
+    }
+};
+}  // namespace
+
 size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, uint8_t* ok) {
     lastF_.assign(n, 0.0);
     lastEvals_.assign(n, 0);
@@ -564,9 +594,18 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
     hpmvs_scene* dev = scene_p->deviceScene();
     if (!dev) return 0;
     const int stride = HPMVS_MAX_IMAGES;
-    std::vector<float> center(4 * n), normal(4 * n), scale(n), color(3 * n), ncc(n);
-    std::vector<int32_t> nimg(n), images(n * stride, -1), evals(n);
-    std::vector<double> fmin(n);
+    const size_t total = (size_t)(16 + 16 + 4 + 12 + 4 + 4 + 4 * stride + 4 + 8) * n + 10 * 64;
+    std::vector<char> pageable;
+    char* blk = tl_arena.reserve(total);
+    if (!blk) { pageable.resize(total + 64); blk = (char*)(((uintptr_t)pageable.data() + 63) & ~(uintptr_t)63); }
+    Carver cv{blk};
+    float* center = cv.take<float>(4 * n); float* normal = cv.take<float>(4 * n); float* scale = cv.take<float>(n);
+    float* color = cv.take<float>(3 * n); float* ncc = cv.take<float>(n);
+    int32_t* nimg = cv.take<int32_t>(n); int32_t* images = cv.take<int32_t>(n * stride); int32_t* evals = cv.take<int32_t>(n);
+    double* fmin = cv.take<double>(n);
+    memset(images, 0xff, sizeof(int32_t) * n * stride);  // -1: no image
+    memset(color, 0, sizeof(float) * 3 * n); memset(ncc, 0, sizeof(float) * n);
+    memset(evals, 0, sizeof(int32_t) * n); memset(fmin, 0, sizeof(double) * n);
     for (size_t i = 0; i < n; i++) {
         const Patch3d& p = *patches[i];
         for (int k = 0; k < 4; k++) { center[4 * i + k] = p.center_[k]; normal[4 * i + k] = p.normal_[k]; }
@@ -583,9 +622,9 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
     hpmvs_patch_batch b;
     memset(&b, 0, sizeof(b));
     b.n = (int32_t)n; b.max_images = stride;
-    b.center = center.data(); b.normal = normal.data(); b.scale = scale.data();
-    b.n_images = nimg.data(); b.images = images.data();
-    b.ok = ok; b.color = color.data(); b.ncc = ncc.data(); b.fmin = fmin.data(); b.nevals = evals.data();
+    b.center = center; b.normal = normal; b.scale = scale;
+    b.n_images = nimg; b.images = images;
+    b.ok = ok; b.color = color; b.ncc = ncc; b.fmin = fmin; b.nevals = evals;
     if (hpmvs_optimize_batch(dev, &o, &b, 0, nullptr) != HPMVS_OK) {
         std::cerr << "patch optimization failed: <" << hpmvs_last_error() << ">" << std::endl;
         for (size_t i = 0; i < n; i++) ok[i] = 0;
@@ -599,7 +638,7 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
         Patch3d& p = *patches[i];
         for (int k = 0; k < 4; k++) { p.center_[k] = center[4 * i + k]; p.normal_[k] = normal[4 * i + k]; }
         p.scale_3dx_ = scale[i];
-        p.images_.assign(images.begin() + i * stride, images.begin() + i * stride + nimg[i]);
+        p.images_.assign(images + i * stride, images + i * stride + nimg[i]);
         p.ncc_ = ncc[i];
         p.color_ = Eigen::Vector3f(color[3 * i], color[3 * i + 1], color[3 * i + 2]);
         good++;

@@ -216,6 +216,19 @@ int hpmvs_set_depths_batch(hpmvs_scene *s, const hpmvs_patch_batch *b, int on_de
 int hpmvs_depth_gates_batch(const hpmvs_scene *s, const hpmvs_patch_batch *b, float margin, int abs_int,
                             int32_t *n_visible, int32_t *n_blocking, int32_t *n_free, int on_device, void *stream);
 
+/* Host-pointer calls and pinned memory.  An array of a host-pointer call (on_device = 0) that lies in pinned host memory
+ * mapped into the GPU's address space -- hipHostMalloc / hipHostRegister, torch's pin_memory(), hpmvs_host_alloc below --
+ * is used IN PLACE: the kernels read a patch's inputs once and write its outputs once, so they travel over PCIe while the
+ * kernel runs; pageable arrays are copied through device buffers as before, array by array.  Results are identical either
+ * way (outputs the kernel does not write for a failed patch -- color, ncc -- read 0, as after a staged call).  The
+ * reference has no counterpart: its patches live in host containers (Scene.cpp:94-96, CellProcessor.cpp:129).
+ * HPMVS_ZERO_COPY=0 in the environment switches the detection off. */
+void *hpmvs_host_alloc(size_t bytes);   /* NULL on failure */
+void hpmvs_host_free(void *p);
+/* of the last host-pointer hpmvs_optimize_batch call above the small-batch thresholds: bytes copied through device
+ * buffers and bytes used in place */
+int hpmvs_last_staging(const hpmvs_scene *s, unsigned long long *staged_bytes, unsigned long long *in_place_bytes);
+
 /* last optimize launch: kernel time measured with HIP events on the launch stream (ms).  Meaningful with ONE caller at a
  * time: the scene holds a single event pair, so concurrent launches from several host threads can pair the start of one
  * launch with the end of another. */
