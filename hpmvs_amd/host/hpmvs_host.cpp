@@ -26,6 +26,53 @@
 
 #include "../../include/hpmvs_amd.h"
 
+// ---------------------------------------------------------------- where the structure-of-arrays copies of a batch live
+// The C ABI uses host arrays that lie in pinned, mapped host memory IN PLACE (include/hpmvs_amd.h, "Host-pointer calls and
+// pinned memory"): no device allocation, staging copy or free per array and call.  PVec<T> is a std::vector whose storage
+// comes from hpmvs_host_alloc through a per-thread cache of power-of-two blocks (pinning pages is slow: a block is pinned
+// once and then reused by later calls of the thread; it goes back to the system when the thread ends).  Batches up to
+// kPinFrom patches take ordinary memory: the C ABI serves those from its own pinned staging pool anyway.
+namespace {
+constexpr size_t kPinFrom = 4096;
+struct PinnedCache {
+    std::vector<void*> free_[4 * 48];
+    ~PinnedCache() { for (auto& v : free_) for (void* p : v) hpmvs_host_free(p); }
+    // size classes: four per octave from 4 KB (a block is at most 25 % larger than asked for)
+    static int cls(size_t bytes, size_t* rounded) {
+        int e = 12;
+        while (((size_t)1 << (e + 1)) < bytes) e++;
+        if (bytes <= ((size_t)1 << 12)) { *rounded = (size_t)1 << 12; return 0; }
+        const size_t q = (size_t)1 << (e - 2);  // a quarter of 2^e: classes 2^e + k * q, k = 1..4
+        const size_t k = (bytes - ((size_t)1 << e) + q - 1) / q;
+        *rounded = ((size_t)1 << e) + k * q;
+        return 4 * (e - 12) + (int)k;
+    }
+    void* get(size_t bytes) {
+        size_t r;
+        const int c = cls(bytes, &r);
+        if (!free_[c].empty()) { void* p = free_[c].back(); free_[c].pop_back(); return p; }
+        return hpmvs_host_alloc(r);
+    }
+    void put(void* p, size_t bytes) { size_t r; free_[cls(bytes, &r)].push_back(p); }
+};
+thread_local PinnedCache tl_pins;
+template <class T>
+struct PinnedAlloc {
+    using value_type = T;
+    bool pin;  // false: ordinary memory
+    explicit PinnedAlloc(bool p = false) : pin(p) {}
+    template <class U> PinnedAlloc(const PinnedAlloc<U>& o) : pin(o.pin) {}
+    T* allocate(size_t n) {
+        if (pin) { if (void* p = tl_pins.get(sizeof(T) * n)) return (T*)p; pin = false; }  // (pinning failed: pageable, staged)
+        return (T*)::operator new(sizeof(T) * n);
+    }
+    void deallocate(T* p, size_t n) { if (pin) tl_pins.put(p, sizeof(T) * n); else ::operator delete(p); }
+    template <class U> bool operator==(const PinnedAlloc<U>& o) const { return pin == o.pin; }
+    template <class U> bool operator!=(const PinnedAlloc<U>& o) const { return pin != o.pin; }
+};
+template <class T> using PVec = std::vector<T, PinnedAlloc<T>>;
+}  // namespace
+
 namespace mo3d {
 
 // ---------------------------------------------------------------- Patch3d (reference src/hpmvs/Patch3d.cpp:28-74)
@@ -349,17 +396,23 @@ bool Scene::initPatches(const NVM_Model& model, const HpmvsOptions& options, std
     if (!dev) return false;
     const size_t n = model.points.size();
     if (n == 0) return true;
-    std::vector<double> xyz(3 * n);
-    std::vector<int32_t> off(n + 1, 0), img;
+    const PinnedAlloc<char> pin(true);  // (this entry stages whatever the batch size: pinned arrays are used in place)
+    PVec<double> xyz(3 * n, pin);
+    PVec<int32_t> off(n + 1, 0, pin), img(pin);
+    {
+        size_t total = 0;
+        for (size_t i = 0; i < n; i++) total += model.points[i].measurements.size();
+        img.reserve(total ? total : 1);  // (one pinned block, not a series of growing ones)
+    }
     for (size_t i = 0; i < n; i++) {
         for (int k = 0; k < 3; k++) xyz[3 * i + k] = model.points[i].xyz[k];
         for (const NVM_Measurement& m : model.points[i].measurements) img.push_back(m.imgIndex);
         off[i + 1] = (int32_t)img.size();
     }
     const int stride = HPMVS_MAX_IMAGES;
-    std::vector<float> center(4 * n), normal(4 * n), scale(n), color(3 * n), ncc(n);
-    std::vector<int32_t> nimg(n), images(n * stride, -1);
-    std::vector<uint8_t> ok(n);
+    PVec<float> center(4 * n, pin), normal(4 * n, pin), scale(n, pin), color(3 * n, pin), ncc(n, pin);
+    PVec<int32_t> nimg(n, pin), images(n * stride, -1, pin);
+    PVec<uint8_t> ok(n, pin);
     hpmvs_options o;
     o.MAXLEVEL = options.MAXLEVEL; o.MINLEVEL = options.MINLEVEL; o.MAX_ANGLE = options.MAX_ANGLE;
     o.MIN_ANGLE = options.MIN_ANGLE; o.MAX_IMAGES_PER_PATCH = options.MAX_IMAGES_PER_PATCH;
@@ -424,10 +477,12 @@ hpmvs_scene* Scene::deviceScene() const {
 // ---------------------------------------------------------------- depth maps + acceptance gates (batched)
 namespace {
 struct HostBatch {  // SoA copy of a patch list for the C ABI (inputs only)
-    std::vector<float> center, normal, scale;
-    std::vector<int32_t> nimg, images;
+    PVec<float> center, normal, scale;
+    PVec<int32_t> nimg, images;
     hpmvs_patch_batch b;
-    HostBatch(const Patch3d* const* patches, size_t n) : center(4 * n), normal(4 * n), scale(n), nimg(n), images(n * HPMVS_MAX_IMAGES, -1) {
+    HostBatch(const Patch3d* const* patches, size_t n)
+        : center(4 * n, PinnedAlloc<float>(true)), normal(4 * n, PinnedAlloc<float>(true)), scale(n, PinnedAlloc<float>(true)),
+          nimg(n, PinnedAlloc<int32_t>(true)), images(n * HPMVS_MAX_IMAGES, -1, PinnedAlloc<int32_t>(true)) {
         for (size_t i = 0; i < n; i++) {
             const Patch3d& p = *patches[i];
             for (int k = 0; k < 4; k++) { center[4 * i + k] = p.center_[k]; normal[4 * i + k] = p.normal_[k]; }
@@ -463,7 +518,8 @@ bool Scene::depthGates(const Patch3d* const* patches, size_t n, float margin, st
     if (!dev) return false;
     if (n == 0) return true;
     HostBatch hb(patches, n);
-    std::vector<int32_t> v(n), k(n), f(n);
+    const PinnedAlloc<char> pin(true);
+    PVec<int32_t> v(n, pin), k(n, pin), f(n, pin);
     if (hpmvs_depth_gates_batch(dev, &hb.b, margin, absInt ? 1 : 0, v.data(), k.data(), f.data(), 0, nullptr) != HPMVS_OK) {
         std::cerr << "hpmvs: " << hpmvs_last_error() << std::endl;
         return false;
@@ -556,36 +612,6 @@ bool PatchOptimizer::optimize(mo3d::Patch3d& patch) {
     return me.ok != 0;
 }
 
-namespace {
-// The structure-of-arrays copy of a batch lives in pinned host memory of the calling thread (hpmvs_host_alloc, grow-only,
-// kept between calls): the device uses such arrays in place (include/hpmvs_amd.h, "Host-pointer calls and pinned memory"), so
-// a batch above the small-batch threshold costs no device allocation, no staging copy and no free.  Pageable memory when
-// the allocation fails: the call then stages as before.
-struct PinnedArena {
-    char* base = nullptr;
-    size_t cap = 0;
-    ~PinnedArena() { if (base) hpmvs_host_free(base); }
-    char* reserve(size_t bytes) {
-        if (bytes > cap) {
-            if (base) hpmvs_host_free(base);
-            cap = bytes + bytes / 4;
-            base = (char*)hpmvs_host_alloc(cap);
-            if (!base) cap = 0;
-        }
-        return base;
-    }
-};
-thread_local PinnedArena tl_arena;
-struct Carver {  // consecutive 64-byte aligned arrays out of one block
-    char* p;
-    template <class T> T* take(size_t count) {
-        T* r = (T*)p;
-        p += (sizeof(T) * count + 63) & ~(size_t)63;
-        return r;
-    }
-};
-}  // namespace
-
 size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, uint8_t* ok) {
     lastF_.assign(n, 0.0);
     lastEvals_.assign(n, 0);
@@ -594,18 +620,10 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
     hpmvs_scene* dev = scene_p->deviceScene();
     if (!dev) return 0;
     const int stride = HPMVS_MAX_IMAGES;
-    const size_t total = (size_t)(16 + 16 + 4 + 12 + 4 + 4 + 4 * stride + 4 + 8) * n + 10 * 64;
-    std::vector<char> pageable;
-    char* blk = tl_arena.reserve(total);
-    if (!blk) { pageable.resize(total + 64); blk = (char*)(((uintptr_t)pageable.data() + 63) & ~(uintptr_t)63); }
-    Carver cv{blk};
-    float* center = cv.take<float>(4 * n); float* normal = cv.take<float>(4 * n); float* scale = cv.take<float>(n);
-    float* color = cv.take<float>(3 * n); float* ncc = cv.take<float>(n);
-    int32_t* nimg = cv.take<int32_t>(n); int32_t* images = cv.take<int32_t>(n * stride); int32_t* evals = cv.take<int32_t>(n);
-    double* fmin = cv.take<double>(n);
-    memset(images, 0xff, sizeof(int32_t) * n * stride);  // -1: no image
-    memset(color, 0, sizeof(float) * 3 * n); memset(ncc, 0, sizeof(float) * n);
-    memset(evals, 0, sizeof(int32_t) * n); memset(fmin, 0, sizeof(double) * n);
+    const PinnedAlloc<char> pin(n > kPinFrom);
+    PVec<float> center(4 * n, pin), normal(4 * n, pin), scale(n, pin), color(3 * n, pin), ncc(n, pin);
+    PVec<int32_t> nimg(n, pin), images(n * stride, -1, pin), evals(n, pin);
+    PVec<double> fmin(n, pin);
     for (size_t i = 0; i < n; i++) {
         const Patch3d& p = *patches[i];
         for (int k = 0; k < 4; k++) { center[4 * i + k] = p.center_[k]; normal[4 * i + k] = p.normal_[k]; }
@@ -622,9 +640,9 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
     hpmvs_patch_batch b;
     memset(&b, 0, sizeof(b));
     b.n = (int32_t)n; b.max_images = stride;
-    b.center = center; b.normal = normal; b.scale = scale;
-    b.n_images = nimg; b.images = images;
-    b.ok = ok; b.color = color; b.ncc = ncc; b.fmin = fmin; b.nevals = evals;
+    b.center = center.data(); b.normal = normal.data(); b.scale = scale.data();
+    b.n_images = nimg.data(); b.images = images.data();
+    b.ok = ok; b.color = color.data(); b.ncc = ncc.data(); b.fmin = fmin.data(); b.nevals = evals.data();
     if (hpmvs_optimize_batch(dev, &o, &b, 0, nullptr) != HPMVS_OK) {
         std::cerr << "patch optimization failed: <" << hpmvs_last_error() << ">" << std::endl;
         for (size_t i = 0; i < n; i++) ok[i] = 0;
@@ -638,7 +656,7 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
         Patch3d& p = *patches[i];
         for (int k = 0; k < 4; k++) { p.center_[k] = center[4 * i + k]; p.normal_[k] = normal[4 * i + k]; }
         p.scale_3dx_ = scale[i];
-        p.images_.assign(images + i * stride, images + i * stride + nimg[i]);
+        p.images_.assign(images.begin() + i * stride, images.begin() + i * stride + nimg[i]);
         p.ncc_ = ncc[i];
         p.color_ = Eigen::Vector3f(color[3 * i], color[3 * i + 1], color[3 * i + 2]);
         good++;
@@ -659,8 +677,9 @@ int PatchOptimizer::expandBatch(ExpandMode mode, const mo3d::Patch3d* const* par
     if (!dev) return N;
     const int stride = HPMVS_MAX_IMAGES;
     const size_t m = n * N;
-    std::vector<float> pc(4 * n), pn(4 * n), ps(n), cc(3 * n), cw(n);
-    std::vector<int32_t> pnimg(n), pimg(n * stride, -1);
+    const PinnedAlloc<char> pin(true);  // (this entry stages whatever the batch size: pinned arrays are used in place)
+    PVec<float> pc(4 * n, pin), pn(4 * n, pin), ps(n, pin), cc(3 * n, pin), cw(n, pin);
+    PVec<int32_t> pnimg(n, pin), pimg(n * stride, -1, pin);
     for (size_t i = 0; i < n; i++) {
         const Patch3d& p = *parents[i];
         for (int k = 0; k < 4; k++) { pc[4 * i + k] = p.center_[k]; pn[4 * i + k] = p.normal_[k]; }
@@ -670,9 +689,9 @@ int PatchOptimizer::expandBatch(ExpandMode mode, const mo3d::Patch3d* const* par
         for (int k = 0; k < 3; k++) cc[3 * i + k] = cells[i].c[k];
         cw[i] = cells[i].width;
     }
-    std::vector<float> center(4 * m), normal(4 * m), scale(m), color(3 * m), ncc(m);
-    std::vector<int32_t> nimg(m), images(m * stride, -1), evals(m);
-    std::vector<double> fmin(m);
+    PVec<float> center(4 * m, pin), normal(4 * m, pin), scale(m, pin), color(3 * m, pin), ncc(m, pin);
+    PVec<int32_t> nimg(m, pin), images(m * stride, -1, pin), evals(m, pin);
+    PVec<double> fmin(m, pin);
     hpmvs_options o;
     o.MAXLEVEL = options_p->MAXLEVEL; o.MINLEVEL = options_p->MINLEVEL;
     o.MAX_ANGLE = options_p->MAX_ANGLE; o.MIN_ANGLE = options_p->MIN_ANGLE;
