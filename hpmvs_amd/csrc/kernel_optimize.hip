@@ -44,6 +44,9 @@
 // The 58-slot build keeps the optimiser states' big matrices in global memory (kernel_optimize_big.hip sets this): a
 // third state region per CU is worth far more there than the L2 round trips cost (C2: 232 -> 221 ms).  With 29 slots
 // (four regions of 40 KB already) it is the other way round (C1: 24.3 -> 25.5 ms), so this build keeps everything in LDS.
+#ifndef HPMVS_SPREAD_SOLO
+#define HPMVS_SPREAD_SOLO 1
+#endif
 #ifndef HPMVS_COLD_GLOBAL
 #define HPMVS_COLD_GLOBAL 0
 #endif
@@ -223,6 +226,17 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
     const int per_wg = (b.n + n_wgs - 1) / n_wgs;
     int quota = per_wg - wv * kP;  // the workgroup's share goes to its wavefronts in order
     quota = quota < 0 ? 0 : (quota < kP ? quota : kP);
+#if HPMVS_SPREAD_SOLO
+    // ... unless it fits the wavefronts that can each keep a state region for good (no more busy wavefronts than regions:
+    // `solo`, no paging): then it is split evenly between them -- four wavefronts with 4 patches each have much shorter rounds
+    // than one with 16 (fewer photometric passes per round, and the optimiser's blocks run on four SIMDs at once).
+    // Measured on the C1 scene, one launch (round 4): 1 024 patches 8.6 -> 7.0 ms, 4 096 10.9 -> 8.8, 10 000 12.8 -> 10.5,
+    // 20 000 13.8 -> 13.0; at 29 000 (114 per workgroup) full wavefronts win again (16.1 against 17.1): up to 3/4 of R x kP.
+    if (4 * per_wg <= 3 * R * kP) {
+        const int a = per_wg < R ? per_wg : R;  // busy wavefronts of this workgroup
+        quota = wv < a ? per_wg / a + (wv < per_wg % a ? 1 : 0) : 0;
+    }
+#endif
     if (service) quota = wv == 0 ? (b.svc_lanes < kP ? b.svc_lanes : kP) : 0;  // few patches per wavefront: latency first
     if (threadIdx.x <= R) hpmvs_lock[threadIdx.x] = 0;
     __syncthreads();
