@@ -44,6 +44,12 @@
 // The 58-slot build keeps the optimiser states' big matrices in global memory (kernel_optimize_big.hip sets this): a
 // third state region per CU is worth far more there than the L2 round trips cost (C2: 232 -> 221 ms).  With 29 slots
 // (four regions of 40 KB already) it is the other way round (C1: 24.3 -> 25.5 ms), so this build keeps everything in LDS.
+#ifndef HPMVS_STATIC_SLOTS
+#define HPMVS_STATIC_SLOTS (!HPMVS_COLD_GLOBAL)   /* (the cold blocks are laid out per wavefront and slot: 29-slot build only) */
+#endif
+#ifndef HPMVS_STATIC_MAX_PER_WG
+#define HPMVS_STATIC_MAX_PER_WG(W_, kS_) ((W_) * (kS_))
+#endif
 #ifndef HPMVS_SPREAD_SOLO
 #define HPMVS_SPREAD_SOLO 1
 #endif
@@ -237,6 +243,19 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
         quota = wv < a ? per_wg / a + (wv < per_wg % a ? 1 : 0) : 0;
     }
 #endif
+#if HPMVS_STATIC_SLOTS
+    // ... and a share that fits W x kS slots goes to ALL wavefronts: W / R of them share a state region for good, each with
+    // its own kS = kP / (W / R) slots of it (no lock, no paging: the regions are [index][slot] arrays, the wavefronts touch
+    // disjoint slots)
+    constexpr bool can_static = !SERVICE && (W % R == 0) && (W / R > 1);
+    constexpr int kS = kP / (W / R > 0 ? W / R : 1);
+    bool stat = false;
+    if (can_static && per_wg <= HPMVS_STATIC_MAX_PER_WG(W, kS)) {
+        stat = true;
+        const int a = per_wg < W ? per_wg : W;
+        quota = wv < a ? per_wg / a + (wv < per_wg % a ? 1 : 0) : 0;
+    }
+#endif
     if (service) quota = wv == 0 ? (b.svc_lanes < kP ? b.svc_lanes : kP) : 0;  // few patches per wavefront: latency first
     if (threadIdx.x <= R) hpmvs_lock[threadIdx.x] = 0;
     __syncthreads();
@@ -257,6 +276,15 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
     Bobyqa3 B;
     B.slot = lane < kP ? lane : 0;
     B.slot_i = B.slot;
+#if HPMVS_STATIC_SLOTS
+    if (stat) {
+        reg = wv / (W / R);
+        const int sl = (lane < kS ? lane : 0) + (wv % (W / R)) * kS;
+        B.slot = sl + reg * (HPMVS_REGION_16 * 2);
+        B.slot_i = sl + reg * (HPMVS_REGION_16 * 4);
+        held = true; solo = true;
+    }
+#endif
 #if HPMVS_COLD_GLOBAL
     B.coff = (unsigned)B.slot * 8u;
     B.coldp = cold;
