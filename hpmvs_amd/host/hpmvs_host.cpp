@@ -624,6 +624,7 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
     PVec<float> center(4 * n, pin), normal(4 * n, pin), scale(n, pin), color(3 * n, pin), ncc(n, pin);
     PVec<int32_t> nimg(n, pin), images(n * stride, -1, pin), evals(n, pin);
     PVec<double> fmin(n, pin);
+    PVec<uint8_t> okp(n, pin);  // (the caller's ok[] is ordinary memory: a copy here keeps the call free of device allocations)
     for (size_t i = 0; i < n; i++) {
         const Patch3d& p = *patches[i];
         for (int k = 0; k < 4; k++) { center[4 * i + k] = p.center_[k]; normal[4 * i + k] = p.normal_[k]; }
@@ -642,12 +643,13 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
     b.n = (int32_t)n; b.max_images = stride;
     b.center = center.data(); b.normal = normal.data(); b.scale = scale.data();
     b.n_images = nimg.data(); b.images = images.data();
-    b.ok = ok; b.color = color.data(); b.ncc = ncc.data(); b.fmin = fmin.data(); b.nevals = evals.data();
+    b.ok = okp.data(); b.color = color.data(); b.ncc = ncc.data(); b.fmin = fmin.data(); b.nevals = evals.data();
     if (hpmvs_optimize_batch(dev, &o, &b, 0, nullptr) != HPMVS_OK) {
         std::cerr << "patch optimization failed: <" << hpmvs_last_error() << ">" << std::endl;
         for (size_t i = 0; i < n; i++) ok[i] = 0;
         return 0;
     }
+    memcpy(ok, okp.data(), n);
     size_t good = 0;
     for (size_t i = 0; i < n; i++) {
         lastF_[i] = fmin[i];
@@ -704,13 +706,16 @@ int PatchOptimizer::expandBatch(ExpandMode mode, const mo3d::Patch3d* const* par
     pb.center = pc.data(); pb.normal = pn.data(); pb.scale = ps.data(); pb.n_images = pnimg.data(); pb.images = pimg.data();
     ob.n = (int32_t)m; ob.max_images = stride;
     ob.center = center.data(); ob.normal = normal.data(); ob.scale = scale.data(); ob.n_images = nimg.data();
-    ob.images = images.data(); ob.ok = accepted.data(); ob.color = color.data(); ob.ncc = ncc.data();
+    PVec<uint8_t> accp(m, pin), skp(skip ? m : 0, pin);  // (pinned copies of the caller's ordinary arrays: no device allocation in the call)
+    if (skip) memcpy(skp.data(), skip, m);
+    ob.images = images.data(); ob.ok = accp.data(); ob.color = color.data(); ob.ncc = ncc.data();
     ob.fmin = fmin.data(); ob.nevals = evals.data();
-    if (hpmvs_expand_batch(dev, &o, (int)mode, &pb, cc.data(), cw.data(), skip, &ob, 0, nullptr) != HPMVS_OK) {
+    if (hpmvs_expand_batch(dev, &o, (int)mode, &pb, cc.data(), cw.data(), skip ? skp.data() : nullptr, &ob, 0, nullptr) != HPMVS_OK) {
         std::cerr << "frontier expansion failed: <" << hpmvs_last_error() << ">" << std::endl;
         accepted.assign(m, 0);
         return N;
     }
+    memcpy(accepted.data(), accp.data(), m);
     candidates.resize(m);
     for (size_t t = 0; t < m; t++) {
         Patch3d& q = candidates[t];
