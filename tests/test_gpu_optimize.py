@@ -310,6 +310,25 @@ def test_invalid_image_ids_are_rejected_not_dereferenced(tiny_seeds, oracle_scen
     assert [p.stage for p in P] == [101, 101, 101]
 
 
+def test_batch_size_does_not_matter(tiny_scene, gpu_scene):
+    """The launch lays a batch out differently depending on its size (kernel_optimize.hip, `quota`): up to 112 patches per
+    workgroup go to all eight wavefronts with fixed state slots (two wavefronts per region, no paging), a bigger share is
+    packed into full wavefronts that time-share the regions, 4 or fewer patches of a host-pointer call go through the open
+    batch, up to 4096 through the pooled staging.  A patch's result is the same bits whichever way its batch went."""
+    from hpmvs_amd import api, synth
+    n_big = 36000   # 141 patches per workgroup: packed wavefronts, LDS time-sharing
+    seeds = synth.make_seeds(tiny_scene, n_big, start_level=2, max_images=16, seed=synth.SEED + 5)
+    whole = api.Batch.from_seeds(seeds)
+    api.optimize_batch(gpu_scene, whole)
+    assert 0 < whole.ok.sum() < n_big
+    fields = ("ok", "center", "normal", "n_images", "images", "color", "fmin", "x", "nevals", "stage", "ngrabs")
+    for lo, n in ((0, 3), (100, 5), (1000, 700), (2000, 4096), (7000, 9000), (5000, 28000)):
+        part = api.Batch.from_seeds(seeds, np.arange(lo, lo + n))
+        api.optimize_batch(gpu_scene, part)
+        for f in fields:
+            assert np.array_equal(getattr(part, f), getattr(whole, f)[lo:lo + n]), (lo, n, f)
+
+
 def test_batch_order_does_not_matter(tiny_scene, tiny_seeds, gpu_scene):
     """Patches are independent (PatchOptimizer.cpp:78-103): refining a permuted batch gives the permuted results,
     byte for byte -- the property the host-side tile sort (distributed.tile_order) and the patch-index
