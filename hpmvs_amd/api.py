@@ -240,29 +240,23 @@ class Batch:
 
     def pin(self):
         """Move every array into pinned host memory (hpmvs_host_alloc).  Host-pointer calls then use the arrays in place
-        (include/hpmvs_amd.h, "Host-pointer calls and pinned memory").  The arrays belong to this object: they are freed
-        with it."""
+        (include/hpmvs_amd.h, "Host-pointer calls and pinned memory").  A pinned block lives exactly as long as the last
+        numpy view of it: `c = batch.center` stays valid after the Batch is gone, and pinning again releases the previous
+        blocks as soon as nothing refers to them."""
+        import weakref
         L = lib()
-        self._pins = getattr(self, "_pins", [])
         for name in self.FIELDS:
             a = getattr(self, name)
             nbytes = max(int(a.nbytes), 1)
             p = L.hpmvs_host_alloc(nbytes)
             if not p:
                 raise MemoryError(f"hpmvs_host_alloc({nbytes})")
-            self._pins.append(p)
-            na = np.frombuffer((C.c_char * nbytes).from_address(p), dtype=a.dtype, count=a.size).reshape(a.shape)
+            buf = (C.c_char * nbytes).from_address(p)   # every view of the new array keeps `buf` alive through .base
+            weakref.finalize(buf, L.hpmvs_host_free, p)
+            na = np.frombuffer(buf, dtype=a.dtype, count=a.size).reshape(a.shape)
             na[...] = a
             setattr(self, name, na)
         return self
-
-    def __del__(self):
-        for p in getattr(self, "_pins", []):
-            try:
-                lib().hpmvs_host_free(p)
-            except Exception:  # noqa: BLE001 -- interpreter shutdown
-                pass
-        self._pins = []
 
     def c_struct(self) -> PatchBatch:
         b = PatchBatch()

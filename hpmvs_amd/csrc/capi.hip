@@ -465,7 +465,17 @@ static void* mapped_host(const void* host, size_t bytes) {
         (void)hipGetLastError();  // pageable memory: not an error here
         return nullptr;
     }
-    return ((const char*)d1 - (const char*)d0 == (ptrdiff_t)(bytes - 1)) ? d0 : nullptr;
+    if ((const char*)d1 - (const char*)d0 != (ptrdiff_t)(bytes - 1)) return nullptr;
+    // ... and both ends must belong to ONE allocation: two adjacent registrations could map their first and last byte the
+    // right distance apart by accident.  Where the runtime cannot name the allocation the end-point test stands.
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)d0) == hipSuccess && base && size) {
+        if ((const char*)d0 < (const char*)base || (const char*)d0 + bytes > (const char*)base + size) return nullptr;
+    } else {
+        (void)hipGetLastError();
+    }
+    return d0;
 }
 
 // copy: the array is an input (its contents travel to the device).  need_zero: an output the kernel may leave untouched for
@@ -495,9 +505,14 @@ int stage_in(Staged& st, T*& dst, const T* host, size_t count, bool copy, bool n
 // The copies / zero-fills of everything stage_in allocated.  Separate from the allocations so that only those (and the
 // frees) run in the Exclusive scope: two threads staging big host batches against one scene overlap their copies and
 // their launches (16 workspaces), they only take turns at hipMalloc / hipFree.
-int stage_flush(Staged& st) {
+// With a launch stream the fills are issued ON it (ordered with the launch, and not waiting behind an open-batch kernel the
+// way null-stream work can: ADVICE r4); a pageable source is consumed before hipMemcpyAsync returns.
+int stage_flush(Staged& st, hipStream_t on = nullptr) {
     for (const Staged::Fill& f : st.fills) {
-        if (f.src) HIPCHK(hipMemcpy(f.dst, f.src, f.bytes, hipMemcpyHostToDevice));
+        if (on) {
+            if (f.src) HIPCHK(hipMemcpyAsync(f.dst, f.src, f.bytes, hipMemcpyHostToDevice, on));
+            else HIPCHK(hipMemsetAsync(f.dst, 0, f.bytes, on));
+        } else if (f.src) HIPCHK(hipMemcpy(f.dst, f.src, f.bytes, hipMemcpyHostToDevice));
         else HIPCHK(hipMemset(f.dst, 0, f.bytes));
     }
     st.fills.clear();
@@ -521,6 +536,10 @@ int check_batch_shape(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_
     // below 1 would let an empty list reach setINCCs (the reference's addImages fails on an empty list regardless)
     if (o->MINLEVEL < 0 || o->MINLEVEL > o->MAXLEVEL) return fail(HPMVS_ERR_ARG, "MINLEVEL out of range");
     if (o->MIN_IMAGES_PER_PATCH < 1) return fail(HPMVS_ERR_ARG, "MIN_IMAGES_PER_PATCH must be >= 1");
+    // sampleTexture reads pyramid levels up to MAXLEVEL - 1 (PatchOptimizer.cpp:487); the device forms the level's address
+    // arithmetically inside the view's slab (prep_from_view), so a view with fewer levels must be refused here
+    for (int v = 0; v < s->n_views; v++)
+        if (s->hviews[v].n_levels < o->MAXLEVEL) return fail(HPMVS_ERR_ARG, "options.MAXLEVEL exceeds the pyramid levels of a view");
     return HPMVS_OK;
 }
 
@@ -1120,7 +1139,7 @@ int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_pat
         s->last_staged_bytes = sg.staged_bytes; s->last_mapped_bytes = sg.mapped_bytes;
     } else rc = stage_batch(sg, b, true, true);
     if (rc) return rc;
-    if ((rc = stage_flush(sg))) return rc;
+    if ((rc = stage_flush(sg, st))) return rc;
     const DevOptions d = make_dev_options(o);
     {
         {

@@ -34,9 +34,20 @@
 // kPinFrom patches take ordinary memory: the C ABI serves those from its own pinned staging pool anyway.
 namespace {
 constexpr size_t kPinFrom = 4096;
+// A thread keeps at most this many bytes of pinned blocks for reuse ($HPMVS_PIN_CACHE_MB, default 512): a frontier loop whose
+// round size changes every round would otherwise leave one non-swappable block per size class and array behind (images[]
+// alone is m * 64 * 4 bytes) and end up holding several times its peak working set pinned.  Beyond the cap the
+// least recently returned blocks go back to the system (hipHostFree).
 struct PinnedCache {
-    std::vector<void*> free_[4 * 48];
-    ~PinnedCache() { for (auto& v : free_) for (void* p : v) hpmvs_host_free(p); }
+    struct Entry { void* p; int cls; size_t bytes; };
+    std::vector<Entry> lru_;  // blocks available for reuse, oldest first
+    size_t cached_ = 0, cap_;
+    PinnedCache() {
+        const char* e = getenv("HPMVS_PIN_CACHE_MB");
+        const long mb = e ? atol(e) : 512;
+        cap_ = (size_t)(mb < 0 ? 0 : mb) << 20;
+    }
+    ~PinnedCache() { for (auto& e : lru_) hpmvs_host_free(e.p); }
     // size classes: four per octave from 4 KB (a block is at most 25 % larger than asked for)
     static int cls(size_t bytes, size_t* rounded) {
         int e = 12;
@@ -47,28 +58,58 @@ struct PinnedCache {
         *rounded = ((size_t)1 << e) + k * q;
         return 4 * (e - 12) + (int)k;
     }
-    void* get(size_t bytes) {
-        size_t r;
-        const int c = cls(bytes, &r);
-        if (!free_[c].empty()) { void* p = free_[c].back(); free_[c].pop_back(); return p; }
-        return hpmvs_host_alloc(r);
+    void* get(size_t bytes, size_t* rounded) {
+        const int c = cls(bytes, rounded);
+        for (size_t i = lru_.size(); i-- > 0;)  // the most recently returned block of the class
+            if (lru_[i].cls == c) { void* p = lru_[i].p; cached_ -= lru_[i].bytes; lru_.erase(lru_.begin() + (long)i); return p; }
+        return hpmvs_host_alloc(*rounded);
     }
-    void put(void* p, size_t bytes) { size_t r; free_[cls(bytes, &r)].push_back(p); }
+    void put(void* p, size_t rounded) {
+        size_t r;
+        lru_.push_back(Entry{p, cls(rounded, &r), rounded});
+        cached_ += rounded;
+        while (cached_ > cap_ && !lru_.empty()) {  // over the cap: the oldest blocks go back to the system
+            cached_ -= lru_.front().bytes;
+            hpmvs_host_free(lru_.front().p);
+            lru_.erase(lru_.begin());
+        }
+    }
+    size_t cached_bytes() const { return cached_; }
+    void set_cap(size_t bytes) {
+        cap_ = bytes;
+        while (cached_ > cap_ && !lru_.empty()) { cached_ -= lru_.front().bytes; hpmvs_host_free(lru_.front().p); lru_.erase(lru_.begin()); }
+    }
 };
 thread_local PinnedCache tl_pins;
+// Whether a block is pinned is recorded IN the block (a 64-byte header in front of the data), not in the allocator object:
+// a vector that owns a pinned block and later reallocates from an allocator whose pinning failed must still hand the old
+// block back to the cache, not to ::operator delete.
+struct PinHeader { unsigned long long magic; unsigned long long pinned; size_t rounded; char pad[40]; };
+static_assert(sizeof(PinHeader) == 64, "the data keeps the block's 64-byte alignment");
+constexpr unsigned long long kPinMagic = 0x48504d5650494e21ull;  // "HPMVPIN!"
 template <class T>
 struct PinnedAlloc {
     using value_type = T;
-    bool pin;  // false: ordinary memory
+    bool pin;  // false: ordinary memory is asked for
     explicit PinnedAlloc(bool p = false) : pin(p) {}
     template <class U> PinnedAlloc(const PinnedAlloc<U>& o) : pin(o.pin) {}
     T* allocate(size_t n) {
-        if (pin) { if (void* p = tl_pins.get(sizeof(T) * n)) return (T*)p; pin = false; }  // (pinning failed: pageable, staged)
-        return (T*)::operator new(sizeof(T) * n);
+        const size_t bytes = sizeof(T) * n + sizeof(PinHeader);
+        PinHeader* h = nullptr;
+        size_t rounded = 0;
+        if (pin) h = (PinHeader*)tl_pins.get(bytes, &rounded);  // (nullptr: pinning failed -> pageable memory, staged by the C ABI)
+        const bool pinned = h != nullptr;
+        if (!h) h = (PinHeader*)::operator new(bytes);
+        h->magic = kPinMagic; h->pinned = pinned ? 1ull : 0ull; h->rounded = rounded;
+        return (T*)(h + 1);
     }
-    void deallocate(T* p, size_t n) { if (pin) tl_pins.put(p, sizeof(T) * n); else ::operator delete(p); }
-    template <class U> bool operator==(const PinnedAlloc<U>& o) const { return pin == o.pin; }
-    template <class U> bool operator!=(const PinnedAlloc<U>& o) const { return pin != o.pin; }
+    void deallocate(T* p, size_t) {
+        PinHeader* h = (PinHeader*)p - 1;
+        if (h->magic != kPinMagic) { std::fprintf(stderr, "hpmvs_host: PinnedAlloc::deallocate of a foreign block\n"); std::abort(); }
+        if (h->pinned) tl_pins.put(h, h->rounded); else ::operator delete(h);
+    }
+    template <class U> bool operator==(const PinnedAlloc<U>&) const { return true; }   // any instance can free any block
+    template <class U> bool operator!=(const PinnedAlloc<U>&) const { return false; }
 };
 template <class T> using PVec = std::vector<T, PinnedAlloc<T>>;
 }  // namespace
@@ -611,6 +652,10 @@ bool PatchOptimizer::optimize(mo3d::Patch3d& patch) {
     lastEvals_.assign(1, me.evals);
     return me.ok != 0;
 }
+
+size_t PatchOptimizer::pinnedCacheBytes() { return tl_pins.cached_bytes(); }
+size_t PatchOptimizer::pinnedCacheCap() { return tl_pins.cap_; }
+void PatchOptimizer::setPinnedCacheCap(size_t bytes) { tl_pins.set_cap(bytes); }
 
 size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, uint8_t* ok) {
     lastF_.assign(n, 0.0);

@@ -238,9 +238,82 @@ def _halton_vec(n: int, base: int) -> np.ndarray:
     return out
 
 
+def _make_seeds_torch(scene, n, start_level, max_images, max_seed_images, extent, seed, displace, device) -> Seeds:
+    """make_seeds with the per-view visibility loop on a torch device (float64, the same formulas in the same
+    order): BASELINE configs[4]'s 1e7 seeds against 200 views are minutes of numpy temporaries on the host and
+    seconds here.  Device trigonometry may differ from numpy's in the last bit, so the two generators are two
+    workloads of the same distribution, not the same arrays; whoever compares GPU and oracle hands BOTH the arrays
+    this returns."""
+    import torch
+    f64 = torch.float64
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+
+    def halton(base):
+        k = torch.arange(1, n + 1, dtype=torch.int64, device=device)
+        out = torch.zeros(n, dtype=f64, device=device)
+        f = 1.0
+        while int(k.max()) > 0:
+            f /= base
+            out += f * (k % base).to(f64)
+            k = k // base
+        return out
+
+    x = (halton(2) * 2 - 1) * extent
+    y = (halton(3) * 2 - 1) * extent
+    z = height(x, y, xp=torch)
+    P = torch.stack([x, y, z], dim=1)
+    gx, gy = height_grad(x, y, xp=torch)
+    nrm = torch.stack([-gx, -gy, torch.ones_like(gx)], dim=1)
+    nrm = nrm / torch.linalg.norm(nrm, dim=1, keepdim=True)
+    Cn = np.stack([v.c for v in scene.views])
+    C = torch.from_numpy(Cn).to(device)
+    Rm = torch.from_numpy(np.stack([_R_from_quat(v.q) for v in scene.views])).to(device)
+    W = np.array([v.width for v in scene.views]); H = np.array([v.height for v in scene.views])
+    F = np.array([v.f for v in scene.views])
+    lw = W // (1 << start_level); lh = H // (1 << start_level)
+    images = -torch.ones((n, max_images), dtype=torch.int32, device=device)
+    n_images = torch.zeros(n, dtype=torch.int64, device=device)
+    margin = 2
+    cos60 = math.cos(math.radians(60.0))
+    for vi in range(scene.n_views):
+        d = P - C[vi]
+        pc = d @ Rm[vi].T
+        u = (float(F[vi]) * pc[:, 0] / pc[:, 2] + float(W[vi]) / 2.0) / (1 << start_level)
+        v = (float(F[vi]) * pc[:, 1] / pc[:, 2] + float(H[vi]) / 2.0) / (1 << start_level)
+        ray = -d / torch.linalg.norm(d, dim=1, keepdim=True)
+        vis = (pc[:, 2] > 0) & (u >= margin) & (v >= margin) & (u < int(lw[vi]) - margin) & (v < int(lh[vi]) - margin)
+        vis &= (ray * nrm).sum(dim=1) > cos60
+        vis &= n_images < max_seed_images
+        rows = torch.nonzero(vis)[:, 0]
+        images[rows, n_images[rows]] = vi
+        n_images[rows] += 1
+    first = torch.where(n_images > 0, images[:, 0].to(torch.int64), torch.zeros_like(n_images))
+    Ft = torch.from_numpy(F.astype(np.float64)).to(device)
+    c0 = C[first]
+    to_cam = c0 - P
+    dist = torch.linalg.norm(to_cam, dim=1)
+    ray0 = to_cam / dist[:, None]
+    scale0 = 2.0 * dist * (1 << start_level) / (2.0 * Ft[first])
+    uni = torch.from_numpy(rng.uniform(-1, 1, size=n)).to(device)
+    center = P + ray0 * (uni * displace * scale0)[:, None]
+    one = torch.ones((n, 1), dtype=f64, device=device)
+    c32 = torch.cat([center, one], dim=1).to(torch.float32)
+    cc = torch.cat([c0, one], dim=1).to(torch.float32)
+    nvec = cc - c32
+    nvec = nvec / torch.sqrt((nvec * nvec).sum(dim=1))[:, None]
+    nvec[:, 3] = 0.0
+    fz = torch.sqrt(((c32 - cc) ** 2).sum(dim=1))
+    scale = (2.0 * fz.to(f64) * (1 << start_level) / (2.0 * Ft[first].to(torch.float32).to(f64))).to(torch.float32)
+    return Seeds(center=c32.cpu().numpy(), normal=nvec.cpu().numpy(), scale=scale.cpu().numpy(),
+                 n_images=n_images.to(torch.int32).cpu().numpy(), images=images.cpu().numpy(), truth=P.cpu().numpy())
+
+
 def make_seeds(scene: SynthScene, n: int, start_level: int = 4, max_images: int = 32, max_seed_images: int = 8,
-               extent: float = 8.0, seed: int = SEED, displace: float = 0.5) -> Seeds:
-    """Seed patches the way Scene::initPatches builds them (reference Scene.cpp:123-163)."""
+               extent: float = 8.0, seed: int = SEED, displace: float = 0.5, device=None) -> Seeds:
+    """Seed patches the way Scene::initPatches builds them (reference Scene.cpp:123-163).  `device` (a torch device):
+    the same construction with torch on that device (see _make_seeds_torch)."""
+    if device is not None:
+        return _make_seeds_torch(scene, n, start_level, max_images, max_seed_images, extent, seed, displace, device)
     rng = np.random.Generator(np.random.PCG64(seed + 1))
     x = (_halton_vec(n, 2) * 2 - 1) * extent
     y = (_halton_vec(n, 3) * 2 - 1) * extent

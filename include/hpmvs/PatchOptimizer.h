@@ -37,6 +37,13 @@ public:
     // (final mean robust INCC f*, PatchOptimizer.cpp:365,376): one entry per patch
     const std::vector<double>& lastObjective() const { return lastF_; }
     const std::vector<int>& lastEvaluations() const { return lastEvals_; }
+    // The batch entries keep their structure-of-arrays copies in pinned host memory that the GPU uses in place, reused from
+    // call to call through a per-thread cache.  Bytes the CALLING thread holds for reuse right now, and the cap beyond which
+    // returned blocks go back to the system (default 512 MB, $HPMVS_PIN_CACHE_MB; setPinnedCacheCap changes it for the
+    // calling thread and trims at once).
+    static size_t pinnedCacheBytes();
+    static size_t pinnedCacheCap();
+    static void setPinnedCacheCap(size_t bytes);
 private:
     const mo3d::HpmvsOptions* options_p;
     const mo3d::Scene* scene_p;

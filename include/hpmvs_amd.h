@@ -222,7 +222,12 @@ int hpmvs_depth_gates_batch(const hpmvs_scene *s, const hpmvs_patch_batch *b, fl
  * kernel runs; pageable arrays are copied through device buffers as before, array by array.  Results are identical either
  * way (outputs the kernel does not write for a failed patch -- color, ncc -- read 0, as after a staged call).  The
  * reference has no counterpart: its patches live in host containers (Scene.cpp:94-96, CellProcessor.cpp:129).
- * HPMVS_ZERO_COPY=0 in the environment switches the detection off. */
+ * HPMVS_ZERO_COPY=0 in the environment switches the detection off.
+ * ON AN INFRASTRUCTURE ERROR (negative status: a HIP error while enqueueing, no workspace) the two forms differ: a staged
+ * call leaves the caller's arrays untouched, an in-place call may already have refined some patches in place (center,
+ * normal, n_images, images) and zero-filled color / ncc -- treat the in/out arrays of a pinned batch as undefined after a
+ * negative status and rebuild them.  Argument errors (HPMVS_ERR_ARG / _STATE) are detected before the first write in
+ * both forms.  Per-patch failure (ok[i] == 0) is not an error and leaves that patch untouched in both forms. */
 void *hpmvs_host_alloc(size_t bytes);   /* NULL on failure */
 void hpmvs_host_free(void *p);
 /* of the last host-pointer hpmvs_optimize_batch call above the small-batch thresholds: bytes copied through device

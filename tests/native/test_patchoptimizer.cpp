@@ -91,6 +91,8 @@ int main(int argc, char** argv) {
                    copies[i].images_.size());
     }
     // (2) the additive batch entry
+    std::vector<mo3d::Patch3d> originals;  // the seeds as read (the batch entry refines `patches` in place)
+    for (auto& p : patches) originals.emplace_back(*p);
     std::vector<mo3d::Patch3d*> raw;
     for (auto& p : patches) raw.push_back(p.get());
     std::vector<unsigned char> ok(np);
@@ -135,6 +137,29 @@ int main(int argc, char** argv) {
         for (size_t t = 0; t < acc.size() && fine; t++)
             printf("depth %zu %d %d %d %d %d %d\n", t, vis[t], blk[t], fre[t], vis2[t], blk2[t], fre2[t]);
         if (!fine) printf("depth failed\n");
+    }
+    // (5) the per-thread cache of pinned blocks stays under its cap whatever sizes the rounds have (a frontier
+    //     loop whose round size changes every round must not pile up one pinned block per size class)
+    {
+        const size_t cap = (size_t)8 << 20;
+        mo3d::PatchOptimizer::setPinnedCacheCap(cap);
+        size_t worst = 0;
+        std::vector<mo3d::Patch3d> copies;
+        for (int rep = 0; rep < 12; rep++) {
+            const size_t m = 4100 + 3000 * (size_t)rep;  // above the pinning threshold, a different size class every round
+            copies.assign(m, originals[0]);
+            for (size_t i = 0; i < m; i++) copies[i] = originals[i % np];
+            std::vector<mo3d::Patch3d*> ptrs(m);
+            for (size_t i = 0; i < m; i++) ptrs[i] = &copies[i];
+            std::vector<unsigned char> okm(m);
+            optimizers[0].optimizeBatch(ptrs.data(), m, okm.data());
+            const size_t held = mo3d::PatchOptimizer::pinnedCacheBytes();
+            worst = held > worst ? held : worst;
+            int same = 1;
+            for (size_t i = 0; i < m; i++) same &= (okm[i] == ok[i % np]);
+            if (!same) { printf("pincache results differ in round %d\n", rep); break; }
+        }
+        printf("pincache cap %zu worst %zu\n", cap, worst);
     }
     printf("good %zu\n", good);
     return 0;

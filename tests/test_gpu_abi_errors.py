@@ -49,6 +49,25 @@ def test_scene_life_cycle_and_argument_errors(tiny_scene, tiny_seeds):
     assert L.hpmvs_scene_destroy(h) == 0
 
 
+def test_options_deeper_than_the_pyramid_are_refused(tiny_scene, tiny_seeds):
+    """ADVICE r4: sampleTexture reads levels up to MAXLEVEL - 1 and the device forms the level's address arithmetically;
+    a scene whose views hold fewer pyramid levels than options.MAXLEVEL must be refused, not sampled past its slab."""
+    import copy
+    from hpmvs_amd import api
+    L = api.lib()
+    shallow = copy.copy(tiny_scene)
+    shallow.max_level = 2              # 3 levels per view
+    sc = api.Scene(shallow, device=0)
+    b = api.Batch.from_seeds(tiny_seeds, np.arange(8))
+    cb = b.c_struct()
+    o = api.default_options()          # MAXLEVEL = 5 > 3 levels
+    assert L.hpmvs_optimize_batch(sc.h, C.byref(o), C.byref(cb), 0, None) == -2
+    assert b"MAXLEVEL" in L.hpmvs_last_error()
+    o.MAXLEVEL = 3                     # exactly as deep as the pyramid: served
+    assert L.hpmvs_optimize_batch(sc.h, C.byref(o), C.byref(cb), 0, None) == 0
+    sc.close()
+
+
 def test_expand_shape_errors(tiny_seeds, gpu_scene):
     from hpmvs_amd import api
     L = api.lib()

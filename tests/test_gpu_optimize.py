@@ -70,7 +70,7 @@ def compare(seeds, oracle_scene, gpu_scene, tag):
     with open("gpurun_out/parity_reports.jsonl", "a") as fh:
         fh.write(json.dumps(report) + "\n")
     assert agree.mean() == 1.0, report
-    assert report["bit_identical_patch"] >= 0.99, report
+    assert report["bit_identical_patch"] >= 0.999, report  # measured: 1.0 on every scene of this file
     # The optimiser variables x[3] (float64, exported by the ABI).  x[0] (depth) and x[2] (asin of a float32, the
     # glibc algorithm restated on the device) must be identical.  x[1] starts from a float64 acos(): the device
     # rounds it to nearest (cr_acos.hpp), glibc 2.35 does not always (its acos is < 1 ulp, not correctly rounded),
@@ -86,7 +86,7 @@ def compare(seeds, oracle_scene, gpu_scene, tag):
             assert xc[0] == xg[0] and xc[2] == xg[2], (tag, k, xc, xg)
             assert abs(xc[1] - xg[1]) <= 16 * np.spacing(abs(xc[1])), (tag, k, xc, xg)
     assert np.mean(dncc) <= 1e-5, report
-    assert basin.mean() >= 0.99 and np.mean(same_imgs) >= 0.99, report
+    assert basin.mean() >= 0.999 and np.mean(same_imgs) >= 0.999, report
     # scale_3dx_ is returned unchanged and ncc_ is the reference's constant
     assert np.all(batch.ncc[ok_gpu] == np.float32(1.4))
     return report
@@ -161,7 +161,7 @@ def test_gpu_against_committed_goldens():
             np.array_equal(np.array(e[k]["center"], dtype=np.float32), batch.center[k]) and
             np.array_equal(np.array(e[k]["normal"], dtype=np.float32), batch.normal[k]) and
             np.array_equal(np.array(e[k]["color"], dtype=np.float32), batch.color[k]) for k in both]
-    assert np.mean(same) >= 0.99, np.mean(same)
+    assert np.mean(same) >= 0.999, np.mean(same)
     gpu.close()
 
 
