@@ -1899,8 +1899,10 @@ BQ_HD void bq_default_step(const double* x, const double* lb, const double* ub, 
 
 // bobyqa() front end (bobyqa.c:3073-3268) + the start of prelim_.  Returns BQ_CONTINUE with the
 // first point in B.xeval, or BQ_DONE with BQN(rc) = BQ_INVALID_ARGS.
+BQ_HD void bq_prelim_points(BqRef B, double (*out)[3]);
+// prelim_out (optional, 18 values): the start points 2..7 of prelim_, see bq_prelim_points
 BQ_HD_NOINLINE int bq_start(BqRef B_in, const double* x0, const double* lb, const double* ub, const double* dx,
-                   double xtol_rel, int maxeval) {
+                   double xtol_rel, int maxeval, double* prelim_out = nullptr) {
     BqRef B = BQ_UNIFORM(B_in);
     BQN(nevals) = 0; BQN(rc) = BQ_SUCCESS; BQS(minf) = HUGE_VAL; BQN(maxeval) = maxeval; BQN(phase) = bq::PH_PRELIM;
     for (int i = 0; i < 3; i++) { BQA(xfinal, i) = x0[i]; BQA(xeval, i) = x0[i]; }
@@ -1944,7 +1946,45 @@ BQ_HD_NOINLINE int bq_start(BqRef B_in, const double* x0, const double* lb, cons
     BQN(kopt) = 1; BQN(knew) = 0; BQN(kbase) = 1; BQN(ntrits) = 0; BQN(itest) = 0; BQN(nresc) = 0; BQN(nfsav) = 0; BQN(nf) = 0;
     bq::prelim_next_point(B);
     BQN(nevals)++;
+    if (prelim_out) {
+        double pts[6][3];
+        bq_prelim_points(B, pts);
+        for (int k = 0; k < 6; k++) for (int i = 0; i < 3; i++) prelim_out[3 * k + i] = pts[k][i];
+    }
     return BQ_CONTINUE;
+}
+
+// The evaluation points 2 .. 7 of prelim_ (bobyqa.c:1822-1883), all at once.  They are functions of the start point, the
+// bounds and rhobeg only -- point nf is xbase + (one coordinate step), the step of the second family (nf >= 5) reads the
+// first family's step of the same coordinate, and the exchange prelim_ makes after an evaluation (bobyqa.c:1916-1926)
+// touches one column of XPT that no later point reads -- so a caller may evaluate them side by side and feed the values
+// to bq_step in order (fewer sequential rounds per patch).  Pure: the state is not changed; out[k] is
+// bit for bit the xeval that bq_step leaves after consuming point k + 1 (tests/test_cpu_oracle.py pins that on the host
+// build).  Valid after a bq_start that returned BQ_CONTINUE.
+BQ_HD void bq_prelim_points(BqRef B, double (*out)[3]) {
+    const double rhobeg = BQS(rhobeg);
+    for (int nf = 2; nf <= 7; nf++) {
+        double row[3] = {0.0, 0.0, 0.0};
+        if (nf <= 4) {
+            const int nfm = nf - 1;
+            double stepa = rhobeg;
+            if (BQ_V(su, nfm) == 0.0) stepa = -stepa;
+            row[nfm - 1] = stepa;
+        } else {
+            const int nfx = nf - 4;
+            double stepb = -rhobeg;
+            if (BQ_V(sl, nfx) == 0.0) stepb = bq::mn(2.0 * rhobeg, BQ_V(su, nfx));
+            if (BQ_V(su, nfx) == 0.0) stepb = bq::mx(-2.0 * rhobeg, BQ_V(sl, nfx));
+            row[nfx - 1] = stepb;
+        }
+        for (int i = 1; i <= 3; i++) {  // set_x_from on that row
+            const double pi = row[i - 1];
+            double v = bq::mn(bq::mx(BQ_V(xl, i), BQ_V(xbase, i) + pi), BQ_V(xu, i));
+            if (pi == BQ_V(sl, i)) v = BQ_V(xl, i);
+            if (pi == BQ_V(su, i)) v = BQ_V(xu, i);
+            out[nf - 2][i - 1] = v * BQ_V(sc, i);
+        }
+    }
 }
 
 BQ_HD_NOINLINE int bq_step_(BqRef B, double f);

@@ -122,6 +122,31 @@ constexpr int kPark16 = HPMVS_REGION_16;  // 16-byte chunks of a wavefront's par
 #ifndef HPMVS_PARK_AUX
 #define HPMVS_PARK_AUX 0
 #endif
+// PROXIES (round 5; VERDICT r4 #4: fewer SEQUENTIAL rounds per patch).  Two runs of evaluations of a patch do not depend on
+// each other's values: prelim_'s seven start points (functions of the start point, the bounds and rhobeg: bq_prelim_points)
+// and setRefImage's candidates (PatchOptimizer.cpp:154-181: one robust setINCCs per attached image).  A lane that is in one of
+// them evaluates the next point itself, as before, and offers the FOLLOWING ones to lanes of its wavefront that own no patch
+// in this round (the ramp-down of a launch, small batches, the open batch behind single-patch callers): the owner leaves what a
+// request needs (centre, normal, scale, list) in its proxy row, a free lane posts the request, the photometric service
+// serves it like any other, and the owner consumes the values in the reference's order -- bq_step once per value,
+// `res_sum < refbest` in index order.  Same operations in the same order per patch; a patch needs up to 6 + (V - 1) fewer
+// rounds.  Nothing changes while every lane owns a patch.  No call site and no second copy of set_center_norm is added
+// to the persistent loop (either costs the hot path ~100 spilled registers: measured while building this).
+// Measured (profiles/r05/proxies_ab.txt; all results byte-identical, the whole -m gpu suite green with HPMVS_PROXY=2): a
+// host call of 8 patches 2.50 -> 2.32 ms, but the extra live values cost the batch kernels 2-4 % (C1 22.7 -> 23.7 ms, C2
+// 215.3 -> 219.8 ms, 125 k seeds 37.1 -> 38.2 ms; 14-24 more spilled registers) for a ramp-down that gets no shorter (a patch
+// that starts while the queue drains finds no free lane during its prelim_), and the open batch behind single-patch callers
+// got SLOWER with them (2.50 -> 2.61 ms per call: 178 spilled registers against 135).  So the product is built WITHOUT
+// proxies (HPMVS_PROXY = 0; 1: the open batch only, 2: every kernel); the code stays as an opt-in like HPMVS_FAST_SUMS.
+#ifndef HPMVS_PROXY
+#define HPMVS_PROXY 0
+#endif
+constexpr int kAuxDoubles = 64;  // a slot's proxy row: [0..17] prelim_'s start points 2..7, [18..24] the values this round's proxies
+constexpr int kAuxVal = 18;      // delivered; as floats from kAuxCtx: scale, nimg, setRefImage's c / n, then c / n of the
+constexpr int kAuxCtx = 64;      // start points 2..7
+constexpr int kMaxExtra = 7;     // values a lane takes from proxies per round
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) float gfloat;
 // the state region <-> this wavefront's parking buffer.  In: LDS-DMA (global_load_lds_dwordx4: 1 KiB per
 // instruction straight into LDS at base + lane * 16, no staging registers, all ~39 pieces in flight at once).
 // Out: ds_read_b128 + 16-byte global stores (fire and forget).
@@ -216,6 +241,18 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
 #endif
     const GlobalRows erows{(float*)((char*)queue + kCounterBytes + (size_t)W * n_wgs * kP * kRow * sizeof(uint16_t) +
                                     (size_t)W * n_wgs * kPark16 * 16) + (size_t)gw * kP * kRow, kRow};
+    constexpr bool kProxy = HPMVS_PROXY == 2 || (HPMVS_PROXY == 1 && SERVICE);
+    // ... and its slots' proxy rows (behind the cold blocks)
+    gdouble* const auxw = (gdouble*)(unsigned long long)((char*)queue + kCounterBytes + (size_t)W * n_wgs * kP * kRow * sizeof(uint16_t) +
+                          (size_t)W * n_wgs * kPark16 * 16 + (size_t)W * n_wgs * kP * kRow * sizeof(float) +
+                          (size_t)W * n_wgs * (size_t)(HPMVS_COLD_GLOBAL ? (164 - HPMVS_STATE_ND) : 0) * kP * sizeof(double)) +
+                          (size_t)gw * kP * kAuxDoubles;
+    gdouble* const aux = auxw + (lane < kP ? lane : 0) * kAuxDoubles;  // my slot's row
+    int pre_nf = 0;        // batched prelim_: the start point this lane is evaluating itself (1..7); 0: not in prelim_
+    bool pre_ctx = false;  // ... and centre / normal of the start points after it are in my row
+    int extra = 0;         // values my proxies delivered in this round (aux[kAuxVal ..])
+    int px_owner = -1;     // this round I evaluate for that lane's patch ...
+    int px_k = 0;          // ... its px_k-th extra point
 
     // ---- per-lane slot state
     // Small batches are spread over as many workgroups as possible (a wavefront with fewer busy slots has shorter
@@ -436,11 +473,24 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
                 ii = 0; refindex = -1; refbest = 3.402823466e+38f;
                 op = OP_REFSUM; req_ref = 0; req_robust = 1;
                 stage = S_RS;
+                if (kProxy) {   // what a proxy needs of me while I am in setRefImage
+                    gfloat* ctx = (gfloat*)aux + kAuxCtx;
+                    ctx[0] = scale; ctx[1] = __int_as_float(nimg);
+                    for (int k = 0; k < 3; k++) { ctx[2 + k] = c[k]; ctx[5 + k] = n[k]; }
+                }
                 break;
             }
             case S_RS: {  // setRefImage (PatchOptimizer.cpp:154-181): one robust setINCCs per candidate
                 if (res_sum < refbest) { refbest = res_sum; refindex = ii; }
                 ii++;
+                if (kProxy) {
+                    for (int k = 0; k < extra; k++) {  // the candidates my proxies evaluated, in index order
+                        const float sx = (float)aux[kAuxVal + k];
+                        if (sx < refbest) { refbest = sx; refindex = ii; }
+                        ii++;
+                    }
+                    extra = 0;
+                }
                 if (ii < nimg) { op = OP_REFSUM; req_ref = ii; req_robust = 1; break; }
                 if (refindex > 0) {  // swap the chosen image into slot 0
                     const uint16_t t = row[0];
@@ -588,8 +638,27 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
 #ifdef HPMVS_HOLD_DELAY  /* experiment: how sensitive is the launch to the time a state region is held? */
             for (int dly = 0; dly < HPMVS_HOLD_DELAY; dly++) __builtin_amdgcn_s_sleep(127);
 #endif
-            if (op == OPQ_START) ret = bq_start(B, x0, lbv, ubv, dx, 1.e-7, 1000);
-            if (op == OPQ_STEP) ret = bq_step(B, res_f);
+            if (kProxy) {
+                if (op == OPQ_START) {
+                    ret = bq_start(B, x0, lbv, ubv, dx, 1.e-7, 1000, (double*)(unsigned long long)aux);  // (+ prelim_'s start points 2..7 into my row)
+                    pre_nf = ret == BQ_CONTINUE ? 1 : 0; pre_ctx = false;
+                }
+                // bq_step with my own value; in prelim_ then with the values my proxies delivered, in order (ONE call site)
+                const bool pre = op == OPQ_STEP && pre_nf > 0;
+                bool stepping = op == OPQ_STEP;
+                double fcur = res_f;
+                int kx = 0;
+                for (;;) {
+                    if (stepping) { ret = bq_step(B, fcur); pre_nf += pre ? 1 : 0; }
+                    stepping = pre && kx < extra && ret == BQ_CONTINUE;
+                    if (!__any(stepping)) break;
+                    if (stepping) { fcur = (double)aux[kAuxVal + kx]; kx++; }
+                }
+                if (pre) { if (pre_nf > 7 || ret != BQ_CONTINUE) pre_nf = 0; extra = 0; }  // (> 7: prelim_ is over)
+            } else {
+                if (op == OPQ_START) ret = bq_start(B, x0, lbv, ubv, dx, 1.e-7, 1000);
+                if (op == OPQ_STEP) ret = bq_step(B, res_f);
+            }
             double xe[3] = {0, 0, 0};
             if (mine) {
                 for (int k = 0; k < 3; k++) xe[k] = BQA(xeval, k);  // next point, or the final one (same slot)
@@ -623,27 +692,76 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
 #if HPMVS_BQ_PRIO
             __builtin_amdgcn_s_setprio(HPMVS_A_PRIO);
 #endif
-            if (mine) {
-                if (ret == BQ_CONTINUE) {
-                    set_center_norm(F, o, xe, c, n);
-                    op = OP_OBJ;
-                } else if (op == OPQ_START || !(nl_result >= 1 && nl_result <= 4)) {
-                    // bq_start refused the arguments, or a result other than SUCCESS / STOPVAL / FTOL / XTOL
-                    // (PatchOptimizer.cpp:367-368; negative codes throw)
-                    op = OP_NONE;
-                    stage = S_BQFAIL;
-                } else {
-                    set_center_norm(F, o, xe, c, n);
-                    op = OPL_ADD;  // addImages
-                    stage = S_ADD2;
+            {
+                const bool cont = mine && ret == BQ_CONTINUE;
+                // bq_start refused the arguments, or a result other than SUCCESS / STOPVAL / FTOL / XTOL (PatchOptimizer.cpp:367-368; negative codes throw)
+                const bool failed = mine && !cont && (op == OPQ_START || !(nl_result >= 1 && nl_result <= 4));
+                const bool done = mine && !cont && !failed;
+                int nset = (cont || done) ? 1 : 0;  // setCenterNorm (PatchOptimizer.cpp:401-414) of the next point / the final one ...
+                // ... and, once per patch and only while lanes are free to act as proxies, of prelim_'s start points after it
+                const int pfirst = pre_nf;  // the start point `xe` is
+                if (kProxy) {
+                    const bool anyfree = __any(!mine && op == OP_NONE && lane < kP && (stage == S_IDLE || (service && stage == S_WAIT)));
+                    if (anyfree && cont && pre_nf >= 1 && pre_nf <= 6 && !pre_ctx) { nset = 8 - pre_nf; pre_ctx = true; }
                 }
+                for (int k = 0; __any(k < nset); k++) {  // (ONE inlined copy of set_center_norm in the persistent loop)
+                    if (k < nset) {
+                        double xk[3] = {xe[0], xe[1], xe[2]};
+                        float ck[3], nk[3];
+                        if (kProxy && k > 0) for (int i3 = 0; i3 < 3; i3++) xk[i3] = aux[3 * (pfirst + k - 2) + i3];  // start point pfirst + k
+                        set_center_norm(F, o, xk, ck, nk);
+                        if (k == 0) { for (int i3 = 0; i3 < 3; i3++) { c[i3] = ck[i3]; n[i3] = nk[i3]; } }
+                        else if (kProxy) {
+                            gfloat* ctx = (gfloat*)aux + kAuxCtx + 8 + 6 * (pfirst + k - 2);
+                            for (int i3 = 0; i3 < 3; i3++) { ctx[i3] = ck[i3]; ctx[3 + i3] = nk[i3]; }
+                            gfloat* c0 = (gfloat*)aux + kAuxCtx;
+                            c0[0] = scale; c0[1] = __int_as_float(nimg);
+                        }
+                    }
+                }
+                if (cont) op = OP_OBJ;
+                else if (failed) { op = OP_NONE; stage = S_BQFAIL; }
+                else if (done) { op = OPL_ADD; stage = S_ADD2; }  // addImages
             }
             // failed lanes finish in phase A; finished optimisations go on with addImages in the list services
             if (__any((op == OP_NONE && stage != S_IDLE) || (op >= OPL_ADD && op <= OPL_F3))) continue;
         }
+        const uint16_t* brow = row;  // the image list my request of this round refers to (a proxy's: its owner's)
+        if (kProxy) {
+            // lanes that own no patch in this round ...
+            unsigned long long freem = __ballot(op == OP_NONE && lane < kP && (stage == S_IDLE || (service && stage == S_WAIT)) && !fin_pending);
+            // ... and lanes with further independent evaluations: prelim_'s start points pre_nf + 1 .. 7, setRefImage's candidates req_ref + 1 .. nimg - 1
+            int want = 0;
+            if (op == OP_OBJ && pre_ctx && pre_nf >= 1 && pre_nf <= 6) want = 7 - pre_nf;
+            else if (op == OP_REFSUM && stage == S_RS) want = nimg - 1 - req_ref;
+            want = want > kMaxExtra ? kMaxExtra : want;
+            unsigned long long own = freem ? __ballot(want > 0) : 0ull;
+            if (own) {  // (wave-uniform)
+                for (; own && freem; own &= own - 1ull) {
+                    const int p = __ffsll((long long)own) - 1;
+                    const int w = bcast_i(want, p);
+                    int cnt = 0;
+                    for (; cnt < w && freem; cnt++, freem &= freem - 1ull)
+                        if (lane == __ffsll((long long)freem) - 1) { px_owner = p; px_k = cnt; }
+                    if (lane == p) extra = cnt;
+                }
+                // a proxy's request, from its owner's row (the proxy's own patch variables are dead: it owns no patch)
+                const int src = px_owner >= 0 ? px_owner : lane;
+                const int o_op = shfl_i(op, src), o_ref = shfl_i(req_ref, src), o_pre = shfl_i(pre_nf, src);
+                if (px_owner >= 0) {
+                    brow = lists + px_owner * kRow;
+                    const gfloat* ctx = (const gfloat*)(auxw + px_owner * kAuxDoubles) + kAuxCtx;
+                    scale = ctx[0]; nimg = __float_as_int(ctx[1]);
+                    const gfloat* cn = (o_op == OP_OBJ) ? ctx + 8 + 6 * (o_pre - 1 + px_k) : ctx + 2;  // start point o_pre + 1 + px_k; or setRefImage's patch
+                    for (int k = 0; k < 3; k++) { c[k] = cn[k]; n[k] = cn[3 + k]; }
+                    if (o_op == OP_OBJ) op = OP_OBJ;
+                    else { op = OP_REFSUM; req_ref = o_ref + 1 + px_k; req_robust = 1; }  // candidate o_ref + 1 + px_k of setRefImage
+                }
+            }
+        }
         BQ_PROF_BEGIN(tax_);
         if (op != OP_NONE) {  // calculatePatchAxis (PatchOptimizer.cpp:532-548), lane-parallel
-            const DevView& RV = sc.views[row[op == OP_OBJ ? 0 : req_ref]];
+            const DevView& RV = sc.views[brow[op == OP_OBJ ? 0 : req_ref]];
             calc_patch_axes(RV.xaxis, RV.yaxis, n, scale, ax, ay, az);
         }
         BQ_PROF_END(tax_, 17);
@@ -675,7 +793,7 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
             PackedRes r;
             r.obj = 2.0; r.keep = 0ull; r.incc_sum = 0.0f; r.ngrabs = 0;
             __builtin_amdgcn_s_setprio(0);
-            wave_eval_rows<false>(sc, o, (const uint16_t*)row, pending, q, r, erows);
+            wave_eval_rows<false>(sc, o, brow, pending, q, r, erows);
             __builtin_amdgcn_s_setprio(HPMVS_A_PRIO);
             if (op != OP_NONE) {
                 res_f = r.obj;
@@ -683,6 +801,20 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
                 res_sum = r.incc_sum;
                 ngrabs += r.ngrabs;
                 op = OP_NONE;
+            }
+            if (kProxy) {   // what the proxies of this round found goes to their owners' rows (value k of an owner: its k-th extra point)
+                const unsigned long long pm = __ballot(px_owner >= 0);
+                if (pm) {
+                    for (unsigned long long t = pm; t; t &= t - 1ull) {
+                        const int fl = __ffsll((long long)t) - 1;
+                        const int p = bcast_i(px_owner, fl), k = bcast_i(px_k, fl), g = bcast_i(r.ngrabs, fl), kind = bcast_i(q.obj_mode, fl);
+                        const double vf = bcast_d(res_f, fl);
+                        const float vs = bcast_f(res_sum, fl);
+                        if (lane == p) { aux[kAuxVal + k] = kind ? vf : (double)vs; ngrabs += g; }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the owners read these values in their next phase A
+                    px_owner = -1;
+                }
             }
         }
         wave_lds_sync();
@@ -731,14 +863,16 @@ size_t HPMVS_V(optimize_workspace_bytes)(int n_cus) {
     // counter block + per wavefront: kP image-list rows, one parking buffer for the optimiser states, kP result rows
     const size_t waves = (size_t)HPMVS_WG_WAVES * max_workgroups(n_cus, HPMVS_WG_WAVES, HPMVS_WG_REGIONS);
     return kCounterBytes + waves * kP * kRow * sizeof(uint16_t) + waves * (size_t)kPark16 * 16 + waves * kP * kRow * sizeof(float) +
-           waves * (size_t)(HPMVS_COLD_GLOBAL ? (164 - HPMVS_STATE_ND) : 0) * kP * sizeof(double);
+           waves * (size_t)(HPMVS_COLD_GLOBAL ? (164 - HPMVS_STATE_ND) : 0) * kP * sizeof(double) +
+           (HPMVS_PROXY == 2 ? waves * kP * kAuxDoubles * sizeof(double) : 0);
 }
 
 #ifndef HPMVS_VARIANT_SUFFIX
 // open batch (b.svc_ctrl set): a fixed grid of `wgs` two-wavefront workgroups (one per CU leaves room for batch launches beside it)
 size_t optimize_workspace_bytes_for(int wgs) {
     return kCounterBytes + (size_t)2 * wgs * kP * kRow * sizeof(uint16_t) + (size_t)2 * wgs * (size_t)kPark16 * 16 +
-           (size_t)2 * wgs * kP * kRow * sizeof(float) + (size_t)2 * wgs * (size_t)(HPMVS_COLD_GLOBAL ? (164 - HPMVS_STATE_ND) : 0) * kP * sizeof(double);
+           (size_t)2 * wgs * kP * kRow * sizeof(float) + (size_t)2 * wgs * (size_t)(HPMVS_COLD_GLOBAL ? (164 - HPMVS_STATE_ND) : 0) * kP * sizeof(double) +
+           (HPMVS_PROXY ? (size_t)2 * wgs * kP * kAuxDoubles * sizeof(double) : 0);
 }
 size_t optimize_stage_bytes_for(int wgs) { return (size_t)2 * wgs * kP * kSvcOutDwords * sizeof(uint32_t); }
 void launch_optimize_service(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int wgs,

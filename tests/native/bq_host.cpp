@@ -29,6 +29,26 @@ extern "C" int bq3_minimize(obj_fn f, void* data, double* x, const double* lb, c
     return BQN(rc);
 }
 
+// bq_prelim_points against the sequence of points the state machine itself produces: returns the number of the six points
+// (2 .. 7) that are bitwise equal, evaluating `f` like bq3_minimize does
+extern "C" int bq3_prelim_points_equal(obj_fn f, void* data, const double* x0, const double* lb, const double* ub, double xtol_rel) {
+    Bobyqa3 B;
+    double dx[3];
+    bq_default_step(x0, lb, ub, dx);
+    if (bq_start(B, x0, lb, ub, dx, xtol_rel, 1000) != BQ_CONTINUE) return -1;
+    double pts[6][3];
+    bq_prelim_points(B, pts);
+    int same = 0, st = BQ_CONTINUE;
+    for (int k = 0; k < 6 && st == BQ_CONTINUE; k++) {
+        const double xe[3] = {BQA(xeval, 0), BQA(xeval, 1), BQA(xeval, 2)};
+        st = bq_step(B, f(3, xe, nullptr, data));
+        if (st != BQ_CONTINUE) break;
+        same += (std::memcmp(&BQA(xeval, 0), pts[k], 8) == 0 && std::memcmp(&BQA(xeval, 1), pts[k] + 1, 8) == 0 &&
+                 std::memcmp(&BQA(xeval, 2), pts[k] + 2, 8) == 0) ? 1 : 0;
+    }
+    return same;
+}
+
 extern "C" int bq3_rescue_calls(void) { return g_rescue_calls; }
 
 // host build of the device's round-to-nearest acos (hpmvs_amd/csrc/cr_acos.hpp)

@@ -610,3 +610,42 @@ def test_oracle_extend_round_bookkeeping():
                     full.add(orc.cell_key([p.center[0] + dx * width, p.center[1] + dy * width, p.center[2] + dz * width], width))
     out, counts = orc.extend_round(osc, D, parents, width, full)
     assert all(out[t].stage == 20 and out[t].nevals == 0 for t in range(6 * len(good)))
+
+
+def test_prelim_points_all_at_once_equal_the_sequential_ones():
+    """prelim_'s evaluation points 2..7 depend on the start point, the bounds and rhobeg only, so the
+    kernel may evaluate them side by side.  bq_prelim_points (computed right after bq_start) must be bit for bit the
+    points the state machine produces one by one -- also with start points on / near the bounds (the shifted steps of
+    bobyqa.c:1838-1850) and with objective values that trigger the exchange of bobyqa.c:1916-1926."""
+    import ctypes as C
+    from helpers import bq_host, LB, UB
+    from oracle import oracle as orc
+    H = bq_host()
+    H.bq3_prelim_points_equal.argtypes = [orc.OBJ_FN, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double), C.c_double]
+    rng = np.random.default_rng(11)
+    cases = []
+    for _ in range(300):
+        cases.append(([float(rng.normal()), float(rng.uniform(-23.9, 23.9)), float(rng.uniform(-23.9, 23.9))], LB, UB))
+    for a in (-23.99999, 23.99999, -23.5, 23.2, -12.0, 12.0, 0.0):       # on a bound, within rhobeg of it, at the switch point
+        for b in (-23.99999, 23.99999, 20.0, 0.0):
+            cases.append(([0.0, a, b], LB, UB))
+    for _ in range(100):  # finite boxes in all three coordinates
+        lo = rng.uniform(-5, 0, 3); hi = lo + rng.uniform(0.5, 10, 3)
+        x0 = lo + rng.uniform(0, 1, 3) * (hi - lo)
+        cases.append(([float(v) for v in x0], [float(v) for v in lo], [float(v) for v in hi]))
+    state = {"k": 0}
+
+    def f(n, x, g, d):
+        state["k"] += 1
+        return float(rng.uniform(0.0, 2.0))   # noise: about half of the second-family points are exchanged
+    cb = orc.OBJ_FN(f)
+    checked = 0
+    for x0, lb, ub in cases:
+        x = (C.c_double * 3)(*x0); l = (C.c_double * 3)(*lb); u = (C.c_double * 3)(*ub)
+        same = H.bq3_prelim_points_equal(cb, None, x, l, u, 1e-7)
+        if same < 0:
+            continue  # bq_start refused the box (narrower than 2 rhobeg)
+        assert same == 6, (x0, lb, ub, same)
+        checked += 1
+    assert checked >= 400
