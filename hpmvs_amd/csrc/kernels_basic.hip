@@ -64,7 +64,12 @@ __device__ __forceinline__ bool list_ok(const DevScene& sc, const DevBatch& b, i
     return !bad;
 }
 
-__global__ void __launch_bounds__(64) objective_kernel(DevScene sc, DevOptions o, DevBatch b,
+// (HPMVS_OBJ_WAVES_PER_EU: measurement builds only -- what the photometric service costs under the register budget of 2 / 3 / 4
+//  wavefronts per SIMD, profiles/r05/split_gate.txt)
+#ifndef HPMVS_OBJ_WAVES_PER_EU
+#define HPMVS_OBJ_WAVES_PER_EU 2
+#endif
+__global__ void __launch_bounds__(64, HPMVS_OBJ_WAVES_PER_EU) objective_kernel(DevScene sc, DevOptions o, DevBatch b,
                                                        const double* __restrict__ xs, double* __restrict__ f_out,
                                                        int32_t* __restrict__ ngrabs_out) {
     const int lane = lane_id();
@@ -107,7 +112,7 @@ void launch_objective(const DevScene& sc, const DevOptions& o, const DevBatch& b
                       int32_t* ngrabs_out, hipStream_t st) {
     if (b.n <= 0) return;
     int blocks = (b.n + kGroups - 1) / kGroups;
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks > 256 * 4 * HPMVS_OBJ_WAVES_PER_EU) blocks = 256 * 4 * HPMVS_OBJ_WAVES_PER_EU;
     hipLaunchKernelGGL(objective_kernel, dim3(blocks), dim3(64), 0, st, sc, o, b, xs, f_out, ngrabs_out);
 }
 

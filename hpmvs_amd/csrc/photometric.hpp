@@ -404,6 +404,20 @@ __device__ __forceinline__ void mean_chains(const float (&vr)[kTex], const float
 #endif
 }
 
+#ifndef HPMVS_SCAN_BATCHES
+#define HPMVS_SCAN_BATCHES 1
+#endif
+// inclusive prefix sum over the 64 lanes (DPP: four shifts inside the rows of 16 lanes, then the rows' totals)
+__device__ __forceinline__ int wave_scan_add(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
 // maximum over the lanes of `v`
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
@@ -462,6 +476,53 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
         // ---- a batch of whole requests whose jobs fit two sets of 64 job lanes (at least one request)
         // When the pending requests need several batches they are cut EVENLY: a batch's pass count is about
         // max(longest request, grabs / 9) + 1, so a last batch with a handful of requests wastes most of its groups.
+#if HPMVS_SCAN_BATCHES
+        // (round 5) the batch, its jobs and every request's first job from ONE prefix sum over the pending requests' image
+        // counts (DPP scan) instead of three scalar loops over the requests (a v_readlane and a dozen scalar instructions
+        // per request and loop: ~4 k cycles per batch with 50 pending requests).  The same batches as the loops form.
+        const bool inrem = (rem >> lane) & 1ull;
+        const int mynp = inrem ? q.nimg : 0;
+        const int incl = wave_scan_add(mynp);
+        const int excl = incl - mynp;                      // jobs of the pending requests before mine
+        const int j_rem = bcast_i(incl, 63);
+        const int n_batches = (j_rem + 64 * kJobSets - 1) / (64 * kJobSets);
+        const int j_target = n_batches > 1 ? (j_rem + n_batches - 1) / n_batches : 64 * kJobSets;
+        const int first = __ffsll((long long)rem) - 1;
+        // the loop's rule: requests are added in lane order until one would overflow the job lanes or the target is reached
+        const unsigned long long stop = __ballot(inrem && lane != first && (incl > 64 * kJobSets || excl >= j_target));
+        const unsigned long long batch = stop ? (rem & ((1ull << (__ffsll((long long)stop) - 1)) - 1ull)) : rem;
+        const int lastb = 63 - __clzll(batch);
+        const int J = bcast_i(incl, lastb);
+        rem &= ~batch;
+        PH_T(t1);
+        // ---- jobs of this lane: job 64 * k + lane of set k -> (request, image index)
+        const int myoff = excl;  // requesting lanes: index of my request's first job
+        int jp[kJobSets], ji[kJobSets];
+        {
+            // job j belongs to the request p with excl[p] <= j < incl[p]: the smallest lane whose inclusive sum exceeds j
+            // (incl is non-decreasing over the lanes: lanes without a pending request add 0) -- a binary search, six
+            // ds_bpermute per job set, the sets' searches interleaved
+            int lo[kJobSets];
+#pragma unroll
+            for (int k = 0; k < kJobSets; k++) lo[k] = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                int v[kJobSets];
+#pragma unroll
+                for (int k = 0; k < kJobSets; k++) v[k] = shfl_i(incl, lo[k] + step - 1);
+#pragma unroll
+                for (int k = 0; k < kJobSets; k++) lo[k] += (v[k] <= lane + 64 * k) ? step : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < kJobSets; k++) {
+                const int j = lane + 64 * k;
+                const int e = shfl_i(excl, lo[k] & 63);
+                const bool has = j < J;
+                jp[k] = has ? lo[k] : -1;
+                ji[k] = has ? j - e : 0;
+            }
+        }
+#else
         int j_rem = 0;
         for (unsigned long long t = rem; t; t &= t - 1ull) j_rem += bcast_i(q.nimg, __ffsll((long long)t) - 1);
         const int n_batches = (j_rem + 64 * kJobSets - 1) / (64 * kJobSets);
@@ -496,6 +557,7 @@ __device__ __forceinline__ void wave_eval_rows(const DevScene& sc, const DevOpti
                 off += np;
             }
         }
+#endif
         // Staged over all job sets in use, so that the loads of one set hide behind those of the others: request data
         // from the requesting lanes (ds_bpermute), image ids, the views' tables, then the arithmetic.
         Prep PS[kJobSets];

@@ -53,11 +53,20 @@ __device__ __forceinline__ int compact_list(int& id, unsigned long long keep) {
     return m;
 }
 
-// minimum over the lanes of `v` (lanes that do not take part pass +inf)
+// minimum over the lanes of `v` (lanes that do not take part pass +inf).  DPP: four shifts inside the rows of 16 lanes, the
+// rows' results handed on with row_bcast, the total read from lane 63 -- seven dependent VALU operations where six
+// __shfl_xor steps are six ds_bpermute round trips (sortImages' greedy selection calls this once per pick).  min is
+// associative and commutative and v_min_f32 treats NaN the same way in either order, so the value is the same.
 __device__ __forceinline__ float wave_min_f32(float v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) v = fminf(v, __shfl_xor(v, d, 64));
-    return v;
+#define HPMVS_MIN_DPP(ctrl, rows) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rows, 0xf, false)))
+    HPMVS_MIN_DPP(0x111, 0xf);  // row_shr:1 (a lane without a left neighbour in its row reads itself)
+    HPMVS_MIN_DPP(0x112, 0xf);
+    HPMVS_MIN_DPP(0x114, 0xf);
+    HPMVS_MIN_DPP(0x118, 0xf);
+    HPMVS_MIN_DPP(0x142, 0xa);  // row_bcast:15 -> rows 1 and 3
+    HPMVS_MIN_DPP(0x143, 0xc);  // row_bcast:31 -> rows 2 and 3
+#undef HPMVS_MIN_DPP
+    return bcast_f(v, 63);
 }
 
 // PatchOptimizer::addImages (PatchOptimizer.cpp:225-258): the test one covisible view has to pass
