@@ -583,6 +583,9 @@ def cpu_leg(out, args, scene, seeds, n_seeds, work, ok, nevals, stage):
     out["cpu_baseline"] = {
         "value": mt / tc, "unit": "patches/s", "cores": cores,
         "kind": "port",
+        "kind_detail": ("port with the reference's own optimiser: photometric path = oracle/hpmvs_oracle.c (C restatement of PatchOptimizer.cpp / "
+                        "Camera / Image / Patch2d), optimiser = the reference's genuine NLopt 2.4.2 BOBYQA compiled from /root/reference (oracle/_ref)"
+                        if which == orc.OPT_REF else "port: photometric path and optimiser both restated (oracle/_ref did not travel)"),
         "sample": f"first {mt} seeds of the same workload, {cores} OpenMP threads (all this container may use), schedule(dynamic,64) over patches like "
                   f"Scene::initPatches; photometric path = oracle/ C restatement, optimiser = "
                   f"{'genuine NLopt 2.4.2 BOBYQA (oracle/_ref)' if which == orc.OPT_REF else 'oracle BOBYQA port'}",

@@ -20,8 +20,14 @@
 //     from the queue, so slots stay busy until the queue drains.
 //   * The image lists (uint16 ids, one 128-byte row per slot) and the parked optimiser states live in the launch
 //     workspace (global memory, L2 resident); nothing per-patch goes through scratch memory.
-//   * The file is compiled twice: 29 slots per wavefront and four state regions per CU (this file), and 58 slots / two
-//     regions for batches that fill the machine many times over (kernel_optimize_big.hip; kernel_launch.hip chooses).
+//   * The file is compiled FOUR times (kernel_launch.hip chooses per launch):
+//       this file                    optimize_kernel           29 slots per wavefront, 4 state regions per CU (all of a state in
+//                                    + optimize_service_kernel  LDS): batches below 480 patches per CU; the open batch behind
+//                                                               single-patch callers (2-wavefront workgroups, 1 region)
+//       kernel_optimize_big.hip      optimize_kernel_big       64 slots (every lane owns a patch), 3 regions of 52 KB, 68 of a
+//                                                               state's 164 float64 (bmat, zmat, vlag, wsuma) in global memory
+//       kernel_optimize_tree.hip,    ..._tree, ..._big_tree    the same two with the opt-in throughput-mode window sums
+//       kernel_optimize_big_tree.hip                            (HPMVS_SUMS=tree; not bit-identical to the oracle)
 #include <hip/hip_runtime.h>
 #include <atomic>
 
@@ -32,18 +38,18 @@
 #ifndef BQ_P
 #define BQ_P 29
 #endif
-// LDS TIME-SHARING.  The float64 optimiser blocks cost about the same per call whether 13, 29 or 58 lanes run them
-// (measured per call: 146 k cycles at 14 lanes, 175 k at 28 before the blocks were rewritten; 109 k at 28 and 123 k at
-// 58 now), so patches per wavefront is THE lever -- and the 160 KB of LDS per CU, at 1364 B of optimiser state per
-// patch, is what bounds it.  But a wavefront needs its optimiser state only inside the optimiser service; during
-// the photometric service (no LDS) it is dead weight.  So the 8 wavefronts of a CU share a POOL of state regions
-// (four of 29 slots, or two of 58): the wavefront that enters the optimiser service takes a free region (LDS
+// LDS TIME-SHARING.  The float64 optimiser blocks cost about the same per call whether 13, 29 or 64 lanes run them
+// (measured per call: 109 k cycles at 29 lanes, 140 k at 64: profiles/r05/phase_profile_c2.txt), so patches per wavefront
+// is THE lever -- and the 160 KB of LDS per CU, at 1364 B of optimiser state per patch, is what bounds it.  But a wavefront
+// needs its optimiser state only inside the optimiser service; during the photometric service (no LDS) it is dead weight.
+// So the 8 wavefronts of a CU share a POOL of state regions (four of 29 slots; three of 64 in the big build, which keeps the
+// states' big matrices in global memory): the wavefront that enters the optimiser service takes a free region (LDS
 // compare-and-swap locks), pages its states in from its parking buffer in global memory with LDS-DMA, runs bq_step
 // kP lanes wide, pages out and releases.  Several times the lanes per optimiser block at the same occupancy.
 #define BQ_SLOTS BQ_P
-// The 58-slot build keeps the optimiser states' big matrices in global memory (kernel_optimize_big.hip sets this): a
-// third state region per CU is worth far more there than the L2 round trips cost (C2: 232 -> 221 ms).  With 29 slots
-// (four regions of 40 KB already) it is the other way round (C1: 24.3 -> 25.5 ms), so this build keeps everything in LDS.
+// The 64-slot build keeps the optimiser states' big matrices in global memory (kernel_optimize_big.hip sets this): a
+// third state region per CU is worth far more there than the L2 round trips cost (C2, round 4: 232 -> 221 ms).  With 29
+// slots (four regions of 40 KB already) it is the other way round (C1: 24.3 -> 25.5 ms), so this build keeps everything in LDS.
 #ifndef HPMVS_STATIC_SLOTS
 #define HPMVS_STATIC_SLOTS (!HPMVS_COLD_GLOBAL)   /* (the cold blocks are laid out per wavefront and slot: 29-slot build only) */
 #endif
@@ -87,9 +93,7 @@
 #define HPMVS_WG_REGIONS 4
 #endif
 #endif
-// This file is compiled four times: as it is (29 slots per wavefront, 4 regions), from kernel_optimize_big.hip (58
-// slots, 2 regions), and twice more with the throughput-mode window sums (kernel_optimize_tree.hip,
-// kernel_optimize_big_tree.hip: photometric.hpp, HPMVS_FAST_SUMS).  The externally visible names of the other copies carry
+// This file is compiled four times (table at the top).  The externally visible names of the other copies carry
 // HPMVS_VARIANT_SUFFIX, and only this copy has the open-batch kernel.
 #ifdef HPMVS_VARIANT_SUFFIX
 #define HPMVS_CAT2(a, b) a##b
