@@ -4,6 +4,7 @@
 // the same bytes, and prints throughput of both forms and the wall latency of a lone optimize() call.
 //   bench_callers <scene dump of tests/test_gpu_cpp_interface.py> <threads>
 #include <omp.h>
+#include <sys/resource.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -87,10 +88,21 @@ int main(int argc, char** argv) {
     for (int i = 0; i < T; i++) pool.emplace_back(options, &scene);
     std::vector<mo3d::Patch3d> B(seeds);
     std::vector<unsigned char> okB(np);
+    // (the caller's thread pool exists before the loop that is timed, as it does in a scheduler that runs round after round:
+    //  creating 256 threads under the container's 16-CPU quota takes longer than the first dozen calls)
+    int started = 0;
+#pragma omp parallel num_threads(T) reduction(+ : started)
+    started += 1;
+    if (started != T) fprintf(stderr, "bench_callers: %d of %d threads\n", started, T);
+    struct rusage ru0, ru1;
+    getrusage(RUSAGE_SELF, &ru0);
     t0 = now();
 #pragma omp parallel for num_threads(T) schedule(dynamic, 1)
     for (int i = 0; i < np; i++) okB[i] = pool[omp_get_thread_num()].optimize(B[i]) ? 1 : 0;
     const double t_calls = now() - t0;
+    getrusage(RUSAGE_SELF, &ru1);
+    const double cpu_user = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + 1e-6 * (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec);
+    const double cpu_sys = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + 1e-6 * (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec);
     int mismatches = 0, good = 0;
     for (int i = 0; i < np; i++) {
         if (okA[i] != okB[i] || !same(A[i], B[i])) mismatches++;
@@ -109,8 +121,8 @@ int main(int argc, char** argv) {
     for (double v : lat) { lmin = v < lmin ? v : lmin; lsum += v; }
     printf("{\"patches\": %d, \"threads\": %d, \"refined\": %d, \"mismatches\": %d, \"batch_s\": %.6f, \"batch_patches_per_s\": %.1f, "
            "\"calls_s\": %.6f, \"calls_patches_per_s\": %.1f, \"calls_over_batch\": %.4f, \"single_call_ms_min\": %.3f, "
-           "\"single_call_ms_mean\": %.3f}\n",
+           "\"single_call_ms_mean\": %.3f, \"loop_cpu_user_s\": %.4f, \"loop_cpu_sys_s\": %.4f}\n",
            np, T, good, mismatches, t_batch, np / t_batch, t_calls, np / t_calls, (np / t_calls) / (np / t_batch), lmin * 1e3,
-           lsum / reps * 1e3);
+           lsum / reps * 1e3, cpu_user, cpu_sys);
     return mismatches ? 1 : 0;
 }

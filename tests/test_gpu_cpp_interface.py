@@ -135,7 +135,10 @@ def test_unchanged_callers_in_a_loop(tiny_scene, tmp_path):
     nproc = os.cpu_count() or 8
     rows = []
     for service, threads in ((1, 2 * nproc), (1, nproc), (1, 64), (1, 8), (1, 1), (0, nproc), (0, 64)):
-        env = dict(os.environ, HPMVS_SERVICE=str(service))
+        # OMP_WAIT_POLICY=passive: the caller's OpenMP threads that run out of iterations must SLEEP -- under the 16-CPU quota of
+        # this pool's containers 256 spinning threads take the CPU time of the ones still working (256 threads: 49-63 k calls/s
+        # with the default policy, 12.7 k with "active", 78-81 k with "passive": profiles/r05/callers_host_side.txt)
+        env = dict(os.environ, HPMVS_SERVICE=str(service), OMP_WAIT_POLICY="passive")
         r = subprocess.run([exe, str(dump), str(threads)], capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 0, r.stdout + r.stderr
         row = json.loads(r.stdout.strip().splitlines()[-1])
@@ -159,14 +162,17 @@ def test_unchanged_callers_in_a_loop(tiny_scene, tmp_path):
     print(out)
     at_nproc = [r for r in rows if r["path"] == "open batch" and r["threads"] == nproc][0]["calls_patches_per_s"]
     assert at_nproc >= 30000.0 or nproc < 128, (at_nproc, "unchanged callers at the box's thread count (VERDICT r2 #3)")
-    assert at_nproc >= 0.5 * cpu_rate, (at_nproc, cpu_rate)
+    # measured in round 5: 78-81 k calls/s at 256 threads against 78-84 k patches/s of the CPU oracle on the 16 usable CPUs (1.0 x
+    # +- 5 %; round 4: 0.8 x); the floor leaves room for the run-to-run spread of both figures
+    assert at_nproc >= 0.8 * cpu_rate, (at_nproc, cpu_rate)
     # with enough callers in flight the unchanged-caller loop beats the CPU path it replaces (a caller waits ~3 ms for its own
     # patch, so the rate is threads / 3 ms until the host side saturates)
     best = max(r["calls_patches_per_s"] for r in rows if r["path"] == "open batch")
     if best < cpu_rate and nproc >= 128:
         # (a throughput figure of 512 host threads under a 16-CPU quota varies by +-15 % from run to run; one more try
         #  before calling it a failure -- both runs stay in the record)
-        r = subprocess.run([exe, str(dump), str(2 * nproc)], capture_output=True, text=True, timeout=900, env=dict(os.environ, HPMVS_SERVICE="1"))
+        r = subprocess.run([exe, str(dump), str(2 * nproc)], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, HPMVS_SERVICE="1", OMP_WAIT_POLICY="passive"))
         assert r.returncode == 0, r.stdout + r.stderr
         row = json.loads(r.stdout.strip().splitlines()[-1])
         row["path"] = "open batch (second run)"
