@@ -801,7 +801,7 @@ PoolLayout pool_layout(size_t n, size_t m) {
 // more, when its room is used up, or when the options change; a second Service object takes over meanwhile.
 // Results are those of any other launch: patches are independent.
 // HPMVS_SERVICE_STATS=1: where the time of a call goes (printed at exit)
-static std::atomic<long long> g_svc_ns_hold{0};
+static std::atomic<long long> g_svc_ns_hold{0}, g_svc_ns_acq{0}, g_svc_slow{0}, g_svc_acq_long{0}, g_svc_ns_acq_long{0};
 static std::atomic<long long> g_svc_calls{0}, g_svc_ns_lock{0}, g_svc_ns_wait{0}, g_svc_ns_total{0}, g_svc_opens{0};
 static bool service_stats() {
     static const bool on = [] {
@@ -809,8 +809,8 @@ static bool service_stats() {
         const bool v = e && e[0] == '1';
         if (v) atexit([] {
             const double c = (double)std::max<long long>(1, g_svc_calls.load());
-            fprintf(stderr, "hpmvs service: %lld calls, %lld launches; per call: submit (lock + copy) %.1f us of which the lock is held %.1f us, wait for the device %.1f us, total %.1f us\n",
-                    g_svc_calls.load(), g_svc_opens.load(), g_svc_ns_lock.load() / c / 1e3, g_svc_ns_hold.load() / c / 1e3, g_svc_ns_wait.load() / c / 1e3, g_svc_ns_total.load() / c / 1e3);
+            fprintf(stderr, "hpmvs service: %lld calls, %lld launches; per call: submit (lock + copy) %.1f us of which the lock is held %.1f us [to get the submission lock %.1f us on average; %lld calls waited > 200 us for it, %.0f us each: behind a thread that was starting a launch; %lld launches started], wait for the device %.1f us, total %.1f us\n",
+                    g_svc_calls.load(), g_svc_opens.load(), g_svc_ns_lock.load() / c / 1e3, g_svc_ns_hold.load() / c / 1e3, g_svc_ns_acq.load() / c / 1e3, g_svc_acq_long.load(), g_svc_ns_acq_long.load() / 1e3 / (double)std::max<long long>(1, g_svc_acq_long.load()), g_svc_slow.load(), g_svc_ns_wait.load() / c / 1e3, g_svc_ns_total.load() / c / 1e3);
         });
         return v;
     }();
@@ -866,15 +866,13 @@ static int service_quiesce(const hpmvs_scene* s) {
         }
     return HPMVS_OK;
 }
-static int service_open(const hpmvs_scene* s, hpmvs_scene::Service& S, const hpmvs_options* o) {  // s->mu and svc_mu held
+// stream, host-mapped record area and launch workspace of one open-batch object (~12 MB pinned + the workspace: ~12 ms)
+static int service_alloc(const hpmvs_scene* s, hpmvs_scene::Service& S) {
     using Service = hpmvs_scene::Service;
-    int rc = service_wait_drained(S);
-    if (rc) return rc;
-    // the owners of the previous generation's patches read their results from S.host: not before they are done
-    while (S.outstanding.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    if (S.st) return HPMVS_OK;
     const size_t in_bytes = sizeof(uint32_t) * kSvcInDwords * (size_t)Service::kCap;
     const size_t out_bytes = sizeof(uint32_t) * kSvcOutDwords * (size_t)Service::kCap;
-    if (!S.st) {
+    {
         S.wgs = s->n_cus;  // one workgroup per CU: batch launches keep three quarters of every CU
         if (const char* e = getenv("HPMVS_SERVICE_WGS")) S.wgs = atoi(e) > 0 ? atoi(e) : S.wgs;  // (experiments)
         S.stage_off = (optimize_workspace_bytes_for(S.wgs) + 255) & ~(size_t)255;
@@ -895,6 +893,15 @@ static int service_open(const hpmvs_scene* s, hpmvs_scene::Service& S, const hpm
         S.ctrl = (volatile int32_t*)(hv + in_bytes + out_bytes);
         S.done = (volatile int32_t*)(hv + in_bytes + out_bytes + 256);
     }
+    return HPMVS_OK;
+}
+static int service_open(const hpmvs_scene* s, hpmvs_scene::Service& S, const hpmvs_options* o) {  // s->mu and svc_mu held
+    using Service = hpmvs_scene::Service;
+    int rc = service_wait_drained(S);
+    if (rc) return rc;
+    // the owners of the previous generation's patches read their results from S.host: not before they are done
+    while (S.outstanding.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    if ((rc = service_alloc(s, S))) return rc;
     memset((void*)S.ctrl, 0, 256 + sizeof(int32_t) * (size_t)Service::kCap);  // ctrl + done flags
     S.opts = *o;
     S.published = 0; S.outstanding.store(0);
@@ -957,11 +964,20 @@ static int optimize_through_service(const hpmvs_scene* s, const hpmvs_options* o
         }
         if (usable(s->svc[0] ? s->svc[s->svc_cur] : nullptr)) break;  // (svc_mu stays locked)
         s->svc_mu.unlock();
+        g_svc_slow++;
         // No open batch that takes this patch: start one -- under the scene lock first (lock order: mu, then svc_mu), so
         // that it is ordered against batch launches: one enqueued before waits on the stream, one enqueued after ends it.
         std::lock_guard<std::recursive_mutex> l1(s->mu);
         std::lock_guard<std::mutex> l2(s->svc_mu);
-        if (!s->svc[0]) { s->svc[0] = new Service(); s->svc[1] = new Service(); }
+        if (!s->svc[0]) {
+            // both objects get their memory NOW: the first caller that finds the current batch closed (full, other options, ended by
+            // a batch launch) would otherwise stall every other caller for the ~12 ms the second object's allocations take
+            // (measured: 257 of the first calls of a 256-thread loop waited 14.7 ms each, profiles/r05/callers_host_side.txt)
+            s->svc[0] = new Service(); s->svc[1] = new Service();
+            int rc0 = service_alloc(s, *s->svc[0]);
+            if (!rc0) rc0 = service_alloc(s, *s->svc[1]);
+            if (rc0) return rc0;
+        }
         Service* cur = s->svc[s->svc_cur];
         if (usable(cur)) continue;  // somebody else did meanwhile
         service_close(*cur);
@@ -974,6 +990,11 @@ static int optimize_through_service(const hpmvs_scene* s, const hpmvs_options* o
     {
         std::lock_guard<std::mutex> lk(s->svc_mu, std::adopt_lock);
         const auto t_held = std::chrono::steady_clock::now();
+        if (stats) {
+            const long long a = std::chrono::duration_cast<std::chrono::nanoseconds>(t_held - t_in).count();
+            g_svc_ns_acq += a;
+            if (a > 200000) { g_svc_acq_long++; g_svc_ns_acq_long += a; }  // (waited behind somebody who was opening a launch)
+        }
         struct Hold { bool on; std::chrono::steady_clock::time_point t0; ~Hold() { if (on) g_svc_ns_hold += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } } hold{stats, t_held};
         Service* cur = s->svc[s->svc_cur];
         S = cur;
