@@ -585,10 +585,11 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
                     const unsigned long long pmask = bcast_u64(res_mask, p);
                     ListResult r;
                     r.nimg = 0; r.fail = 0; r.rgb = U3{0.0f, 0.0f, 0.0f};
-                    if (kind == OPL_ADD) r.nimg = coop_add_images(sc, o, prow, pn, pc, pnrm, pscale);
-                    else if (kind == OPL_F1) r = coop_list_f1(sc, o, prow, pn, pmask, pc, pnrm, pscale);
-                    else if (kind == OPL_F2) r = coop_list_f2(sc, o, prow, pn, pmask, pc, pnrm);
-                    else r = coop_list_f3(sc, o, prow, pn, pmask, pc, pscale, b.max_images, service || b.color != nullptr);
+                    const ListEnv le = list_env(sc, o);
+                    if (kind == OPL_ADD) r.nimg = coop_add_images(le, prow, pn, pc, pnrm, pscale);
+                    else if (kind == OPL_F1) r = coop_list_f1(le, prow, pn, pmask, pc, pnrm, pscale);
+                    else if (kind == OPL_F2) r = coop_list_f2(le, prow, pn, pmask, pc, pnrm);
+                    else { LevelThr lt; for (int k = 0; k < kMaxLevels; k++) lt.t[k] = sc.lvl_thr[k]; r = coop_list_f3(sc.views, lt, o.MIN_IMAGES_PER_PATCH, prow, pn, pmask, pc, pscale, b.max_images, service || b.color != nullptr); }
                     if (lane == p) {
                         res_n = r.nimg; res_fail = r.fail;
                         res_rgb[0] = r.rgb.x; res_rgb[1] = r.rgb.y; res_rgb[2] = r.rgb.z;

@@ -33,6 +33,18 @@ enum Stage {
 
 struct U3 { float x, y, z; };  // a wave-uniform 3-vector
 
+// What the list services need of DevScene / DevOptions, and nothing else: their arguments travel in vector registers (a real
+// call), and the two structures by value were 38 of them at every call site of a kernel that has none to spare.
+struct LevelThr { double t[kMaxLevels]; };   // DevScene::lvl_thr by value
+struct ListEnv {
+    const DevView* views; const int32_t* covis_off; const int32_t* covis;
+    float cos_max_f, sort_thr, MAX_ANGLE, MIN_ANGLE;
+    int32_t MAXLEVEL, MINLEVEL, MIN_IMAGES_PER_PATCH;
+};
+__device__ __forceinline__ ListEnv list_env(const DevScene& sc, const DevOptions& o) {
+    return ListEnv{sc.views, sc.covis_off, sc.covis, o.cos_max_f, o.sort_thr, o.MAX_ANGLE, o.MIN_ANGLE, o.MAXLEVEL, o.MINLEVEL, o.MIN_IMAGES_PER_PATCH};
+}
+
 __device__ __forceinline__ void ray_to_cam(const DevView& V, const float* c, float* ray) {
     // (camera.center_ - pCenter).normalized() on 4-vectors whose w components cancel
     const float d[3] = {V.center[0] - c[0], V.center[1] - c[1], V.center[2] - c[2]};
@@ -70,7 +82,8 @@ __device__ __forceinline__ float wave_min_f32(float v) {
 }
 
 // PatchOptimizer::addImages (PatchOptimizer.cpp:225-258): the test one covisible view has to pass
-__device__ __forceinline__ bool add_images_test(const DevView& V, const DevOptions& o, const float* c, const float* n, float scale) {
+template <class OP>
+__device__ __forceinline__ bool add_images_test(const DevView& V, const OP& o, const float* c, const float* n, float scale) {
     float ray[3];
     ray_to_cam(V, c, ray);
     if (dot3f(ray, n) < o.cos_max_f) return false;
@@ -92,7 +105,7 @@ __device__ __forceinline__ bool add_images_test(const DevView& V, const DevOptio
 
 // addImages on the list at `row` (global workspace, nimg entries): the covisible views of image 0 that are not
 // attached yet and pass the test are appended in covisibility order.  Returns the new count, -1 on overflow.
-__device__ __noinline__ int coop_add_images(DevScene sc, DevOptions o, uint16_t* row, int nimg, U3 c_, U3 n_, float scale) {
+__device__ __noinline__ int coop_add_images(ListEnv sc, uint16_t* row, int nimg, U3 c_, U3 n_, float scale) {
     if (nimg <= 0) return 0;
     const int lane = lane_id();
     const float c[3] = {c_.x, c_.y, c_.z}, n[3] = {n_.x, n_.y, n_.z};
@@ -107,7 +120,7 @@ __device__ __noinline__ int coop_add_images(DevScene sc, DevOptions o, uint16_t*
         bool found = false;
         for (int k = 0; k < existing; k++) found |= (bcast_i(id, k) == cv);
         bool pass = false;
-        if (valid && !found) pass = add_images_test(sc.views[cv], o, c, n, scale);
+        if (valid && !found) pass = add_images_test(sc.views[cv], sc, c, n, scale);
         const unsigned long long m = __ballot(pass);
         const int cnt = __popcll(m);
         if (nimg + cnt > kMaxImages) return -1;
@@ -119,7 +132,8 @@ __device__ __noinline__ int coop_add_images(DevScene sc, DevOptions o, uint16_t*
 
 // PatchOptimizer::sortImages + getAngleWeightedScales (PatchOptimizer.cpp:183-223, 260-284) on the register
 // list; returns the new count (the reference ignores the boolean result).
-__device__ __forceinline__ int coop_sort_images(const DevScene& sc, const DevOptions& o, int& id, int nimg, const float* c,
+template <class SC, class OP>
+__device__ __forceinline__ int coop_sort_images(const SC& sc, const OP& o, int& id, int nimg, const float* c,
                                                 const float* n, float scale) {
     const int lane = lane_id();
     bool cand = false;
@@ -175,7 +189,8 @@ __device__ __forceinline__ int coop_sort_images(const DevScene& sc, const DevOpt
 }
 
 // PatchOptimizer::assureImageAngles (PatchOptimizer.cpp:105-123)
-__device__ __forceinline__ bool coop_assure_image_angles(const DevScene& sc, const DevOptions& o, int id, int nimg, const float* c) {
+template <class SC, class OP>
+__device__ __forceinline__ bool coop_assure_image_angles(const SC& sc, const OP& o, int id, int nimg, const float* c) {
     const int lane = lane_id();
     float rj[3] = {0.0f, 0.0f, 0.0f};
     if (lane < nimg) ray_to_cam(sc.views[id], c, rj);
@@ -192,7 +207,8 @@ __device__ __forceinline__ bool coop_assure_image_angles(const DevScene& sc, con
 }
 
 // PatchOptimizer::filterImagesByAngle (PatchOptimizer.cpp:125-136)
-__device__ __forceinline__ int coop_filter_images_by_angle(const DevScene& sc, const DevOptions& o, int& id, int nimg,
+template <class SC, class OP>
+__device__ __forceinline__ int coop_filter_images_by_angle(const SC& sc, const OP& o, int& id, int nimg,
                                                            const float* c, const float* n) {
     bool keep = false;
     if (lane_id() < nimg) {
@@ -257,8 +273,9 @@ __device__ __forceinline__ void store_list(uint16_t* row, int id, int nimg) {
 }
 
 // filterImagesNCC(alpha1)'s removal -> sortImages -> assureImageAngles (PatchOptimizer.cpp:52-56, 144-151)
-__device__ __noinline__ ListResult coop_list_f1(DevScene sc, DevOptions o, uint16_t* row, int nimg, unsigned long long keep,
+__device__ __noinline__ ListResult coop_list_f1(ListEnv sc, uint16_t* row, int nimg, unsigned long long keep,
                                                U3 c_, U3 n_, float scale) {
+    const ListEnv& o = sc;
     const int lane = lane_id();
     const float c[3] = {c_.x, c_.y, c_.z}, n[3] = {n_.x, n_.y, n_.z};
     ListResult r;
@@ -277,8 +294,9 @@ __device__ __noinline__ ListResult coop_list_f1(DevScene sc, DevOptions o, uint1
 }
 
 // filterImagesNCC(alpha2)'s removal -> filterImagesByAngle -> assureImageAngles (PatchOptimizer.cpp:62-67)
-__device__ __noinline__ ListResult coop_list_f2(DevScene sc, DevOptions o, uint16_t* row, int nimg, unsigned long long keep,
+__device__ __noinline__ ListResult coop_list_f2(ListEnv sc, uint16_t* row, int nimg, unsigned long long keep,
                                                U3 c_, U3 n_) {
+    const ListEnv& o = sc;
     const int lane = lane_id();
     const float c[3] = {c_.x, c_.y, c_.z}, n[3] = {n_.x, n_.y, n_.z};
     ListResult r;
@@ -297,8 +315,11 @@ __device__ __noinline__ ListResult coop_list_f2(DevScene sc, DevOptions o, uint1
 }
 
 // the last filterImagesNCC(alpha2)'s removal (PatchOptimizer.cpp:73) and Scene::getColor(patch) (PatchOptimizer.cpp:100)
-__device__ __noinline__ ListResult coop_list_f3(DevScene sc, DevOptions o, uint16_t* row, int nimg, unsigned long long keep,
+__device__ __noinline__ ListResult coop_list_f3(const DevView* views, LevelThr lt, int min_images, uint16_t* row, int nimg, unsigned long long keep,
                                                U3 c_, float scale, int max_images, int want_colour) {
+    DevScene sc;  // (what colour_at / level_clamped read of it)
+    sc.views = views; sc.covis_off = nullptr; sc.covis = nullptr; sc.n_views = 0;
+    for (int k = 0; k < kMaxLevels; k++) sc.lvl_thr[k] = lt.t[k];
     const int lane = lane_id();
     const float c[3] = {c_.x, c_.y, c_.z};
     ListResult r;
@@ -307,7 +328,7 @@ __device__ __noinline__ ListResult coop_list_f3(DevScene sc, DevOptions o, uint1
     const unsigned long long all = nimg >= 64 ? ~0ull : ((1ull << nimg) - 1ull);
     nimg = compact_list(id, (keep | 1ull) & all);
     r.nimg = nimg;
-    if (nimg < o.MIN_IMAGES_PER_PATCH) { r.fail = 9; return r; }
+    if (nimg < min_images) { r.fail = 9; return r; }
     if (nimg > max_images) { r.fail = 100; return r; }
     store_list(row, id, nimg);
     if (want_colour) r.rgb = coop_patch_colour(sc, id, nimg, c, scale);
