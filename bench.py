@@ -368,10 +368,10 @@ def main(argv=None, backend=None):
     achieved = alg_bytes / (last_ms * 1e-3) / 1e9
 
     # which build of the kernel the library picked for this batch size (kernel_launch.hip: 64 slots per wavefront from
-    # 480 patches per CU upwards, unless HPMVS_SLOTS forces one)
+    # 768 patches per CU upwards, unless HPMVS_SLOTS forces one)
     n_cus_dev = int(torch.cuda.get_device_properties(dev).multi_processor_count) if dev.type == "cuda" else 256
     forced = os.environ.get("HPMVS_SLOTS", "")
-    kernel_name = "optimize_kernel_big" if (forced in ("58", "60", "64") or (forced != "29" and n_seeds >= 480 * n_cus_dev)) else "optimize_kernel"
+    kernel_name = "optimize_kernel_big" if (forced in ("58", "60", "64") or (forced != "29" and n_seeds >= 768 * n_cus_dev)) else "optimize_kernel"
     # HPMVS_SUMS=tree: the opt-in throughput build of the kernel (row sums first; NOT bit-identical to the oracle, and
     # never the default: a line measured in that mode says so here and in config.sums)
     sums_mode = "tree" if os.environ.get("HPMVS_SUMS") == "tree" else "exact"

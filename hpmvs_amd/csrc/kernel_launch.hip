@@ -33,10 +33,13 @@ int optimize_sums_mode() {
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus,
                      hipStream_t st) {
     // HPMVS_SLOTS=29 / 64 forces one build (measurements; 58 and 60, the big build's earlier slot counts, mean it too);
-    // otherwise the 64-slot build from 480 patches per CU (122 880 on an MI355X), where its lower cost per patch has paid
-    // for its longer ramp-down (C2 scene, round 4: 250 k patches 64.4 ms against 66.7, 500 k 119 against 127)
+    // otherwise the 64-slot build from 768 patches per CU (196 608 on an MI355X), where its lower cost per patch has paid
+    // for its longer ramp-down.  Round 5, 29 / 64 slots, same gpurun call (profiles/r05/slots_crossover.txt): C2 scene 100 k
+    // patches 29.6 / 32.3 ms, 150 k 42.4 / 43.2, 250 k 61.3 / 59.6; C1 scene (half the grabs per patch) 150 k 27.5 / 32.4,
+    // 250 k 40.4 / 43.2 -- the crossover moved up from round 4's 480 per CU (the list services and the photometric front end
+    // got cheaper, the optimiser's blocks did not) and depends on the scene; 768 is the C2 scene's.
     static const int forced = [] { const char* e = getenv("HPMVS_SLOTS"); return e ? atoi(e) : 0; }();
-    const bool big = forced == 58 || forced == 60 || forced == 64 || (forced != 29 && (long long)b.n >= 480ll * n_cus);
+    const bool big = forced == 58 || forced == 60 || forced == 64 || (forced != 29 && (long long)b.n >= 768ll * n_cus);
     if (optimize_sums_mode() == 1) {
         if (big) launch_optimize_big_tree(sc, o, b, workspace, n_cus, st);
         else launch_optimize_tree(sc, o, b, workspace, n_cus, st);

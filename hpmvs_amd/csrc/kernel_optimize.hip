@@ -22,7 +22,7 @@
 //     workspace (global memory, L2 resident); nothing per-patch goes through scratch memory.
 //   * The file is compiled FOUR times (kernel_launch.hip chooses per launch):
 //       this file                    optimize_kernel           29 slots per wavefront, 4 state regions per CU (all of a state in
-//                                    + optimize_service_kernel  LDS): batches below 480 patches per CU; the open batch behind
+//                                    + optimize_service_kernel  LDS): batches below 768 patches per CU; the open batch behind
 //                                                               single-patch callers (2-wavefront workgroups, 1 region)
 //       kernel_optimize_big.hip      optimize_kernel_big       64 slots (every lane owns a patch), 3 regions of 52 KB, 68 of a
 //                                                               state's 164 float64 (bmat, zmat, vlag, wsuma) in global memory

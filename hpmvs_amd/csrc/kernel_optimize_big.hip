@@ -6,7 +6,7 @@
 // wsuma/ptsid vector (bmat, zmat, vlag, wsuma: state indices [77, 145), 68 of 164 doubles) live in global memory behind
 // buffer loads (BQ_COLD_GLOBAL, bobyqa3.hpp): 64 x (96 x 8 + 52) B = 52 480 B per region.
 // Measured on the C2 scene (1 MI355X, round 4): 64 slots 213.6 ms against 219.0 ms for 60 slots with wsuma in LDS and
-// 241 ms for the 29-slot build; launch_optimize() in kernel_launch.hip takes this build from 480 patches per CU upwards.
+// 241 ms for the 29-slot build; launch_optimize() in kernel_launch.hip takes this build from 768 patches per CU upwards (round 5; 480 in round 4).
 #ifndef HPMVS_BIG_P
 #define HPMVS_BIG_P 64
 #endif

@@ -358,7 +358,7 @@ def test_batch_order_does_not_matter(tiny_scene, tiny_seeds, gpu_scene):
 def test_both_builds_of_the_kernel_give_the_same_results(tiny_scene, tiny_seeds, gpu_scene, tmp_path):
     """The library holds two builds of the refinement kernel (29 patch slots per wavefront / 4 state regions per CU, all
     optimiser state in LDS; and 64 slots / 3 regions with the optimiser's big matrices and wsuma in global memory behind buffer
-    loads, for batches from 480 patches per CU upwards, kernel_launch.hip).  The same seeds through each build,
+    loads, for batches from 768 patches per CU upwards, kernel_launch.hip).  The same seeds through each build,
     forced with HPMVS_SLOTS in separate processes: every output array is byte-identical, and equal to the in-process
     run (which the other tests compare with the oracle)."""
     import os, subprocess, sys
