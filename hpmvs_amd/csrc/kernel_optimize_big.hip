@@ -20,13 +20,15 @@
 #ifndef HPMVS_WG_REGIONS
 #define HPMVS_WG_REGIONS 3   /* (2 regions of 84 KB without BQ_COLD_GLOBAL: pass -DHPMVS_COLD_GLOBAL=0 -DHPMVS_WG_REGIONS=2 -DHPMVS_BIG_P=58) */
 #endif
-// the lone-request shortcuts of the photometric service (photometric.hpp) stay out of this build: the extra code costs
-// its 64-slot rounds more registers (spills) than its short ramp-down gets back (round 4: C2 +1 %)
+// Of the lone-request shortcuts of the photometric service (photometric.hpp) this build takes the ONE-REQUEST batch (a batch that
+// is one request hands its images to the groups directly: the ramp-down of a launch) but not the split preparation of the job
+// sets: round 5, after the kernel lost ~10 spilled registers elsewhere, C2 202.5 ms against 203.2 and 250 k patches 59.7 ms
+// against 60.4-61.3 with it, 204.7 / 60.1 with both (round 4: either one +1 %, both +17 %; profiles/r05/ab_variants.txt)
 #ifndef HPMVS_SPLIT_PREP
 #define HPMVS_SPLIT_PREP 0
 #endif
 #ifndef HPMVS_SINGLE_FAST
-#define HPMVS_SINGLE_FAST 0
+#define HPMVS_SINGLE_FAST 1
 #endif
 #define HPMVS_VARIANT_SUFFIX _big
 #include "kernel_optimize.hip"
