@@ -227,6 +227,10 @@ def test_many_views_multi_chunk_is_bit_identical():
 @pytest.mark.parametrize("opts", [
     dict(MIN_IMAGES_PER_PATCH=2, NCC_ALPHA_1=0.5, NCC_ALPHA_2=0.6),
     dict(MAX_ANGLE=float(np.float32(45.0 * np.pi / 180.0)), MIN_ANGLE=float(np.float32(5.0 * np.pi / 180.0)), NCC_ALPHA_1=0.3, NCC_ALPHA_2=0.4),
+    # the level options: MAXLEVEL bounds sampleTexture's level (MAXLEVEL - 1) and addImages' (MAXLEVEL - 2); MINLEVEL addImages' floor
+    dict(MAXLEVEL=4),
+    dict(MAXLEVEL=3, NCC_ALPHA_1=0.3),
+    dict(MINLEVEL=1, MAXLEVEL=5, MIN_IMAGES_PER_PATCH=2),
 ])
 def test_non_default_options_are_honoured_identically(opts, tiny_seeds, oracle_scene, gpu_scene):
     """HpmvsOptions fields the path reads (reference include/hpmvs/HpmvsOptions.h:29-58) reach the kernel and
@@ -244,7 +248,7 @@ def test_non_default_options_are_honoured_identically(opts, tiny_seeds, oracle_s
     stage_cpu = np.array([p.stage for p in P])
     assert np.array_equal(stage_cpu, b.stage)
     ok = np.nonzero(b.ok)[0]
-    assert len(ok) >= 20
+    assert len(ok) >= (20 if "MAXLEVEL" not in opts and "MINLEVEL" not in opts else 1), len(ok)
     for k in ok:
         assert np.array_equal(np.array(P[k].center[:], dtype=np.float32), b.center[k])
         assert np.array_equal(np.array(P[k].normal[:], dtype=np.float32), b.normal[k])
