@@ -1312,6 +1312,18 @@ int hpmvs_expand_batch(const hpmvs_scene* s, const hpmvs_options* o, int mode, c
     return HPMVS_OK;
 }
 
+// hpmvs_objective_batch is answered by the refinement kernel's own evaluator driven stand-alone (kernels_basic.hip).  A
+// measurement build (`make LANE=1`, tools/objective_ab.py) also carries the one-lane-per-grab kernel of
+// kernel_objective_lane.hip and runs it with HPMVS_OBJECTIVE_KERNEL=lane: same values, no faster (profiles/r05/lane_per_grab.txt).
+static void launch_objective_chosen(const DevScene& sc, const DevOptions& d, const DevBatch& b, const double* x, double* f,
+                                    int32_t* g, hipStream_t st) {
+#ifdef HPMVS_WITH_LANE_KERNEL
+    const char* e = getenv("HPMVS_OBJECTIVE_KERNEL");
+    if (e && strcmp(e, "lane") == 0) { launch_objective_lane(sc, d, b, x, f, g, st); return; }
+#endif
+    launch_objective(sc, d, b, x, f, g, st);
+}
+
 int hpmvs_objective_batch(const hpmvs_scene* s, const hpmvs_options* o, const hpmvs_patch_batch* b, const double* x,
                           double* f_out, int32_t* ngrabs_out, int on_device, void* stream) {
     int rc = check_batch(s, o, b);
@@ -1326,7 +1338,7 @@ int hpmvs_objective_batch(const hpmvs_scene* s, const hpmvs_options* o, const hp
     const size_t n = (size_t)b->n;
     if (on_device) {
         if ((rc = stage_batch(sg, b, true, false))) return rc;
-        launch_objective(dev_scene(s), d, sg.d, x, f_out, ngrabs_out, st);
+        launch_objective_chosen(dev_scene(s), d, sg.d, x, f_out, ngrabs_out, st);
         HIPCHK(hipGetLastError());
         return HPMVS_OK;
     }
@@ -1340,7 +1352,7 @@ int hpmvs_objective_batch(const hpmvs_scene* s, const hpmvs_options* o, const hp
         if ((rc = stage_in(sg, dg, ngrabs_out, n, false))) return rc;
     }
     if ((rc = stage_flush(sg))) return rc;
-    launch_objective(dev_scene(s), d, sg.d, dx, df, dg, st);
+    launch_objective_chosen(dev_scene(s), d, sg.d, dx, df, dg, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     if ((rc = stage_out(f_out, df, n))) return rc;

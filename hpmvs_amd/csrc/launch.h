@@ -9,6 +9,9 @@ namespace hpmvs {
 void launch_half_resize(const uint8_t* src, int w, int h, uint8_t* dst, hipStream_t st);
 void launch_objective(const DevScene& sc, const DevOptions& o, const DevBatch& b, const double* xs, double* f_out,
                       int32_t* ngrabs_out, hipStream_t st);
+// the same values from the one-lane-per-grab kernel (kernel_objective_lane.hip)
+void launch_objective_lane(const DevScene& sc, const DevOptions& o, const DevBatch& b, const double* xs, double* f_out,
+                           int32_t* ngrabs_out, hipStream_t st);
 void launch_inccs(const DevScene& sc, const DevOptions& o, const DevBatch& b, int ref_idx, int robust, float* out,
                   hipStream_t st);
 void launch_seed_init(const DevScene& sc, const DevOptions& o, int start_level, int n, const double* xyz,
