@@ -39,3 +39,86 @@ def test_random_scene_refines_bit_identically(scene_seed):
         assert list(P[k].images[:P[k].n_images]) == list(b.images[k, :b.n_images[k]]) and P[k].nevals == b.nevals[k], (tag, k)
     print(tag)
     g.close()
+
+
+def _host_acos_is_not_correctly_rounded(scene, seeds, k, v0):
+    """The float64 acos() of patch k's start point (parametersFromCenterNorm, PatchOptimizer.cpp:416-446, for reference image
+    v0): does this host's libm (the oracle's) return something else than the correctly rounded value (the device's, cr_acos.hpp)?
+    DESIGN section 5: the one known source of GPU-vs-oracle differences."""
+    import math
+    import mpmath
+    from hpmvs_amd import api
+    f32 = np.float32
+
+    def nrm(v):
+        v = np.asarray(list(v), f32)
+        n2 = f32(f32(v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])
+        return v / np.sqrt(n2) if n2 > 0 else v
+
+    def dot3(a, c):
+        return f32(f32(a[0] * c[0] + a[1] * c[1]) + a[2] * c[2])
+
+    vw = scene.views[v0]
+    cam = api.camera_from_nvm(vw.f, vw.q, vw.c, vw.width, vw.height)
+    X, Y, Z = nrm(cam.xaxis), nrm(cam.yaxis), nrm(cam.zaxis)
+    n = np.asarray(seeds.normal[k][:3], f32)
+    fy, fz = dot3(Y, n), dot3(Z, n)
+    t = max(-1.0, min(1.0, float(np.arcsin(f32(fy)))))
+    cosb = f32(math.cos(t))
+    if cosb == 0:
+        return False
+    u = max(-1.0, min(1.0, float(f32(-fz) / cosb)))
+    mpmath.mp.prec = 200
+    return math.acos(u) != float(mpmath.acos(mpmath.mpf(u)))
+
+
+@pytest.mark.parametrize("scene_seed", [1101, 1202, 1303, 1404, 1505, 1606, 1707, 1808])
+def test_random_scene_with_random_options(scene_seed):
+    """The same with random HpmvsOptions on top (levels, angle gates, image counts, both NCC thresholds), the device and the oracle
+    given the same values.  A patch may differ ONLY if it is of the one known class: its start point's float64 acos() is one of
+    the arguments for which this host's libm is not correctly rounded (the device rounds to nearest) -- checked per patch, and
+    at most one such patch per scene (the class is ~1 in 3e4 patches)."""
+    import os
+    import torch
+    from hpmvs_amd import api, synth
+    from oracle import oracle as orc
+    if api.device_count() < 1:
+        pytest.fail("no HIP device: -m gpu tests need the MI355X box (no CPU fallback exists)")
+    rng = np.random.default_rng(scene_seed)
+    nv = int(rng.integers(3, 17))
+    W = int(rng.choice([320, 512, 640, 800, 1024]))
+    H = int(W * rng.choice([0.5625, 0.75]))
+    waves = int(rng.integers(6, 28))
+    sl = int(rng.integers(1, 4))
+    n = 400
+    scene = synth.make_scene(nv, W, H, n_waves=waves, device=torch.device("cuda", 0))
+    seeds = synth.make_seeds(scene, n, start_level=sl, max_images=32, max_seed_images=int(rng.integers(3, 12)),
+                             seed=int(rng.integers(1, 1 << 30)), displace=float(rng.uniform(0.1, 1.5)))
+    opts = dict(MAXLEVEL=int(rng.integers(2, 6)), MINLEVEL=int(rng.integers(0, 2)),
+                MAX_ANGLE=float(np.float32(np.deg2rad(rng.choice([45.0, 60.0, 75.0])))),
+                MIN_ANGLE=float(np.float32(np.deg2rad(rng.choice([0.0, 3.0, 10.0])))),
+                MAX_IMAGES_PER_PATCH=int(rng.choice([4, 8, 12, 32])), MIN_IMAGES_PER_PATCH=int(rng.integers(2, 5)),
+                NCC_ALPHA_1=float(rng.choice([0.2, 0.3, 0.4, 0.6])), NCC_ALPHA_2=float(rng.choice([0.3, 0.5, 0.7, 0.9])))
+    og, oc = api.default_options(), orc.default_options()
+    for k, v in opts.items():
+        setattr(og, k, v)
+        setattr(oc, k, v)
+    g = api.Scene(scene)
+    b = api.Batch.from_seeds(seeds)
+    api.optimize_batch(g, b, og)
+    P = orc.patches_from_seeds(seeds)
+    orc.optimize_batch(orc.OracleScene(scene), P, which=orc.best_optimizer(), options=oc, n_threads=min(16, os.cpu_count() or 1))
+    tag = dict(scene_seed=scene_seed, views=nv, size=f"{W}x{H}", start_level=sl, refined=int(b.ok.sum()), **opts)
+    differing = set(np.nonzero(np.array([p.stage for p in P]) != b.stage)[0].tolist())
+    for k in np.nonzero(b.ok)[0]:
+        if not (np.array_equal(np.array(P[k].center[:], dtype=np.float32), b.center[k]) and
+                np.array_equal(np.array(P[k].normal[:], dtype=np.float32), b.normal[k]) and
+                list(P[k].images[:P[k].n_images]) == list(b.images[k, :b.n_images[k]]) and P[k].nevals == b.nevals[k]):
+            differing.add(int(k))
+    assert len(differing) <= 1, (tag, sorted(differing))
+    for k in differing:
+        v0 = int(P[k].images[0]) if P[k].n_images > 0 else int(seeds.images[k, 0])
+        assert _host_acos_is_not_correctly_rounded(scene, seeds, k, v0), \
+            (tag, k, "differs from the oracle and is NOT of the known acos class")
+    print(tag, "differing (known acos class):", sorted(differing))
+    g.close()
