@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <limits.h>
 #include <math.h>
+#include <quadmath.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -40,6 +41,44 @@ void orc_set_dot4_order(int order) { g_dot4_order = order; }
  *   0  true division   <- what the HIP path restates      1  multiply by 1/scalar */
 static int g_vec_div_mode = 0;
 void orc_set_vec_div_mode(int mode) { g_vec_div_mode = mode; }
+/* A third one, for DIAGNOSIS only (tools/full_parity.py): which libm the float64 transcendental calls of the path see.
+ * The reference calls the C library's acos / sin / cos (PatchOptimizer.cpp:405-407, 429-437); glibc 2.35's are < 1 ulp but not
+ * correctly rounded, the device cannot call them, and BOBYQA occasionally amplifies a last-bit difference of the start point
+ * or of a normal.  With these bits the oracle uses what the DEVICE uses, so that a differing patch can be attributed:
+ *   bit 0  acos correctly rounded (libquadmath's acosq rounded to double -- x87's acosl is not enough: for u = 0.9677955508232117 it
+ *          rounds to glibc's value, one ulp above the correctly rounded one; the device: hpmvs_amd/csrc/cr_acos.hpp)
+ *   bit 1  sin / cos of setCenterNorm by the device's Horner series (photometric.hpp sincos_halfpi, same IEEE operations)
+ *   0      the host libm  <- every parity statement of the repo */
+static int g_libm_mode = 0;
+void orc_set_libm_mode(int bits) { g_libm_mode = bits; }
+static double path_acos(double u) { return (g_libm_mode & 1) ? (double)acosq((__float128)u) : acos(u); }
+static void path_sincos(double a, double *s, double *c) {
+    if (!(g_libm_mode & 2)) { *s = sin(a); *c = cos(a); return; }
+    const double z = a * a;
+    double ps = -1.0 / 51090942171709440000.0;
+    ps = ps * z + 1.0 / 121645100408832000.0;
+    ps = ps * z - 1.0 / 355687428096000.0;
+    ps = ps * z + 1.0 / 1307674368000.0;
+    ps = ps * z - 1.0 / 6227020800.0;
+    ps = ps * z + 1.0 / 39916800.0;
+    ps = ps * z - 1.0 / 362880.0;
+    ps = ps * z + 1.0 / 5040.0;
+    ps = ps * z - 1.0 / 120.0;
+    ps = ps * z + 1.0 / 6.0;
+    *s = a - a * z * ps;
+    double pc = 1.0 / 1124000727777607680000.0;
+    pc = pc * z - 1.0 / 2432902008176640000.0;
+    pc = pc * z + 1.0 / 6402373705728000.0;
+    pc = pc * z - 1.0 / 20922789888000.0;
+    pc = pc * z + 1.0 / 87178291200.0;
+    pc = pc * z - 1.0 / 479001600.0;
+    pc = pc * z + 1.0 / 3628800.0;
+    pc = pc * z - 1.0 / 40320.0;
+    pc = pc * z + 1.0 / 720.0;
+    pc = pc * z - 1.0 / 24.0;
+    pc = pc * z + 0.5;
+    *c = 1.0 - z * pc;
+}
 static inline float vdiv(float a, float s, float inv_s) { return g_vec_div_mode ? a * inv_s : a / s; }
 static inline float sum4(float p0, float p1, float p2, float p3) {
     if (g_dot4_order == 1) return (p0 + p2) + (p1 + p3);
@@ -551,9 +590,12 @@ static void set_center_norm(popt *po, const double *x) {
     for (int k = 0; k < 4; k++) po->pCenter[k] = po->refCenter[k] + (x0 * po->refRay[k]) * po->depthScale;
     const float angle1 = (float)(x[1] * po->angleScale);
     const float angle2 = (float)(x[2] * po->angleScale);
-    const float fx = (float)(sin(angle1) * cos(angle2));
-    const float fy = (float)sin(angle2);
-    const float fz = (float)(-cos(angle1) * cos(angle2));
+    double s1, c1, s2, c2;  /* (float arguments promoted to double: the unqualified sin / cos of the reference, see the header) */
+    path_sincos((double)angle1, &s1, &c1);
+    path_sincos((double)angle2, &s2, &c2);
+    const float fx = (float)(s1 * c2);
+    const float fy = (float)s2;
+    const float fz = (float)(-c1 * c2);
     for (int k = 0; k < 3; k++)
         po->pNormal[k] = (po->imgX0[k] * fx + po->imgY0[k] * fy) + po->imgZ0[k] * fz;
     po->pNormal[3] = 0.0f;
@@ -576,7 +618,7 @@ static void parameters_from_center_norm(popt *po, const float *c, const float *n
         const double cosa = -fz / cosb;
         double u = (-1.0 < cosa) ? cosa : -1.0;
         u = (u < 1.0) ? u : 1.0;
-        x[1] = acos(u);
+        x[1] = path_acos(u);
         if (sina < 0.0) x[1] = -x[1];
     }
     x[1] /= po->angleScale;

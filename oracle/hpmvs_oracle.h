@@ -176,6 +176,8 @@ void orc_set_dot4_order(int order);
 /* Eigen's vector / scalar: 0 true division (Eigen >= 3.2, the default and what the HIP path restates), 1 multiply by the
  * reciprocal (Eigen 3.0 / 3.1) */
 void orc_set_vec_div_mode(int mode);
+/* diagnosis only: bit 0 correctly rounded acos, bit 1 the device's sin / cos series (hpmvs_oracle.c) */
+void orc_set_libm_mode(int bits);
 
 #ifdef __cplusplus
 }

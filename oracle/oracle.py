@@ -111,6 +111,11 @@ def default_options() -> Options:
     return o
 
 
+def set_libm_mode(bits: int):
+    """Diagnosis only (tools/full_parity.py): bit 0 = acos correctly rounded, bit 1 = the device's sin / cos series."""
+    lib().orc_set_libm_mode(int(bits))
+
+
 def set_dot4_order(order: int):
     """Evaluation order of Eigen's 4-float reductions in the oracle (0 left-to-right, 1 SSE2, 2 SSE3 haddps)."""
     lib().orc_set_dot4_order(int(order))
@@ -206,6 +211,18 @@ class OracleDepths:
         v, b, f = C.c_int(), C.c_int(), C.c_int()
         lib().orc_depth_gates(self.scene.h, self.h, C.byref(patch), float(margin), int(abs_int), C.byref(v), C.byref(b), C.byref(f))
         return v.value, b.value, f.value
+
+
+def patch_view(arr):
+    """A numpy structured view (no copy) of a ctypes array of Patch: fields by the struct's own offsets."""
+    import numpy as _np
+    fmt = {"center": ("<f4", (4,)), "normal": ("<f4", (4,)), "scale": "<f4", "n_images": "<i4", "images": ("<i4", (MAX_IMAGES,)),
+           "ncc_const": "<f4", "color": ("<f4", (3,)), "fmin": "<f8", "x": ("<f8", (3,)), "nlopt_result": "<i4", "nevals": "<i4",
+           "stage": "<i4", "ngrabs": "<i8", "ngrabs_all": "<i8"}
+    names = [n for n, _ in Patch._fields_]
+    dt = _np.dtype(dict(names=names, formats=[fmt[n] for n in names], offsets=[getattr(Patch, n).offset for n in names],
+                        itemsize=C.sizeof(Patch)))
+    return _np.frombuffer(arr, dtype=dt)
 
 
 def patches_from_seeds(seeds, idx=None):

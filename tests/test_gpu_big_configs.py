@@ -11,6 +11,8 @@ Two kinds of checks per configuration:
     MIN_IMAGES_PER_PATCH images, two launches give identical bytes (the work queue hands patches to wavefronts
     in a different order every time), and the sample's results do not depend on the batch they were part of.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -99,6 +101,11 @@ def _run_config(views, w, h, n, tag):
     with open("gpurun_out/parity_reports.jsonl", "a") as fh:
         fh.write(json.dumps(report) + "\n")
     assert ident.mean() >= 0.999, report   # measured: 1.0 (C1, C4), 0.99997 (C2: one glibc-acos patch)
+    # ... and whatever differs does so for the one known reason: with the oracle's acos() correctly rounded (what the device
+    # computes) the oracle gives the GPU's result for that patch (helpers.equals_gpu_with_correctly_rounded_acos)
+    from helpers import equals_gpu_with_correctly_rounded_acos
+    for k in both[~ident]:
+        assert equals_gpu_with_correctly_rounded_acos(osc, orc.default_options(), seeds, int(k), batch), (report, int(k))
     assert dncc.mean() <= 1e-5, report
     gpu.close()
 
@@ -194,4 +201,34 @@ def test_c4_200_views_4k_1e7_seeds():
     with open("gpurun_out/parity_reports.jsonl", "a") as fh:
         fh.write(json.dumps(report) + "\n")
     assert ident.mean() >= 0.999 and dncc.mean() <= 1e-5, report
+    from helpers import equals_gpu_with_correctly_rounded_acos
+    for k in both[~ident]:  # (none measured) a difference is allowed for the one known reason only
+        assert equals_gpu_with_correctly_rounded_acos(osc, orc.default_options(), seeds, int(k), batch), (report, int(k))
     gpu.close()
+
+
+def test_c2_every_patch_against_the_oracle():
+    """BASELINE configs[2] without sampling: all 1e6 patches through the GPU and through the oracle (genuine NLopt, all granted
+    cores, ~17 s), compared bit for bit -- the failing stage of every patch; centre, normal, colour, image list and evaluation
+    count of every refined one (tools/full_parity.py).  Measured: 49 of 968 000 refined patches differ.  The claim of DESIGN
+    section 5 is tested for EVERY one of them: run again with the oracle's acos() correctly rounded (libquadmath; what the device's
+    cr_acos.hpp returns) the oracle equals the GPU -- nothing differs for any other reason, and no list outgrows the 32-id rows."""
+    import sys
+    from hpmvs_amd import api
+    from oracle import oracle as orc
+    if api.device_count() < 1:
+        pytest.fail("no HIP device: -m gpu tests need the MI355X box (no CPU fallback exists)")
+    assert orc.optimizer_available(orc.OPT_REF), "oracle/_ref (genuine NLopt BOBYQA) did not travel to this box"
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import full_parity
+    rec = full_parity.run(50, 3840, 2160, 1_000_000)
+    brief = {k: v for k, v in rec.items() if k != "differing_patches"}
+    print(brief)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/full_parity_c2.json", "w") as fh:
+        import json
+        fh.write(json.dumps(rec) + "\n")
+    assert rec["refined_by_both"] == rec["refined_gpu"] > 900_000, brief
+    assert rec["differing"] <= 100, brief                      # measured: 49 (0.005 %)
+    assert rec["unexplained"] == 0, (brief, rec["differing_patches"])
+    assert rec["attribution"]["equal_with_correctly_rounded_acos"] == rec["differing"], brief

@@ -41,47 +41,17 @@ def test_random_scene_refines_bit_identically(scene_seed):
     g.close()
 
 
-def _host_acos_is_not_correctly_rounded(scene, seeds, k, v0):
-    """The float64 acos() of patch k's start point (parametersFromCenterNorm, PatchOptimizer.cpp:416-446, for reference image
-    v0): does this host's libm (the oracle's) return something else than the correctly rounded value (the device's, cr_acos.hpp)?
-    DESIGN section 5: the one known source of GPU-vs-oracle differences."""
-    import math
-    import mpmath
-    from hpmvs_amd import api
-    f32 = np.float32
-
-    def nrm(v):
-        v = np.asarray(list(v), f32)
-        n2 = f32(f32(v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])
-        return v / np.sqrt(n2) if n2 > 0 else v
-
-    def dot3(a, c):
-        return f32(f32(a[0] * c[0] + a[1] * c[1]) + a[2] * c[2])
-
-    vw = scene.views[v0]
-    cam = api.camera_from_nvm(vw.f, vw.q, vw.c, vw.width, vw.height)
-    X, Y, Z = nrm(cam.xaxis), nrm(cam.yaxis), nrm(cam.zaxis)
-    n = np.asarray(seeds.normal[k][:3], f32)
-    fy, fz = dot3(Y, n), dot3(Z, n)
-    t = max(-1.0, min(1.0, float(np.arcsin(f32(fy)))))
-    cosb = f32(math.cos(t))
-    if cosb == 0:
-        return False
-    u = max(-1.0, min(1.0, float(f32(-fz) / cosb)))
-    mpmath.mp.prec = 200
-    return math.acos(u) != float(mpmath.acos(mpmath.mpf(u)))
-
-
 @pytest.mark.parametrize("scene_seed", [1101, 1202, 1303, 1404, 1505, 1606, 1707, 1808])
 def test_random_scene_with_random_options(scene_seed):
     """The same with random HpmvsOptions on top (levels, angle gates, image counts, both NCC thresholds), the device and the oracle
-    given the same values.  A patch may differ ONLY if it is of the one known class: its start point's float64 acos() is one of
-    the arguments for which this host's libm is not correctly rounded (the device rounds to nearest) -- checked per patch, and
-    at most one such patch per scene (the class is ~1 in 3e4 patches)."""
+    given the same values.  A patch may differ ONLY for the one known reason: run again with the oracle's acos() correctly rounded
+    (the device rounds to nearest, this host's libm does not always) the oracle must give the GPU's result bit for bit -- checked
+    per differing patch, and at most one such patch per scene (the class is ~1 in 2e4 refined patches)."""
     import os
     import torch
     from hpmvs_amd import api, synth
     from oracle import oracle as orc
+    from helpers import equals_gpu_with_correctly_rounded_acos
     if api.device_count() < 1:
         pytest.fail("no HIP device: -m gpu tests need the MI355X box (no CPU fallback exists)")
     rng = np.random.default_rng(scene_seed)
@@ -116,9 +86,9 @@ def test_random_scene_with_random_options(scene_seed):
                 list(P[k].images[:P[k].n_images]) == list(b.images[k, :b.n_images[k]]) and P[k].nevals == b.nevals[k]):
             differing.add(int(k))
     assert len(differing) <= 1, (tag, sorted(differing))
+    osc = orc.OracleScene(scene)
     for k in differing:
-        v0 = int(P[k].images[0]) if P[k].n_images > 0 else int(seeds.images[k, 0])
-        assert _host_acos_is_not_correctly_rounded(scene, seeds, k, v0), \
-            (tag, k, "differs from the oracle and is NOT of the known acos class")
+        assert equals_gpu_with_correctly_rounded_acos(osc, oc, seeds, k, b), \
+            (tag, k, "differs from the oracle and does NOT equal it with a correctly rounded acos")
     print(tag, "differing (known acos class):", sorted(differing))
     g.close()
