@@ -52,6 +52,7 @@ void orc_set_vec_div_mode(int mode) { g_vec_div_mode = mode; }
 static int g_libm_mode = 0;
 void orc_set_libm_mode(int bits) { g_libm_mode = bits; }
 static double path_acos(double u) { return (g_libm_mode & 1) ? (double)acosq((__float128)u) : acos(u); }
+double orc_acos_in_mode(double u, int bits) { const int keep = g_libm_mode; g_libm_mode = bits; const double r = path_acos(u); g_libm_mode = keep; return r; }  /* (tests) */
 static void path_sincos(double a, double *s, double *c) {
     if (!(g_libm_mode & 2)) { *s = sin(a); *c = cos(a); return; }
     const double z = a * a;

@@ -178,6 +178,7 @@ void orc_set_dot4_order(int order);
 void orc_set_vec_div_mode(int mode);
 /* diagnosis only: bit 0 correctly rounded acos, bit 1 the device's sin / cos series (hpmvs_oracle.c) */
 void orc_set_libm_mode(int bits);
+double orc_acos_in_mode(double u, int bits); /* the acos() the path would call under `bits` (tests) */
 
 #ifdef __cplusplus
 }

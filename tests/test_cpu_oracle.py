@@ -649,3 +649,26 @@ def test_prelim_points_all_at_once_equal_the_sequential_ones():
         assert same == 6, (x0, lb, ub, same)
         checked += 1
     assert checked >= 400
+
+
+def test_diagnosis_switch_rounds_acos_correctly():
+    """orc_set_libm_mode bit 0 (tools/full_parity.py, the attribution step of the GPU parity tests): acos() by libquadmath rounded
+    to double must be the correctly rounded value (mpmath at 200 bits) -- also where this host's libm is not, e.g. the start
+    point argument that tests/test_gpu_random_scenes.py keeps meeting -- and mode 0 must be the host libm itself."""
+    import ctypes as C
+    import mpmath
+    from oracle import oracle as orc
+    L = orc.lib()
+    L.orc_acos_in_mode.restype = C.c_double
+    L.orc_acos_in_mode.argtypes = [C.c_double, C.c_int]
+    mpmath.mp.prec = 200
+    rng = np.random.default_rng(3)
+    us = [0.9677955508232117] + list(np.cos(rng.uniform(0.0, math.pi, 20000))) + [1.0, -1.0, 0.0, 0.5, -0.5]
+    host_off = 0
+    for u in us:
+        u = float(u)
+        cr = float(mpmath.acos(mpmath.mpf(u)))
+        assert L.orc_acos_in_mode(u, 1) == cr, u
+        assert L.orc_acos_in_mode(u, 0) == math.acos(u), u
+        host_off += math.acos(u) != cr
+    print("host libm acos differs from the correctly rounded value for", host_off, "of", len(us), "arguments")
