@@ -233,8 +233,8 @@ def main(argv=None, backend=None):
     plan = Plan(workload, args.scaling, args.patches, rank, world)
     views, W, H, start_level, scaling = plan.views, plan.W, plan.H, plan.start_level, plan.scaling
     n_total, n_seeds, n_job, lo, hi, counts = plan.n_total, plan.n_seeds, plan.n_job, plan.lo, plan.hi, plan.counts
-    # rows of the batch's image lists: 32 ids hold every list of the BASELINE configs (checked on EVERY patch of C1, C2 and 1e6
-    # of the C4 scene: no list overflows, tools/full_parity.py); at START_LEVEL 1 a patch of the 50-view scene attaches up to
+    # rows of the batch's image lists: 32 ids hold every list of the BASELINE configs (checked on EVERY patch of C1, C2 and C4
+    # at its 1e7 seeds: no list overflows, tools/full_parity.py); at START_LEVEL 1 a patch of the 50-view scene attaches up to
     # ~50 images and 9 % of the patches would end at stage 100 (list overflow) instead of being refined, so the stress
     # workload gets the C ABI's maximum of 64 (the reference's lists are unbounded vectors)
     max_images = 64 if start_level < 4 else 32
