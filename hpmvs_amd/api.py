@@ -274,10 +274,12 @@ def optimize_batch(scene: Scene, batch: Batch, options: Options | None = None) -
     return batch
 
 
-def init_patches_batch(scene: Scene, xyz, meas_off, meas_img, start_level=4, max_images=32,
+def init_patches_batch(scene: Scene, xyz, meas_off, meas_img, start_level=4, max_images=MAX_IMAGES,
                        options: Options | None = None) -> Batch:
     """Scene::initPatches seed loop on the GPU (reference Scene.cpp:112-178): seeds built on device, refined,
-    drift-gated.  Returns the batch (seed patches, refined where ok)."""
+    drift-gated.  Returns the batch (seed patches, refined where ok).  max_images: the rows of the batch's image lists; a point
+    with more measurements than that ends at stage 100 (the C ABI's maximum, 64, by default: in a 50-view scene most NVM points
+    have more than 32)."""
     o = options or default_options()
     xyz = np.ascontiguousarray(xyz, dtype=np.float64)
     off = np.ascontiguousarray(meas_off, dtype=np.int32)
