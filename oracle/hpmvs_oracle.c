@@ -658,11 +658,11 @@ static double static_objective_fn(unsigned n, const double *x, double *grad, voi
 
 typedef int (*ref_bobyqa_fn)(int n, int npt, double *x, const double *lb, const double *ub, const double *dx,
                              double xtol_rel, int maxeval, double *minf, int *nevals, orc_obj_fn f, void *data);
-/* oracle/bobyqa_port.cpp */
-int orc_port_bobyqa(int n, int npt, double *x, const double *lb, const double *ub, const double *dx,
-                    double xtol_rel, int maxeval, double *minf, int *nevals, orc_obj_fn f, void *data);
-int orc_port_bobyqa_available(void);
-
+/* tests/native/bobyqa_port.cpp -> tests/native/libbq_port.so: a host build of the PRODUCT's BOBYQA state machine.  It is NOT part
+ * of this library (an oracle holds no product code): it is loaded at run time, and only when a caller names ORC_OPT_PORT. */
+static ref_bobyqa_fn g_port_bobyqa = NULL;
+static int g_port_tried = 0;
+static ref_bobyqa_fn load_port_bobyqa(void);
 static ref_bobyqa_fn g_ref_bobyqa = NULL;
 static int g_ref_tried = 0;
 
@@ -682,9 +682,25 @@ static ref_bobyqa_fn load_ref_bobyqa(void) {
     return g_ref_bobyqa;
 }
 
+static ref_bobyqa_fn load_port_bobyqa(void) {
+    if (g_port_tried) return g_port_bobyqa;
+    g_port_tried = 1;
+    Dl_info info;
+    char path[4096];
+    if (dladdr((void *)&load_port_bobyqa, &info) && info.dli_fname) {
+        snprintf(path, sizeof(path), "%s", info.dli_fname);
+        char *slash = strrchr(path, '/');
+        if (slash) *slash = 0; else snprintf(path, sizeof(path), ".");
+        strncat(path, "/../tests/native/libbq_port.so", sizeof(path) - strlen(path) - 1);
+        void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (h) g_port_bobyqa = (ref_bobyqa_fn)dlsym(h, "orc_port_bobyqa");
+    }
+    return g_port_bobyqa;
+}
+
 int orc_optimizer_available(int which) {
     if (which == ORC_OPT_REF) return load_ref_bobyqa() ? 0 : -1;
-    return orc_port_bobyqa_available() ? 0 : -1;
+    return load_port_bobyqa() ? 0 : -1;
 }
 
 static int is_inf(double x) { return fabs(x) >= HUGE_VAL * 0.99 || isinf(x); } /* api/general.c:30-36 */
@@ -717,7 +733,9 @@ int orc_bobyqa_minimize(int which, int n, orc_obj_fn f, void *data, double *x, c
         if (!fn) { fprintf(stderr, "oracle: oracle/_ref/libref_bobyqa.so missing\n"); return -1; }
         return fn(n, 2 * n + 1, x, lb, ub, dx, xtol_rel, maxeval, minf, nevals, f, data);
     }
-    return orc_port_bobyqa(n, 2 * n + 1, x, lb, ub, dx, xtol_rel, maxeval, minf, nevals, f, data);
+    ref_bobyqa_fn pf = load_port_bobyqa();
+    if (!pf) { fprintf(stderr, "oracle: tests/native/libbq_port.so missing (make -C tests/native)\n"); return -1; }
+    return pf(n, 2 * n + 1, x, lb, ub, dx, xtol_rel, maxeval, minf, nevals, f, data);
 }
 
 /* PatchOptimizer::optimizePatch, src/hpmvs/PatchOptimizer.cpp:322-382 */

@@ -13,7 +13,7 @@
  * unpinned" for that part, anchored only by analytic known-answer tests.  The
  * optimiser part is pinned: it runs the reference's genuine vendored NLopt
  * 2.4.2 BOBYQA, compiled in place from /root/reference into oracle/_ref/
- * (see oracle/Makefile); the fallback (oracle/bobyqa_port.cpp) is checked against
+ * (see oracle/Makefile); the port (tests/native/bobyqa_port.cpp, its own library) is checked against
  * it evaluation by evaluation.
  *
  * Every function cites the reference file:line it follows (paths relative to

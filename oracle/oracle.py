@@ -134,7 +134,7 @@ def optimizer_available(which: int) -> bool:
 def best_optimizer(allow_port: bool = False) -> int:
     """The optimiser every parity check runs: the reference's GENUINE NLopt BOBYQA (oracle/_ref).
 
-    There is no silent downgrade: oracle/bobyqa_port.cpp is a host build of the PRODUCT's own
+    There is no silent downgrade: tests/native/bobyqa_port.cpp (libbq_port.so, loaded at run time, never linked into liboracle.so) is a host build of the PRODUCT's own
     bobyqa3.hpp, so comparing the HIP path against it proves nothing about the reference.  If
     oracle/_ref did not travel this raises; the port is only used where a caller asks for it by
     name (`which=OPT_PORT`, or allow_port=True / HPMVS_ORACLE_ALLOW_PORT=1 for timing-only use)."""

@@ -1,5 +1,6 @@
 /*
- * bobyqa_port.cpp -- CPU ORACLE fallback optimiser (test infrastructure, NOT product code).
+ * bobyqa_port.cpp -- the optimiser that the oracle's ORC_OPT_PORT names (test infrastructure; built as tests/native/libbq_port.so,
+ * NOT linked into oracle/liboracle.so: the oracle itself holds no product code and loads this at run time).
  *
  * Used only when the reference's genuine NLopt BOBYQA (oracle/_ref/libref_bobyqa.so, built from
  * /root/reference by oracle/Makefile) is not present on the box.  It is a host build of the BOBYQA
@@ -10,9 +11,9 @@
  * it shares its source with the product's optimiser, results obtained with it are labelled
  * "oracle BOBYQA port" wherever they are reported.
  */
-#include "hpmvs_oracle.h"
+#include "../../oracle/hpmvs_oracle.h"
 
-#include "../hpmvs_amd/csrc/bobyqa3.hpp"
+#include "../../hpmvs_amd/csrc/bobyqa3.hpp"
 
 using namespace hpmvs;
 

@@ -31,7 +31,7 @@ def compare(seeds, oracle_scene, gpu_scene, tag):
     batch = api.Batch.from_seeds(seeds)
     api.optimize_batch(gpu_scene, batch)
     P = orc.patches_from_seeds(seeds)
-    orc.optimize_batch(oracle_scene, P, n_threads=8)
+    orc.optimize_batch(oracle_scene, P, which=orc.OPT_REF, n_threads=8)
     n = batch.n
     ok_cpu = np.array([P[k].stage == 0 for k in range(n)])
     ok_gpu = batch.ok.astype(bool)
@@ -478,7 +478,7 @@ np.savez(sys.argv[1], ok=b.ok, center=b.center, normal=b.normal, fmin=b.fmin, ne
         outs[mode] = np.load(f)
     n = len(tiny_seeds.scale)
     P = orc.patches_from_seeds(tiny_seeds)
-    orc.optimize_batch(oracle_scene, P, n_threads=8)
+    orc.optimize_batch(oracle_scene, P, which=orc.OPT_REF, n_threads=8)
     ok_cpu = np.array([p.stage == 0 for p in P])
     ex, tr = outs["exact"], outs["tree"]
     # exact: the oracle's decisions and bits
