@@ -307,7 +307,18 @@ def main(argv=None, backend=None):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         rows = [[float(v) for v in t.cpu()] for t in every]
-        per_rank = {"patches": [int(r[3]) for r in rows], "kernel_ms": [r[1] for r in rows],
+        # what the collective layer itself saw (the first SCALE record checks itself: ranks, one device per rank, the
+        # gathered round has every rank's shard)
+        dev_idx = int(dev.index or 0) if dev.type == "cuda" else -1
+        seen = torch.tensor([float(rank), float(dev_idx)], dtype=torch.float64, device=dev)
+        seen_all = [torch.zeros_like(seen) for _ in range(world)]
+        dist.all_gather(seen_all, seen)
+        collective = {"backend": dist.get_backend(), "world_size_seen": int(dist.get_world_size()),
+                      "ranks_seen": [int(t[0].item()) for t in seen_all], "device_of_rank": [int(t[1].item()) for t in seen_all],
+                      "gathered_records": int(gathered.shape[0]) if gathered is not None else 0,
+                      "gathered_equals_job": bool(gathered is not None and int(gathered.shape[0]) == (n_total if scaling == "strong" else world * n_total)),
+                      "shards_sum_to_job": bool(sum(int(r[3]) for r in rows) == n_job)}
+        per_rank = {"patches": [int(r[3]) for r in rows], "kernel_ms": [r[1] for r in rows], "collective": collective,
                     "pack_plus_allgather_ms": [r[2] for r in rows], "ms_per_step": [1e3 * r[0] / args.steps for r in rows],
                     "what": "per rank: its shard, HIP-event time of its refinement kernel, of hpmvs_pack_records + the "
                             "all-gather behind it, and its wall time per step between the barriers"}

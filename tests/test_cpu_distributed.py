@@ -252,3 +252,30 @@ def test_bench_main_two_ranks_on_gloo_equals_one_rank():
     assert gc["records"] == 16 and gc["gathered_total"] == 31 and gc["bytes_equal_python_packer"] and gc["fields_equal_results"]
     u = dd.unpack_records(torch.from_numpy(g0))
     assert u["ok"].sum() >= 10
+
+
+def test_bench_main_eight_ranks_on_gloo_ragged_shards_in_tile_order():
+    """bench.main() at world size 8 (what the driver's SCALE run launches), strong scaling of a 61-seed round: shards of
+    8, 8, 8, 8, 8, 7, 7, 7 seeds, each rank's shard bucket-sorted by (reference image, tile) before it is refined
+    (`--order tiles`).  Every rank ends with the same gathered round; it holds exactly the records of the
+    one-rank round (the tile order permutes them inside a shard, so the comparison is on the sorted records); the line's
+    `per_rank.collective` block checks itself (8 ranks seen, the shards add up to the job)."""
+    from hpmvs_amd import distributed as dd
+    argv = ["--gpus", "8", "--workload", "c0_tiny", "--scaling", "strong", "--patches", "61", "--steps", "1", "--warmup", "0",
+            "--no-cpu", "--check-gather", "--order", "tiles"]
+    eight = _run_bench(8, argv)
+    one = _run_bench(1, ["--gpus", "1"] + argv[2:-2])     # the one-rank round in the seeds' own order
+    g0 = eight[0][1]
+    assert g0.shape == (61, dd.RECORD_BYTES)
+    for r in range(1, 8):
+        assert np.array_equal(eight[r][1], g0), f"rank {r} gathered a different round"
+    as_rows = lambda g: sorted(bytes(row) for row in g)
+    assert as_rows(g0) == as_rows(one[0][1])
+    out0 = eight[0][0]
+    pr = out0["per_rank"]
+    assert pr["patches"] == [8, 8, 8, 8, 8, 7, 7, 7] and len(pr["kernel_ms"]) == 8
+    co = pr["collective"]
+    assert co["backend"] == "gloo" and co["world_size_seen"] == 8 and co["ranks_seen"] == list(range(8))
+    assert co["gathered_records"] == 61 and co["gathered_equals_job"] and co["shards_sum_to_job"]
+    assert out0["n_gpus"] == 8 and out0["config"]["order"] == "tiles" and out0["config"]["seeds_per_step_all_gpus"] == 61
+    assert all(abs(eight[r][0]["ms_per_step"] - out0["ms_per_step"]) < 1e-9 for r in range(8))   # MAX over ranks, on every rank

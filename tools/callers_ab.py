@@ -15,8 +15,8 @@ for name in ["product"] + sys.argv[1:]:
     env = dict(os.environ, HPMVS_SERVICE="1")
     if name != "product":
         env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "tools", "ab", name) + ":" + env.get("LD_LIBRARY_PATH", "")
-    for rep in range(2):
-        for threads in (512, 256, 64, 8, 1):
+    for rep in range(int(os.environ.get('CALLERS_REPS', '2'))):
+        for threads in [int(t) for t in os.environ.get('CALLERS_THREADS', '512,256,64,8,1').split(',')]:
             r = subprocess.run([exe, dump, str(threads)], capture_output=True, text=True, timeout=900, env=env)
             if r.returncode != 0:
                 print(name, threads, "FAILED", r.stderr[-300:]); continue

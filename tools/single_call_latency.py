@@ -2,6 +2,7 @@
 import sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 from hpmvs_amd import api, synth
+if len(sys.argv) > 1: api.LIB_PATH = sys.argv[1]   # a variant build (tools/ab/<name>/libhpmvs_amd.so)
 dev = torch.device('cuda', 0)
 scene = synth.make_scene(12, 1920, 1080, n_waves=24, device=dev)
 g = api.Scene(scene)
