@@ -53,7 +53,7 @@ EXPORTS = [
     "hpmvs_expand_batch", "hpmvs_expand_directions", "hpmvs_selftest_bobyqa",
     "hpmvs_pack_records", "hpmvs_unpack_records", "hpmvs_allgather_records",
     "hpmvs_scene_depth_reset", "hpmvs_scene_depth_set_level", "hpmvs_scene_depth_get_level",
-    "hpmvs_set_depths_batch", "hpmvs_depth_gates_batch",
+    "hpmvs_set_depths_batch", "hpmvs_depth_gates_batch", "hpmvs_depth_footprints_batch",
     "hpmvs_host_alloc", "hpmvs_host_free", "hpmvs_last_staging",
 ]
 
@@ -104,6 +104,8 @@ def lib():
     L.hpmvs_scene_depth_get_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
                                               C.POINTER(C.c_int)]
     L.hpmvs_set_depths_batch.argtypes = [C.c_void_p, C.POINTER(PatchBatch), C.c_int, C.c_void_p]
+    L.hpmvs_depth_footprints_batch.argtypes = [C.c_void_p, C.POINTER(PatchBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int, C.c_void_p]
     L.hpmvs_depth_gates_batch.argtypes = [C.c_void_p, C.POINTER(PatchBatch), C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_void_p]
     _lib = L
@@ -370,6 +372,17 @@ def depth_gates_batch(scene: Scene, batch: Batch, margin=1.0, abs_int=0):
     _chk(lib().hpmvs_depth_gates_batch(scene.h, C.byref(b), float(margin), int(abs_int), v.ctypes.data, k.ctypes.data,
                                        f.ctypes.data, 0, None))
     return v, k, f
+
+
+def depth_footprints_batch(scene: Scene, batch: Batch):
+    """The depth-map cells the gates of every patch READ and the cells setDepths would WRITE for it (integers; layouts in
+    include/hpmvs_amd.h): (writes [n, M, 4], frees [n, M, 4], attached [n, M, 3], view_block [n, n_views, 3])."""
+    b = batch.c_struct()
+    n, M, V = batch.n, batch.max_images, scene.n_views
+    wr = np.zeros((n, M, 4), np.int32); fr = np.zeros((n, M, 4), np.int32)
+    at = np.zeros((n, M, 3), np.int32); vb = np.zeros((n, V, 3), np.int32)
+    _chk(lib().hpmvs_depth_footprints_batch(scene.h, C.byref(b), wr.ctypes.data, fr.ctypes.data, at.ctypes.data, vb.ctypes.data, 0, None))
+    return wr, fr, at, vb
 
 
 def build_pyramid(img: np.ndarray, device: int = 0) -> np.ndarray:

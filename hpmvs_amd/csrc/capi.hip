@@ -1522,6 +1522,42 @@ int hpmvs_depth_gates_batch(const hpmvs_scene* s, const hpmvs_patch_batch* b, fl
     return stage_out(n_free, df, n);
 }
 
+int hpmvs_depth_footprints_batch(const hpmvs_scene* s, const hpmvs_patch_batch* b, int32_t* writes, int32_t* frees,
+                                 int32_t* attached, int32_t* view_block, int on_device, void* stream) {
+    int rc = check_depth_batch(s, b, "depth_footprints_batch");
+    if (rc) return rc;
+    if (!writes && !frees && !attached && !view_block) return fail(HPMVS_ERR_ARG, "depth_footprints_batch: no output array");
+    if (b->n == 0) return HPMVS_OK;
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    Staged sg;
+    sg.scene = s;
+    if (on_device) {
+        if ((rc = stage_batch(sg, b, true, false))) return rc;
+        launch_depth_footprints(dev_scene(s), s->ddepth, sg.d, writes, frees, attached, view_block, st);
+        HIPCHK(hipGetLastError());
+        return HPMVS_OK;
+    }
+    const size_t n = (size_t)b->n, M = (size_t)b->max_images, V = (size_t)s->n_views;
+    int32_t *dw = nullptr, *df = nullptr, *da = nullptr, *dv = nullptr;
+    {
+        Exclusive ex(s);  // the allocations of a host-staged call (see Exclusive)
+        if ((rc = stage_batch(sg, b, false, false))) return rc;
+        if ((rc = stage_in(sg, dw, writes, n * M * 4, false))) return rc;
+        if ((rc = stage_in(sg, df, frees, n * M * 4, false))) return rc;
+        if ((rc = stage_in(sg, da, attached, n * M * 3, false))) return rc;
+        if ((rc = stage_in(sg, dv, view_block, n * V * 3, false))) return rc;
+    }
+    if ((rc = stage_flush(sg))) return rc;
+    launch_depth_footprints(dev_scene(s), s->ddepth, sg.d, dw, df, da, dv, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    if ((rc = stage_out(writes, dw, n * M * 4))) return rc;
+    if ((rc = stage_out(frees, df, n * M * 4))) return rc;
+    if ((rc = stage_out(attached, da, n * M * 3))) return rc;
+    return stage_out(view_block, dv, n * V * 3);
+}
+
 // debug: phase counters of the last optimize launch (only meaningful in -DHPMVS_PROFILE_PHASES builds)
 int hpmvs_debug_counters(const hpmvs_scene* s, unsigned long long* out4) {
     if (!s || !out4) return fail(HPMVS_ERR_ARG, "debug_counters: null argument");

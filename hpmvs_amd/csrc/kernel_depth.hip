@@ -65,13 +65,50 @@ __device__ __forceinline__ float full_depth(const DevDepthView& D, int n_levels,
     }
     return depth;
 }
+// the 3x3 level-0 pixel block Scene::depthTest reads (Scene.cpp:538-550): its top-left pixel and the patch's depth there
+__device__ __forceinline__ void depth_test_block(const DevView& V, const float* c, int& ix0, int& iy0, float& depth) {
+    float m[3];
+    mult_level(V, c, 0, m);
+    depth = m[2];
+    ix0 = (int)((double)(m[0] / m[2]) + 0.5) - 1; iy0 = (int)((double)(m[1] / m[2]) + 0.5) - 1;
+}
+// the one cell Scene::pixelFreeTest reads (Scene.cpp:590-604); false: it returns before reading a cell
+__device__ __forceinline__ bool pixel_free_cell(const DevView& V, const DevDepthView& D, const float* c, float scale, int& level, int& x, int& y) {
+    level = level_rounded(V, c, scale);
+    if (!(level >= 0 && level < V.n_levels)) return false;
+    float r[3];
+    project_level(V, c, level, r);
+    const int ix = (int)((double)(r[0] / r[2]) + 0.5), iy = (int)((double)(r[1] / r[2]) + 0.5);
+    if (ix < 0 || ix >= V.w[level] || iy < 0 || iy >= V.h[level]) return false;
+    x = sub_index(ix); y = sub_index(iy);
+    return !(x < 0 || x >= D.cols[level] || y < 0 || y >= D.rows[level]);
+}
+// the one cell Scene::setDepths writes for an attached image (Scene.cpp:353-372) and the depth it offers; false: none
+__device__ __forceinline__ bool set_depths_cell(const DevScene& sc, const DevView& V, const DevDepthView& D, const float* c, float scale,
+                                                int& level, int& x, int& y, float& d) {
+    const float d0 = c[0] - V.center[0], d1 = c[1] - V.center[1], d2 = c[2] - V.center[2];
+    level = level_clamped(sc, scale, V.fsum, sqrtf((d0 * d0 + d1 * d1) + d2 * d2), V.n_levels - 1);
+    float m[3];
+    mult_level(V, c, level, m);
+    x = sub_index((int)((double)(m[0] / m[2]) + 0.5)); y = sub_index((int)((double)(m[1] / m[2]) + 0.5));
+    d = m[2];
+    if (x < 0 || x >= D.cols[level] || y < 0 || y >= D.rows[level]) return false;
+    return m[2] >= 0.0f;  // (the reference CHECK-fails on a negative depth)
+}
+// does Scene::viewBlockTest look at this view at all (Scene.cpp:611-621)?
+__device__ __forceinline__ bool view_block_visible(const DevView& V, const float* c, float scale) {
+    const int level = level_rounded(V, c, scale);
+    if (level < 0 || level > V.n_levels - 1) return false;
+    float r[3];
+    project_level(V, c, level, r);
+    return !(r[0] < 0 || r[0] > (float)V.w[level] || r[1] < 0 || r[1] > (float)V.h[level]);
+}
 // Scene::depthTest(patch, image, margin, neighbours = true, viewBlock) (Scene.cpp:531-580)
 __device__ __forceinline__ bool depth_test(const DevView& V, const DevDepthView& D, const float* c, const float* n,
                                            float scale, float margin, bool view_block, int abs_int) {
-    float m[3];
-    mult_level(V, c, 0, m);
-    const float depth = m[2];
-    const int ix0 = (int)((double)(m[0] / m[2]) + 0.5) - 1, iy0 = (int)((double)(m[1] / m[2]) + 0.5) - 1;
+    int ix0, iy0;
+    float depth;
+    depth_test_block(V, c, ix0, iy0, depth);
     // patch-constant part of the pixel test
     float ray[3];
     const float d[3] = {c[0] - V.center[0], c[1] - V.center[1], c[2] - V.center[2]};
@@ -113,16 +150,12 @@ __global__ void __launch_bounds__(256) set_depths_kernel(DevScene sc, const DevD
     const DevView& V = sc.views[idx];
     const float c[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
     const float scale = b.scale[p];
-    const float d0 = c[0] - V.center[0], d1 = c[1] - V.center[1], d2 = c[2] - V.center[2];
-    const int level = level_clamped(sc, scale, V.fsum, sqrtf((d0 * d0 + d1 * d1) + d2 * d2), V.n_levels - 1);
-    float m[3];
-    mult_level(V, c, level, m);
-    const int x = sub_index((int)((double)(m[0] / m[2]) + 0.5)), y = sub_index((int)((double)(m[1] / m[2]) + 0.5));
     const DevDepthView& D = depths[idx];
-    if (x < 0 || x >= D.cols[level] || y < 0 || y >= D.rows[level]) return;
-    if (!(m[2] >= 0.0f)) return;  // (the reference CHECK-fails on a negative depth)
+    int level, x, y;
+    float d;
+    if (!set_depths_cell(sc, V, D, c, scale, level, x, y, d)) return;
     // `if (d < old) old = d` for non-negative floats = unsigned minimum of the bit patterns
-    atomicMin((unsigned int*)&D.d[level][y + (size_t)x * D.rows[level]], __float_as_uint(m[2]));
+    atomicMin((unsigned int*)&D.d[level][y + (size_t)x * D.rows[level]], __float_as_uint(d));
 }
 
 // depthTests / viewBlockTest / pixelFreeTests: one wavefront per patch, one lane per view
@@ -151,9 +184,9 @@ __global__ void __launch_bounds__(256) depth_gates_kernel(DevScene sc, const Dev
                     const int ix = (int)((double)(r[0] / r[2]) + 0.5), iy = (int)((double)(r[1] / r[2]) + 0.5);
                     if (!(ix < 0 || ix >= V.w[level] || iy < 0 || iy >= V.h[level])) {
                         const DevDepthView& D = depths[idx];
-                        const int x = sub_index(ix), y = sub_index(iy);
-                        float dv = kMaxDepth;
-                        if (!(x < 0 || x >= D.cols[level] || y < 0 || y >= D.rows[level])) dv = D.d[level][y + (size_t)x * D.rows[level]];
+                        int fl, x, y;
+                        float dv = kMaxDepth;   // (a pixel inside the image whose cell lies outside the map: getDetphAtLevel returns MAX_DEPTH)
+                        if (pixel_free_cell(V, D, c, scale, fl, x, y)) dv = D.d[fl][y + (size_t)x * D.rows[fl]];
                         fre = dv == kMaxDepth;
                     }
                 }
@@ -167,13 +200,7 @@ __global__ void __launch_bounds__(256) depth_gates_kernel(DevScene sc, const Dev
             bool blk = false;
             if (v < sc.n_views) {
                 const DevView& V = sc.views[v];
-                const int level = level_rounded(V, c, scale);
-                if (!(level < 0 || level > V.n_levels - 1)) {
-                    float r[3];
-                    project_level(V, c, level, r);
-                    if (!(r[0] < 0 || r[0] > (float)V.w[level] || r[1] < 0 || r[1] > (float)V.h[level]))
-                        blk = depth_test(V, depths[v], c, n, scale, margin, true, abs_int);
-                }
+                if (view_block_visible(V, c, scale)) blk = depth_test(V, depths[v], c, n, scale, margin, true, abs_int);
             }
             nb += __popcll(__ballot(blk));
         }
@@ -183,6 +210,69 @@ __global__ void __launch_bounds__(256) depth_gates_kernel(DevScene sc, const Dev
             if (n_free) n_free[p] = nf;
         }
     }
+}
+
+// The depth-map cells a candidate's gates READ and the cells setDepths would WRITE for it, as integers -- what a scheduler
+// needs to run the candidates of one priority level in conflict-free waves and still get the reference's sequential
+// result (hpmvs_amd/frontier.py; the gates of candidate i must see the writes of the candidates accepted before it,
+// CellProcessor.cpp:130-142 -> Scene.cpp:351-381).  Computed by the very helpers the gates / setDepths kernels use.
+//   wr [n][M][4]  attached image k: view, level, x, y of the cell setDepths offers its depth to   (view = -1: none)
+//   fr [n][M][4]  attached image k: view, level, x, y of the cell pixelFreeTest reads             (view = -1: none)
+//   at [n][M][3]  attached image k: view, ix0, iy0: top-left of the 3x3 level-0 pixel block depthTests reads through
+//                 getFullDepth (every pyramid level at (pixel / 2) >> level)                      (view = -1: none)
+//   vb [n][V][3]  every view v of the scene: 1 if viewBlockTest looks at it, then ix0, iy0 of its 3x3 block
+__global__ void __launch_bounds__(256) depth_footprints_kernel(DevScene sc, const DevDepthView* __restrict__ depths, DevBatch b,
+                                                               int32_t* __restrict__ wr, int32_t* __restrict__ fr,
+                                                               int32_t* __restrict__ at, int32_t* __restrict__ vb) {
+    const int lane = lane_id();
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int M = b.max_images;
+    for (int p = wave; p < b.n; p += nwaves) {
+        const float c[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
+        const float scale = b.scale[p];
+        int nimg = b.n_images[p];
+        nimg = nimg < 0 ? 0 : (nimg > M ? M : nimg);
+        if (lane < M) {
+            int w4[4] = {-1, 0, 0, 0}, f4[4] = {-1, 0, 0, 0}, a3[3] = {-1, 0, 0};
+            const int idx = lane < nimg ? b.images[(size_t)p * M + lane] : -1;
+            if (idx >= 0 && idx < sc.n_views) {
+                const DevView& V = sc.views[idx];
+                const DevDepthView& D = depths[idx];
+                int level, x, y;
+                float d;
+                if (set_depths_cell(sc, V, D, c, scale, level, x, y, d)) { w4[0] = idx; w4[1] = level; w4[2] = x; w4[3] = y; }
+                if (pixel_free_cell(V, D, c, scale, level, x, y)) { f4[0] = idx; f4[1] = level; f4[2] = x; f4[3] = y; }
+                float depth;
+                depth_test_block(V, c, a3[1], a3[2], depth);
+                a3[0] = idx;
+            }
+            const size_t o = (size_t)p * M + lane;
+            if (wr) for (int k = 0; k < 4; k++) wr[4 * o + k] = w4[k];
+            if (fr) for (int k = 0; k < 4; k++) fr[4 * o + k] = f4[k];
+            if (at) for (int k = 0; k < 3; k++) at[3 * o + k] = a3[k];
+        }
+        if (vb)
+            for (int base = 0; base < sc.n_views; base += 64) {
+                const int v = base + lane;
+                if (v < sc.n_views) {
+                    const DevView& V = sc.views[v];
+                    int ix0 = 0, iy0 = 0;
+                    float depth;
+                    const int seen = view_block_visible(V, c, scale) ? 1 : 0;
+                    if (seen) depth_test_block(V, c, ix0, iy0, depth);
+                    const size_t o = ((size_t)p * sc.n_views + v) * 3;
+                    vb[o] = seen; vb[o + 1] = ix0; vb[o + 2] = iy0;
+                }
+            }
+    }
+}
+
+void launch_depth_footprints(const DevScene& sc, const DevDepthView* depths, const DevBatch& b, int32_t* wr, int32_t* fr, int32_t* at,
+                             int32_t* vb, hipStream_t st) {
+    if (b.n <= 0) return;
+    int blocks = (b.n + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(depth_footprints_kernel, dim3(blocks), dim3(256), 0, st, sc, depths, b, wr, fr, at, vb);
 }
 
 void launch_depth_fill(float* p, size_t n, hipStream_t st) {

@@ -42,6 +42,10 @@ void launch_set_depths(const DevScene& sc, const DevDepthView* depths, const Dev
 void launch_depth_gates(const DevScene& sc, const DevDepthView* depths, const DevBatch& b, float margin, int abs_int,
                         int32_t* n_visible, int32_t* n_blocking, int32_t* n_free, hipStream_t st);
 
+// the cells a batch's gates read and setDepths would write (the scheduler's conflict test; layouts at the kernel)
+void launch_depth_footprints(const DevScene& sc, const DevDepthView* depths, const DevBatch& b, int32_t* wr, int32_t* fr, int32_t* at,
+                             int32_t* vb, hipStream_t st);
+
 // refined-patch records of the multi-GPU exchange (include/hpmvs_amd.h: hpmvs_record, 192 bytes)
 void launch_pack_records(const DevBatch& b, void* records, hipStream_t st);
 void launch_unpack_records(const void* records, int n, const DevBatch& b, hipStream_t st);

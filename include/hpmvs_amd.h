@@ -215,6 +215,17 @@ int hpmvs_scene_depth_get_level(const hpmvs_scene *s, int view, int level, float
 int hpmvs_set_depths_batch(hpmvs_scene *s, const hpmvs_patch_batch *b, int on_device, void *stream);
 int hpmvs_depth_gates_batch(const hpmvs_scene *s, const hpmvs_patch_batch *b, float margin, int abs_int,
                             int32_t *n_visible, int32_t *n_blocking, int32_t *n_free, int on_device, void *stream);
+/* The cells those calls touch, as integers: what a scheduler needs to run one priority level's candidates in conflict-free
+ * waves and still end with the reference's SEQUENTIAL result (CellProcessor.cpp:130-142 reads maps that earlier candidates
+ * of the same level have written, Scene.cpp:351-381; hpmvs_amd/frontier.py is that scheduler, INTEGRATION.md has the recipe).
+ * Any output may be NULL.  Computed with the same device code as the gates / setDepths, so the cells are exact.
+ *   writes     [n][max_images][4]  attached image k: view, level, x, y of the cell setDepths offers its depth to (view -1: none)
+ *   frees      [n][max_images][4]  attached image k: view, level, x, y of the cell pixelFreeTest reads (view -1: none)
+ *   attached   [n][max_images][3]  attached image k: view, ix0, iy0 -- depthTests reads getFullDepth of the 3x3 level-0 pixel
+ *                                  block from (ix0, iy0): cell ((int)(px / 2.0) >> l, (int)(py / 2.0) >> l) of every level l
+ *   view_block [n][n_views][3]     every view v: 1 if viewBlockTest examines it, ix0, iy0 of its 3x3 block (read the same way) */
+int hpmvs_depth_footprints_batch(const hpmvs_scene *s, const hpmvs_patch_batch *b, int32_t *writes, int32_t *frees,
+                                 int32_t *attached, int32_t *view_block, int on_device, void *stream);
 
 /* Host-pointer calls and pinned memory.  An array of a host-pointer call (on_device = 0) that lies in pinned host memory
  * mapped into the GPU's address space -- hipHostMalloc / hipHostRegister, torch's pin_memory(), hpmvs_host_alloc below --

@@ -175,3 +175,85 @@ def test_two_composed_expansion_levels_against_the_sequential_loop(abs_int, tiny
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     with open(os.path.join(root, "gpurun_out", "expand_round_report.jsonl"), "a") as fh:
         fh.write(json.dumps(report) + "\n")
+
+
+# ---- the frontier round with the reference's SEQUENTIAL result (hpmvs_amd/frontier.py: conflict-free waves)
+def _sequential_levels(tag, scene, seeds, oscene, gscene, n_parents, abs_int, levels=2):
+    import time
+    from hpmvs_amd import api, frontier
+    from oracle import oracle as orc
+    b0 = api.Batch.from_seeds(seeds)
+    api.optimize_batch(gscene, b0)
+    keep = np.nonzero(b0.ok)[0][:n_parents]
+    parents = api.Batch(b0.center[keep], b0.normal[keep], b0.scale[keep], b0.n_images[keep], b0.images[keep])
+    width = float(np.float32(2.0 * np.median(parents.scale) / 0.9))
+    occ_gpu = {orc.cell_key(parents.center[k], width) for k in range(parents.n)}
+    occ_cpu = set(occ_gpu)
+    api.depth_reset(gscene)
+    parents.ok[:] = 1
+    api.set_depths_batch(gscene, parents)
+    OD = orc.OracleDepths(oscene)
+    leaves_cpu = _oracle_patches(parents)
+    for k in range(parents.n):
+        OD.set_depths(leaves_cpu[k])
+    leaves_gpu = parents
+    report = {"scene": tag, "abs_int": abs_int, "levels": []}
+    for level in range(levels):
+        n = leaves_gpu.n
+        t0 = time.perf_counter()
+        res = frontier.extend_level(gscene, leaves_gpu, width, occ_gpu, MARGIN, abs_int)
+        t_gpu = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        cand, cnt = orc.extend_round(oscene, OD, leaves_cpu, width, occ_cpu, MARGIN, abs_int, frozen_gates=False)   # the TRUE sequential loop
+        t_cpu = time.perf_counter() - t0
+        st = np.array([cand[t].stage for t in range(6 * n)])
+        # what the plain frontier round (level-start maps) would have done, for the record: on a copy of the state before this level
+        differing = np.nonzero(res.stage != st)[0]
+        assert len(differing) == 0, (tag, level, "fates differ from the sequential loop", differing[:10], res.stage[differing[:10]], st[differing[:10]])
+        assert np.array_equal(res.counts, cnt), (tag, level, np.nonzero((res.counts != cnt).any(axis=1))[0][:10])
+        for t in range(6 * n):
+            if st[t] in (0, 21, 22, 23, 24, 25, 26):
+                assert np.array_equal(np.array(cand[t].center[:], dtype=np.float32), res.candidates.center[t]), (tag, level, t)
+                assert np.array_equal(np.array(cand[t].normal[:], dtype=np.float32), res.candidates.normal[t]), (tag, level, t)
+        assert occ_gpu == occ_cpu, (tag, level)
+        ok, where = _maps_equal(gscene, OD, scene)
+        assert ok, (tag, level, where)
+        acc = [t for t in range(6 * n) if st[t] == 0]
+        assert res.accepted == acc and len(acc) >= 5, (tag, level, len(acc))
+        report["levels"].append({"level": level, "leaves": n, "candidates": 6 * n, "accepted": len(acc), "waves": res.waves,
+                                 "deferred_per_wave": res.deferred_per_wave, "fates_differing_from_sequential_loop": 0,
+                                 "frontier_s": round(t_gpu, 4), "sequential_cpu_oracle_s": round(t_cpu, 4),
+                                 "stage_histogram": {int(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))}})
+        a = np.array(acc)
+        out = res.candidates
+        leaves_gpu = api.Batch(out.center[a], out.normal[a], out.scale[a], out.n_images[a], out.images[a])
+        leaves_cpu = (orc.Patch * len(acc))(*[cand[t] for t in acc])
+    print("sequential frontier:", json.dumps(report))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "expand_round_sequential.jsonl"), "a") as fh:
+        fh.write(json.dumps(report) + "\n")
+    return report
+
+
+@pytest.mark.parametrize("abs_int", [0, 1])
+def test_frontier_waves_equal_the_sequential_loop_on_configs0(abs_int, tiny_scene, tiny_seeds, oracle_scene, gpu_scene):
+    """BASELINE configs[0]: two consecutive priority levels, ZERO candidates whose fate differs from CellProcessor::extend run
+    leaf by leaf (the plain frontier round of the test above differs in 27 of 360 on the first level)."""
+    rep = _sequential_levels("configs0_3v_640x480", tiny_scene, tiny_seeds, oracle_scene, gpu_scene, 60, abs_int)
+    assert all(lv["waves"] >= 1 for lv in rep["levels"])
+    assert rep["levels"][0]["waves"] > 1   # the level DOES interact through the maps: one wave would be the plain frontier round
+
+
+def test_frontier_waves_equal_the_sequential_loop_on_a_12_view_scene():
+    """The same on a 12-view scene (more views per candidate: viewBlockTest reads every one of them)."""
+    from hpmvs_amd import api, synth
+    from oracle import oracle as orc
+    scene = synth.make_scene(12, 640, 480, n_waves=24)
+    seeds = synth.make_seeds(scene, 600, start_level=2)
+    g = api.Scene(scene, device=0)
+    try:
+        rep = _sequential_levels("12v_640x480", scene, seeds, orc.OracleScene(scene), g, 150, 0)
+    finally:
+        g.close()
+    assert rep["levels"][0]["candidates"] >= 600
