@@ -19,7 +19,8 @@ except Exception:  # pragma: no cover - torch is optional plumbing
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libhpmvs_amd.so")
-MAX_IMAGES = 64
+MAX_IMAGES = 256   # HPMVS_MAX_IMAGES: ids per list row the C ABI takes
+FAST_IMAGES = 64   # HPMVS_FAST_IMAGES: lists that never outgrow this run in the batch kernel alone
 MAX_LEVELS = 8
 
 
@@ -50,6 +51,7 @@ EXPORTS = [
     "hpmvs_scene_create", "hpmvs_scene_set_view", "hpmvs_scene_set_covis", "hpmvs_scene_commit",
     "hpmvs_scene_destroy", "hpmvs_scene_get_level", "hpmvs_scene_bytes", "hpmvs_build_pyramid",
     "hpmvs_optimize_batch", "hpmvs_init_patches_batch", "hpmvs_objective_batch", "hpmvs_inccs_batch", "hpmvs_last_kernel_ms",
+    "hpmvs_last_wide_patches",
     "hpmvs_expand_batch", "hpmvs_expand_directions", "hpmvs_selftest_bobyqa",
     "hpmvs_pack_records", "hpmvs_unpack_records", "hpmvs_allgather_records",
     "hpmvs_scene_depth_reset", "hpmvs_scene_depth_set_level", "hpmvs_scene_depth_get_level",
@@ -202,6 +204,12 @@ class Scene:
         _chk(lib().hpmvs_last_staging(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def last_wide_patches(self) -> int:
+        """Patches of the last refinement launch whose list outgrew 64 ids and that the wide kernel redid."""
+        n = C.c_int32()
+        _chk(lib().hpmvs_last_wide_patches(self.h, C.byref(n)))
+        return n.value
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         _chk(lib().hpmvs_last_kernel_ms(self.h, C.byref(ms)))
@@ -276,7 +284,7 @@ def optimize_batch(scene: Scene, batch: Batch, options: Options | None = None) -
     return batch
 
 
-def init_patches_batch(scene: Scene, xyz, meas_off, meas_img, start_level=4, max_images=MAX_IMAGES,
+def init_patches_batch(scene: Scene, xyz, meas_off, meas_img, start_level=4, max_images=FAST_IMAGES,
                        options: Options | None = None) -> Batch:
     """Scene::initPatches seed loop on the GPU (reference Scene.cpp:112-178): seeds built on device, refined,
     drift-gated.  Returns the batch (seed patches, refined where ok).  max_images: the rows of the batch's image lists; a point

@@ -86,6 +86,7 @@ struct hpmvs_scene {
     // entry, one H2D and one D2H copy per call, no hipMalloc / hipFree
     struct StageEntry { hipStream_t st = nullptr; char* dev = nullptr; char* host = nullptr; std::mutex mu; };
     static constexpr int kStageEntries = 8;
+    mutable int32_t* last_ws = nullptr;   // the workspace of the last refinement launch (hpmvs_last_wide_patches)
     static constexpr int kStageCapPatches = 4096;
     mutable StageEntry stage[kStageEntries];
     mutable std::atomic<unsigned> stage_next{0};
@@ -647,6 +648,7 @@ static int enqueue_refinement(const hpmvs_scene* s, const DevOptions& d, const D
         HIPCHK(hipMemsetAsync(q, 0, kQueueSlotBytes, st));
         HIPCHK(hipEventRecord(s->ev0, st));
         launch_optimize(dev_scene(s), d, batch, q, s->n_cus, st);
+        s->last_ws = q;
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(s->ev1, st));
     }
@@ -908,7 +910,7 @@ static int service_open(const hpmvs_scene* s, hpmvs_scene::Service& S, const hpm
     S.gen++;
     DevBatch D;
     memset(&D, 0, sizeof(D));
-    D.n = Service::kCap; D.max_images = HPMVS_MAX_IMAGES;
+    D.n = Service::kCap; D.max_images = HPMVS_FAST_IMAGES;   // (the open batch's records hold 64 ids)
     // (unified addressing: the host pointer is the device pointer of mapped memory)
     D.svc_in = (const unsigned long long*)S.in; D.svc_out = S.out; D.svc_stage = (uint32_t*)((char*)S.ws + S.stage_off);
     D.svc_ctrl = (const int32_t*)S.ctrl; D.svc_done = (int32_t*)S.done; D.svc_lanes = Service::kLanes;
@@ -1005,7 +1007,7 @@ static int optimize_through_service(const hpmvs_scene* s, const hpmvs_options* o
             memcpy(rec + 0, b->center + 4 * i, 12); memcpy(rec + 3, b->scale + i, 4);
             memcpy(rec + 4, b->normal + 4 * i, 12);
             // a list longer than the caller's row cannot come back: failed like every other launch does (stage 100)
-            const int32_t ni = b->n_images[i] > m ? (int32_t)(HPMVS_MAX_IMAGES + 1) : b->n_images[i];
+            const int32_t ni = b->n_images[i] > m ? (int32_t)(HPMVS_FAST_IMAGES + 1) : b->n_images[i];
             memcpy(rec + 7, &ni, 4);
             memcpy(rec + 8, b->images + (size_t)i * m, 4 * (size_t)m);
         }
@@ -1149,7 +1151,31 @@ int hpmvs_optimize_batch(const hpmvs_scene* s, const hpmvs_options* o, hpmvs_pat
     if (!b->ok) return fail(HPMVS_ERR_ARG, "optimize_batch: ok[] is required");
     if (b->n == 0) return HPMVS_OK;
     HIPCHK(hipSetDevice(s->device));
-    if (!on_device && !stream && b->n <= kServiceMaxPatches && service_enabled()) return optimize_through_service(s, o, b);
+    if (!on_device && !stream && b->n <= kServiceMaxPatches && b->max_images <= HPMVS_FAST_IMAGES && service_enabled()) {
+        // The open batch runs the 64-id kernel alone.  A patch that comes back with stage 100 (its list outgrew 64 ids, or the
+        // caller's row) was left untouched: it goes through a batch launch of its own, whose wide kernel takes lists up to
+        // HPMVS_MAX_IMAGES (kernel_wide.hip) -- same result as if it had been part of a batch.
+        std::vector<int32_t> stage_tmp;
+        hpmvs_patch_batch bb = *b;
+        if (!bb.stage) { stage_tmp.assign((size_t)b->n, 0); bb.stage = stage_tmp.data(); }
+        if ((rc = optimize_through_service(s, o, &bb))) return rc;
+        for (int i = 0; i < b->n; i++) {
+            if (bb.ok[i] || bb.stage[i] != 100) continue;
+            hpmvs_patch_batch one = bb;
+            one.n = 1;
+            one.center += 4 * i; one.normal += 4 * i; one.scale += i; one.n_images += i; one.images += (size_t)i * b->max_images; one.ok += i;
+            if (one.color) one.color += 3 * i;
+            if (one.ncc) one.ncc += i;
+            if (one.fmin) one.fmin += i;
+            if (one.x) one.x += 3 * i;
+            if (one.result) one.result += i;
+            if (one.nevals) one.nevals += i;
+            if (one.stage) one.stage += i;
+            if (one.ngrabs) one.ngrabs += i;
+            if ((rc = optimize_small_host_batch(s, o, &one))) return rc;
+        }
+        return HPMVS_OK;
+    }
     if (!on_device && !stream && b->n <= hpmvs_scene::kStageCapPatches) return optimize_small_host_batch(s, o, b);
     hipStream_t st = (hipStream_t)stream;
     Staged sg;
@@ -1556,6 +1582,17 @@ int hpmvs_depth_footprints_batch(const hpmvs_scene* s, const hpmvs_patch_batch* 
     if ((rc = stage_out(frees, df, n * M * 4))) return rc;
     if ((rc = stage_out(attached, da, n * M * 3))) return rc;
     return stage_out(view_block, dv, n * V * 3);
+}
+
+// how many patches of the last refinement launch outgrew the batch kernel's 64-id rows and were redone by the wide kernel
+int hpmvs_last_wide_patches(const hpmvs_scene* s, int32_t* n) {
+    if (!s || !n) return fail(HPMVS_ERR_ARG, "last_wide_patches: null argument");
+    *n = 0;
+    if (!s->last_ws) return HPMVS_OK;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(n, s->last_ws + 241, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return HPMVS_OK;
 }
 
 // debug: phase counters of the last optimize launch (only meaningful in -DHPMVS_PROFILE_PHASES builds)

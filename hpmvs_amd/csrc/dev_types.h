@@ -5,7 +5,8 @@
 namespace hpmvs {
 
 constexpr int kMaxLevels = 8;
-constexpr int kMaxImages = 64;   // = wavefront width: lane v <-> attached image v
+constexpr int kMaxImages = 64;   // = wavefront width: lane v <-> attached image v (the batch kernel's list rows)
+constexpr int kWideImages = 256; // HPMVS_MAX_IMAGES: what the wide kernel (kernel_wide.hip) takes over beyond 64
 constexpr int kTex = 7;          // PatchTex = Patch2d<7,float> (reference Patch2d.hpp:88)
 constexpr int kTexPix = 49;
 

@@ -139,8 +139,8 @@ __global__ void __launch_bounds__(256) depth_fill_kernel(float* p, size_t n) {
 
 // Scene::setDepths(patch, subtract = false): one thread per (patch, attached image)
 __global__ void __launch_bounds__(256) set_depths_kernel(DevScene sc, const DevDepthView* __restrict__ depths, DevBatch b) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int p = t / kMaxImages, k = t - p * kMaxImages;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = (int)(t / b.max_images), k = (int)(t - (long long)p * b.max_images);
     if (p >= b.n) return;
     if (b.ok && !b.ok[p]) return;
     const int nimg = b.n_images[p];
@@ -171,9 +171,11 @@ __global__ void __launch_bounds__(256) depth_gates_kernel(DevScene sc, const Dev
         int nimg = b.n_images[p];
         nimg = nimg < 0 ? 0 : (nimg > b.max_images ? b.max_images : nimg);
         // the attached images: depthTests (similar depth) and pixelFreeTests
+        int nv = 0, nf = 0;
+        for (int k0 = 0; k0 < nimg; k0 += 64) {   // (lists longer than a wavefront: HPMVS_MAX_IMAGES = 256)
         bool vis = false, fre = false;
-        if (lane < nimg) {
-            const int idx = b.images[(size_t)p * b.max_images + lane];
+        if (k0 + lane < nimg) {
+            const int idx = b.images[(size_t)p * b.max_images + k0 + lane];
             if (idx >= 0 && idx < sc.n_views) {
                 const DevView& V = sc.views[idx];
                 vis = depth_test(V, depths[idx], c, n, scale, margin, false, abs_int);
@@ -192,7 +194,8 @@ __global__ void __launch_bounds__(256) depth_gates_kernel(DevScene sc, const Dev
                 }
             }
         }
-        const int nv = __popcll(__ballot(vis)), nf = __popcll(__ballot(fre));
+        nv += __popcll(__ballot(vis)); nf += __popcll(__ballot(fre));
+        }
         // every view of the scene: does the patch lie in front of a confirmed surface there?
         int nb = 0;
         for (int base = 0; base < sc.n_views; base += 64) {
@@ -232,9 +235,9 @@ __global__ void __launch_bounds__(256) depth_footprints_kernel(DevScene sc, cons
         const float scale = b.scale[p];
         int nimg = b.n_images[p];
         nimg = nimg < 0 ? 0 : (nimg > M ? M : nimg);
-        if (lane < M) {
+        for (int kk = lane; kk < M; kk += 64) {
             int w4[4] = {-1, 0, 0, 0}, f4[4] = {-1, 0, 0, 0}, a3[3] = {-1, 0, 0};
-            const int idx = lane < nimg ? b.images[(size_t)p * M + lane] : -1;
+            const int idx = kk < nimg ? b.images[(size_t)p * M + kk] : -1;
             if (idx >= 0 && idx < sc.n_views) {
                 const DevView& V = sc.views[idx];
                 const DevDepthView& D = depths[idx];
@@ -246,7 +249,7 @@ __global__ void __launch_bounds__(256) depth_footprints_kernel(DevScene sc, cons
                 depth_test_block(V, c, a3[1], a3[2], depth);
                 a3[0] = idx;
             }
-            const size_t o = (size_t)p * M + lane;
+            const size_t o = (size_t)p * M + kk;
             if (wr) for (int k = 0; k < 4; k++) wr[4 * o + k] = w4[k];
             if (fr) for (int k = 0; k < 4; k++) fr[4 * o + k] = f4[k];
             if (at) for (int k = 0; k < 3; k++) at[3 * o + k] = a3[k];
@@ -283,7 +286,7 @@ void launch_depth_fill(float* p, size_t n, hipStream_t st) {
 }
 void launch_set_depths(const DevScene& sc, const DevDepthView* depths, const DevBatch& b, hipStream_t st) {
     if (b.n <= 0) return;
-    const size_t threads = (size_t)b.n * kMaxImages;
+    const size_t threads = (size_t)b.n * (size_t)b.max_images;
     hipLaunchKernelGGL(set_depths_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, sc, depths, b);
 }
 void launch_depth_gates(const DevScene& sc, const DevDepthView* depths, const DevBatch& b, float margin, int abs_int,

@@ -30,8 +30,20 @@ int optimize_sums_mode() {
     return mode;
 }
 
+void launch_optimize_wide(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* counter, int n_cus, hipStream_t st);
+static void launch_optimize_fast(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus, hipStream_t st);
+
+// A refinement launch = the batch kernel (lists up to 64 ids) + the wide kernel behind it, which redoes the patches the batch
+// kernel marked ok == 2 (list longer than 64 ids; kernel_wide.hip).  With nothing marked the wide kernel is a scan of ok[].
 void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus,
                      hipStream_t st) {
+    if (b.n <= 0) return;
+    launch_optimize_fast(sc, o, b, workspace, n_cus, st);
+    launch_optimize_wide(sc, o, b, workspace + 240, n_cus, st);   // (its scan counter: a word of the zeroed counter block nobody else uses)
+}
+
+static void launch_optimize_fast(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus,
+                                 hipStream_t st) {
     // HPMVS_SLOTS=29 / 64 forces one build (measurements; 58 and 60, the big build's earlier slot counts, mean it too);
     // otherwise the 64-slot build from 768 patches per CU (196 608 on an MI355X), where its lower cost per patch has paid
     // for its longer ramp-down.  Round 5, 29 / 64 slots, same gpurun call (profiles/r05/slots_crossover.txt): C2 scene 100 k

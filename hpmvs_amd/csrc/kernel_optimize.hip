@@ -530,7 +530,9 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
                     }
                     fin_idx = idx; fin_pending = true; yield = true;
                 } else {
-                    b.ok[idx] = finish_ok ? 1 : 0;
+                    // (2: the list outgrew this kernel's 64-id rows -- optimize_wide_kernel, launched behind this one, redoes the
+                    //  patch from its untouched inputs: kernel_wide.hip)
+                    b.ok[idx] = finish_ok ? 1 : (fail_stage == 100 ? 2 : 0);
                     if (finish_ok) {
                         for (int k = 0; k < 3; k++) { b.center[4 * idx + k] = c[k]; b.normal[4 * idx + k] = n[k]; }
                         b.center[4 * idx + 3] = 1.0f;

@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(256) pack_records_kernel(DevBatch b, DevRecord
     r.fmin = b.fmin ? b.fmin[i] : 0.0;
     r.ok = b.ok ? b.ok[i] : 0; r.pad0 = 0;
     const int nim = b.n_images[i];
-    r.n_images = (uint16_t)nim;
+    r.n_images = (uint16_t)nim;   // (the true count; beyond kMaxImages ids only the first 64 travel: INTEGRATION.md)
     for (int k = 0; k < 4; k++) r.pad1[k] = 0;
     for (int k = 0; k < kMaxImages; k++)
         r.images[k] = (k < nim && k < b.max_images) ? (uint16_t)b.images[(size_t)i * b.max_images + k] : (uint16_t)0xFFFF;

@@ -432,6 +432,18 @@ bool Scene::extractCoVisiblilty(const NVM_Model& model, const HpmvsOptions&) {
     return true;
 }
 
+// Row width of the image-id arrays handed to the C ABI.  The reference's lists are unbounded vectors; a list cannot hold more
+// than the scene's views (addImages never attaches a view twice), so rows of min(views, HPMVS_MAX_IMAGES) ids hold every list
+// that can come back -- but never fewer than HPMVS_FAST_IMAGES, and exactly that for up to four patches (the unchanged
+// callers' optimize()): 64-id rows are what the open batch behind single-patch calls takes.
+static int list_stride(size_t n_views, size_t n_patches, size_t longest_input) {
+    size_t m = n_views > longest_input ? n_views : longest_input;
+    if (n_patches <= 4 && longest_input <= (size_t)HPMVS_FAST_IMAGES) m = HPMVS_FAST_IMAGES;
+    if (m < (size_t)HPMVS_FAST_IMAGES) m = HPMVS_FAST_IMAGES;
+    if (m > (size_t)HPMVS_MAX_IMAGES) m = HPMVS_MAX_IMAGES;
+    return (int)m;
+}
+
 bool Scene::initPatches(const NVM_Model& model, const HpmvsOptions& options, std::vector<Ppatch3d>& out) const {
     hpmvs_scene* dev = deviceScene();
     if (!dev) return false;
@@ -450,7 +462,9 @@ bool Scene::initPatches(const NVM_Model& model, const HpmvsOptions& options, std
         for (const NVM_Measurement& m : model.points[i].measurements) img.push_back(m.imgIndex);
         off[i + 1] = (int32_t)img.size();
     }
-    const int stride = HPMVS_MAX_IMAGES;
+    size_t longest_in = 0;
+    for (size_t i = 0; i < n; i++) longest_in = std::max(longest_in, (size_t)(off[i + 1] - off[i]));
+    const int stride = list_stride(cameras_.size(), n, longest_in);
     PVec<float> center(4 * n, pin), normal(4 * n, pin), scale(n, pin), color(3 * n, pin), ncc(n, pin);
     PVec<int32_t> nimg(n, pin), images(n * stride, -1, pin);
     PVec<uint8_t> ok(n, pin);
@@ -521,19 +535,25 @@ struct HostBatch {  // SoA copy of a patch list for the C ABI (inputs only)
     PVec<float> center, normal, scale;
     PVec<int32_t> nimg, images;
     hpmvs_patch_batch b;
+    static size_t longest(const Patch3d* const* patches, size_t n) {
+        size_t m = 1;
+        for (size_t i = 0; i < n; i++) m = patches[i]->images_.size() > m ? patches[i]->images_.size() : m;
+        return m < (size_t)HPMVS_MAX_IMAGES ? m : (size_t)HPMVS_MAX_IMAGES;
+    }
     HostBatch(const Patch3d* const* patches, size_t n)
         : center(4 * n, PinnedAlloc<float>(true)), normal(4 * n, PinnedAlloc<float>(true)), scale(n, PinnedAlloc<float>(true)),
-          nimg(n, PinnedAlloc<int32_t>(true)), images(n * HPMVS_MAX_IMAGES, -1, PinnedAlloc<int32_t>(true)) {
+          nimg(n, PinnedAlloc<int32_t>(true)), images(n * longest(patches, n), -1, PinnedAlloc<int32_t>(true)) {
+        const size_t stride = longest(patches, n);   // (inputs only: the rows need not hold more than the longest list)
         for (size_t i = 0; i < n; i++) {
             const Patch3d& p = *patches[i];
             for (int k = 0; k < 4; k++) { center[4 * i + k] = p.center_[k]; normal[4 * i + k] = p.normal_[k]; }
             scale[i] = p.scale_3dx_;
-            const size_t m = p.images_.size() < (size_t)HPMVS_MAX_IMAGES ? p.images_.size() : (size_t)HPMVS_MAX_IMAGES;
+            const size_t m = p.images_.size() < stride ? p.images_.size() : stride;
             nimg[i] = (int32_t)m;
-            for (size_t k = 0; k < m; k++) images[i * HPMVS_MAX_IMAGES + k] = p.images_[k];
+            for (size_t k = 0; k < m; k++) images[i * stride + k] = p.images_[k];
         }
         memset(&b, 0, sizeof(b));
-        b.n = (int32_t)n; b.max_images = HPMVS_MAX_IMAGES;
+        b.n = (int32_t)n; b.max_images = (int32_t)stride;
         b.center = center.data(); b.normal = normal.data(); b.scale = scale.data(); b.n_images = nimg.data(); b.images = images.data();
     }
 };
@@ -664,7 +684,9 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
     if (n == 0) return 0;
     hpmvs_scene* dev = scene_p->deviceScene();
     if (!dev) return 0;
-    const int stride = HPMVS_MAX_IMAGES;
+    size_t longest_in = 0;
+    for (size_t i = 0; i < n; i++) longest_in = std::max(longest_in, patches[i]->images_.size());
+    const int stride = list_stride(scene_p->cameras_.size(), n, longest_in);
     const PinnedAlloc<char> pin(n > kPinFrom);
     PVec<float> center(4 * n, pin), normal(4 * n, pin), scale(n, pin), color(3 * n, pin), ncc(n, pin);
     PVec<int32_t> nimg(n, pin), images(n * stride, -1, pin), evals(n, pin);
@@ -722,7 +744,9 @@ int PatchOptimizer::expandBatch(ExpandMode mode, const mo3d::Patch3d* const* par
     if (n == 0) return N;
     hpmvs_scene* dev = scene_p->deviceScene();
     if (!dev) return N;
-    const int stride = HPMVS_MAX_IMAGES;
+    size_t longest_in = 0;
+    for (size_t i = 0; i < n; i++) longest_in = std::max(longest_in, parents[i]->images_.size());
+    const int stride = list_stride(scene_p->cameras_.size(), n * N, longest_in);
     const size_t m = n * N;
     const PinnedAlloc<char> pin(true);  // (this entry stages whatever the batch size: pinned arrays are used in place)
     PVec<float> pc(4 * n, pin), pn(4 * n, pin), ps(n, pin), cc(3 * n, pin), cw(n, pin);

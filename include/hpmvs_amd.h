@@ -46,7 +46,11 @@ extern "C" {
 #define HPMVS_ERR_NODEVICE (-4) /* no gfx950 device visible: there is NO CPU fallback */
 
 #define HPMVS_MAX_LEVELS 8
-#define HPMVS_MAX_IMAGES 64 /* images attached to one patch (reference: unbounded vector<int>); overflow => stage 100 */
+#define HPMVS_MAX_IMAGES 256 /* images attached to one patch (reference: unbounded vector<int>); overflow => stage 100.  Lists of up to
+                              HPMVS_FAST_IMAGES ids run in the batch kernel; a patch whose list outgrows that at any point of the
+                              pipeline is redone by the wide kernel behind it (same launch, same results, one patch per wavefront) */
+#define HPMVS_FAST_IMAGES 64
+#define HPMVS_RECORD_IMAGES 64 /* ids an hpmvs_record carries */
 
 typedef struct hpmvs_scene hpmvs_scene; /* opaque; owns the HBM-resident pyramids and tables */
 
@@ -249,6 +253,9 @@ int hpmvs_last_staging(const hpmvs_scene *s, unsigned long long *staged_bytes, u
  * time: the scene holds a single event pair, so concurrent launches from several host threads can pair the start of one
  * launch with the end of another. */
 int hpmvs_last_kernel_ms(const hpmvs_scene *s, float *ms);
+/* How many patches of the last refinement launch outgrew the batch kernel's HPMVS_FAST_IMAGES-id rows and were redone by the
+ * wide kernel behind it (synchronises the device). */
+int hpmvs_last_wide_patches(const hpmvs_scene *s, int32_t *n);
 
 /* ---- multi-GPU: the per-round exchange of refined patches ---------------------------------------------------------
  * Patches are independent (PatchOptimizer.cpp:78-103 reads only its patch and the immutable scene; the reference
@@ -276,7 +283,7 @@ typedef struct hpmvs_record {
     uint8_t pad0;
     uint16_t n_images;
     uint8_t pad1[4];
-    uint16_t images[HPMVS_MAX_IMAGES]; /* unused slots 0xFFFF */
+    uint16_t images[HPMVS_RECORD_IMAGES]; /* unused slots 0xFFFF; n_images > HPMVS_RECORD_IMAGES: the first 64 ids */
 } hpmvs_record;                        /* 192 bytes */
 int hpmvs_pack_records(const hpmvs_patch_batch *b, hpmvs_record *records, void *stream);
 int hpmvs_unpack_records(const hpmvs_record *records, int n, hpmvs_patch_batch *b, void *stream);

@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define ORC_MAX_LEVELS 8
-#define ORC_MAX_IMAGES 64 /* cap on images attached to one patch (reference: unbounded vector) */
+#define ORC_MAX_IMAGES 256 /* cap on images attached to one patch (reference: unbounded vector); = HPMVS_MAX_IMAGES */
 
 /* include/hpmvs/HpmvsOptions.h:29-58 (only the fields the path reads) */
 typedef struct {

@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-MAX_IMAGES = 64
+MAX_IMAGES = 256  # = ORC_MAX_IMAGES = HPMVS_MAX_IMAGES
 MAX_LEVELS = 8
 OPT_REF, OPT_PORT = 0, 1
 
