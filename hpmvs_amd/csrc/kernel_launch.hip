@@ -30,7 +30,8 @@ int optimize_sums_mode() {
     return mode;
 }
 
-void launch_optimize_wide(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* counter, int n_cus, hipStream_t st);
+void launch_optimize_wide(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int32_t* counter, size_t list_cap,
+                          int n_cus, hipStream_t st);
 static void launch_optimize_fast(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus, hipStream_t st);
 
 // A refinement launch = the batch kernel (lists up to 64 ids) + the wide kernel behind it, which redoes the patches the batch
@@ -39,7 +40,9 @@ void launch_optimize(const DevScene& sc, const DevOptions& o, const DevBatch& b,
                      hipStream_t st) {
     if (b.n <= 0) return;
     launch_optimize_fast(sc, o, b, workspace, n_cus, st);
-    launch_optimize_wide(sc, o, b, workspace + 240, n_cus, st);   // (its scan counter: a word of the zeroed counter block nobody else uses)
+    // (its three counters: words of the zeroed counter block nobody else uses; its list of marked patches: the rest of the
+    //  workspace, which the batch kernel is through with)
+    launch_optimize_wide(sc, o, b, workspace, workspace + 240, (optimize_workspace_bytes(n_cus) - 1024) / sizeof(int32_t), n_cus, st);
 }
 
 static void launch_optimize_fast(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int n_cus,

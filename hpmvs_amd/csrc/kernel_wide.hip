@@ -36,7 +36,6 @@ namespace {
 constexpr int kWide = kWideImages;   // ids per list
 constexpr int kChunk = 63;           // images per sub-request beside the reference image
 constexpr int kSubs = (kWide - 1 + kChunk - 1) / kChunk;  // 5
-constexpr int kScan = 4096;          // patches a wavefront claims per step of the scan over ok[]
 
 __shared__ uint16_t w_list[kWide], w_tmp[kWide];
 __shared__ uint16_t w_sub[kSubs][64];
@@ -397,19 +396,39 @@ __device__ void wide_run(const DevScene& sc, const DevOptions& o, int m, const f
 
 }  // namespace
 
-// One wavefront per workgroup; the wavefronts claim stretches of the batch (counter[0]) and redo every patch marked ok == 2.
-__global__ void __launch_bounds__(64, 2) optimize_wide_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* counter) {
+// Two launches behind the batch kernel.  wide_collect_kernel: one thread per patch, the marked ones (ok == 2) are appended to a
+// list (one atomic per wavefront that has any); the list lives in the launch workspace behind the counter block -- the batch
+// kernel's parking buffers, which nobody needs any more when this runs.  optimize_wide_kernel: one wavefront per workgroup,
+// each takes the next list entry until the list is through (a marked patch costs milliseconds: one patch per claim).
+// counter[0]: next list entry, counter[1]: patches redone (hpmvs_last_wide_patches), counter[2]: list length.
+__global__ void __launch_bounds__(256) wide_collect_kernel(DevBatch b, int32_t* counter, int32_t* list) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool marked = i < b.n && b.ok[i] == 2;
+    const unsigned long long mk = __ballot(marked);
+    if (!mk) return;
     const int lane = lane_id();
+    int base = 0;
+    if (lane == __ffsll((long long)mk) - 1) base = atomicAdd(counter + 2, __popcll(mk));
+    base = bcast_i(base, __ffsll((long long)mk) - 1);
+    if (marked) list[base + __popcll(mk & lanes_below(lane))] = i;
+}
+
+__global__ void __launch_bounds__(256) wide_unmark_kernel(DevBatch b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < b.n && b.ok[i] == 2) b.ok[i] = 0;
+}
+
+__global__ void __launch_bounds__(64, 2) optimize_wide_kernel(DevScene sc, DevOptions o, DevBatch b, int32_t* counter, const int32_t* list) {
+    const int lane = lane_id();
+    const int total = counter[2];
     for (;;) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(counter, kScan);
-        base = bcast_i(base, 0);
-        if (base >= b.n) return;
-        for (int j0 = base; j0 < base + kScan && j0 < b.n; j0 += 64) {
-            const int i = j0 + lane;
-            unsigned long long todo = __ballot(i < b.n && b.ok[i] == 2);
-            for (; todo; todo &= todo - 1ull) {
-                const int idx = j0 + __ffsll((long long)todo) - 1;
+        int t = 0;
+        if (lane == 0) t = atomicAdd(counter, 1);
+        t = bcast_i(t, 0);
+        if (t >= total) return;
+        {
+            {
+                const int idx = list[t];
                 const float c0[3] = {b.center[4 * idx], b.center[4 * idx + 1], b.center[4 * idx + 2]};
                 const float n0[3] = {b.normal[4 * idx], b.normal[4 * idx + 1], b.normal[4 * idx + 2]};
                 const float scale = b.scale[idx];
@@ -454,12 +473,19 @@ __global__ void __launch_bounds__(64, 2) optimize_wide_kernel(DevScene sc, DevOp
     }
 }
 
-void launch_optimize_wide(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* counter, int n_cus, hipStream_t st) {
+// workspace: the launch workspace of the batch kernel that ran before (its first kCounterBytes = 1 KB are the counter block; the
+// words from `counter` on are zero and nobody else's), list_cap: ints that fit behind the counter block
+void launch_optimize_wide(const DevScene& sc, const DevOptions& o, const DevBatch& b, int32_t* workspace, int32_t* counter, size_t list_cap,
+                          int n_cus, hipStream_t st) {
     if (b.n <= 0) return;
-    int wgs = (b.n + kScan - 1) / kScan;
-    const int cap = n_cus * 8;
-    if (wgs > cap) wgs = cap;
-    hipLaunchKernelGGL(optimize_wide_kernel, dim3(wgs), dim3(64), 0, st, sc, o, b, counter);
+    if ((size_t)b.n > list_cap) {   // (more patches than the workspace holds list entries -- ~50 M: no wide pass, the marked patches keep stage 100)
+        hipLaunchKernelGGL(wide_unmark_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b);
+        return;
+    }
+    int32_t* list = workspace + 256;
+    hipLaunchKernelGGL(wide_collect_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b, counter, list);
+    int wgs = b.n < n_cus * 8 ? b.n : n_cus * 8;
+    hipLaunchKernelGGL(optimize_wide_kernel, dim3(wgs), dim3(64), 0, st, sc, o, b, counter, list);
 }
 
 }  // namespace hpmvs

@@ -36,7 +36,7 @@ def test_scene_life_cycle_and_argument_errors(tiny_scene, tiny_seeds):
     assert L.hpmvs_scene_commit(h) == -3                           # twice
     assert L.hpmvs_scene_set_covis(h, 0, ids, 1) == -3             # after commit
     # bad batches / options
-    bad = b.c_struct(); bad.max_images = 65
+    bad = b.c_struct(); bad.max_images = 257   # > HPMVS_MAX_IMAGES
     assert L.hpmvs_optimize_batch(h, C.byref(o), C.byref(bad), 0, None) == -2
     bad = b.c_struct(); bad.ok = None
     assert L.hpmvs_optimize_batch(h, C.byref(o), C.byref(bad), 0, None) == -2
