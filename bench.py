@@ -233,11 +233,10 @@ def main(argv=None, backend=None):
     plan = Plan(workload, args.scaling, args.patches, rank, world)
     views, W, H, start_level, scaling = plan.views, plan.W, plan.H, plan.start_level, plan.scaling
     n_total, n_seeds, n_job, lo, hi, counts = plan.n_total, plan.n_seeds, plan.n_job, plan.lo, plan.hi, plan.counts
-    # rows of the batch's image lists: 32 ids hold every list of the BASELINE configs (checked on EVERY patch of C1, C2 and C4
-    # at its 1e7 seeds: no list overflows, tools/full_parity.py); at START_LEVEL 1 a patch of the 50-view scene attaches up to
-    # ~50 images and 9 % of the patches would end at stage 100 (list overflow) instead of being refined, so the stress
-    # workload gets the C ABI's maximum of 64 (the reference's lists are unbounded vectors)
-    max_images = 64 if start_level < 4 else 32
+    # rows of the batch's image lists: a list cannot hold more than the scene's views (addImages never attaches a view twice), so
+    # rows of min(views, HPMVS_MAX_IMAGES) ids hold every list that can come back -- no patch of any workload ends at stage 100
+    # for want of room.  (Lists that outgrow 64 ids on the way are redone by the wide kernel behind the batch kernel.)
+    max_images = min(views, api.MAX_IMAGES)
 
     # ---- scene: rendered on the GPU, replicated on every rank, resident in HBM
     t0 = time.time()

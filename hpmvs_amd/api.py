@@ -53,7 +53,7 @@ EXPORTS = [
     "hpmvs_optimize_batch", "hpmvs_init_patches_batch", "hpmvs_objective_batch", "hpmvs_inccs_batch", "hpmvs_last_kernel_ms",
     "hpmvs_last_wide_patches",
     "hpmvs_expand_batch", "hpmvs_expand_directions", "hpmvs_selftest_bobyqa",
-    "hpmvs_pack_records", "hpmvs_unpack_records", "hpmvs_allgather_records",
+    "hpmvs_pack_records", "hpmvs_unpack_records", "hpmvs_allgather_records", "hpmvs_pack_record_tails", "hpmvs_unpack_record_tails",
     "hpmvs_scene_depth_reset", "hpmvs_scene_depth_set_level", "hpmvs_scene_depth_get_level",
     "hpmvs_set_depths_batch", "hpmvs_depth_gates_batch", "hpmvs_depth_footprints_batch",
     "hpmvs_host_alloc", "hpmvs_host_free", "hpmvs_last_staging",

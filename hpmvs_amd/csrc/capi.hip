@@ -682,6 +682,33 @@ extern "C" int hpmvs_unpack_records(const hpmvs_record* records, int n, hpmvs_pa
     HIPCHK(hipGetLastError());
     return HPMVS_OK;
 }
+static_assert(sizeof(hpmvs_record_tail) == 392, "hpmvs_record_tail is 392 bytes");
+extern "C" int hpmvs_pack_record_tails(const hpmvs_patch_batch* b, hpmvs_record_tail* tails, int32_t cap, int32_t* n_tails, void* stream) {
+    if (!b || !n_tails || b->n < 0 || cap < 0 || b->max_images < 1 || b->max_images > HPMVS_MAX_IMAGES) return fail(HPMVS_ERR_ARG, "pack_record_tails: bad batch");
+    *n_tails = 0;
+    if (b->n == 0 || b->max_images <= HPMVS_RECORD_IMAGES) return HPMVS_OK;   // (rows of up to 64 ids have no tails)
+    if (!b->n_images || !b->images || (cap > 0 && !tails)) return fail(HPMVS_ERR_ARG, "pack_record_tails: missing array");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nblocks = ((size_t)b->n + 63) / 64;
+    int32_t* scratch = nullptr;
+    HIPCHK(hipMalloc((void**)&scratch, sizeof(int32_t) * (nblocks + 1)));
+    launch_pack_record_tails(as_dev_batch(b), tails, cap, scratch, scratch + nblocks, st);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(n_tails, scratch + nblocks, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(scratch);
+    if (e != hipSuccess) return fail(HPMVS_ERR_HIP, std::string("pack_record_tails: ") + hipGetErrorString(e));
+    if (*n_tails > cap) return fail(HPMVS_ERR_ARG, "pack_record_tails: " + std::to_string(*n_tails) + " tails do not fit the " + std::to_string(cap) + " handed over");
+    return HPMVS_OK;
+}
+extern "C" int hpmvs_unpack_record_tails(const hpmvs_record_tail* tails, int32_t n_tails, int32_t patch_offset, hpmvs_patch_batch* b, void* stream) {
+    if (!b || n_tails < 0 || b->n < 0 || b->max_images < 1 || b->max_images > HPMVS_MAX_IMAGES) return fail(HPMVS_ERR_ARG, "unpack_record_tails: bad batch");
+    if (n_tails == 0) return HPMVS_OK;
+    if (!tails || !b->images) return fail(HPMVS_ERR_ARG, "unpack_record_tails: missing array");
+    launch_unpack_record_tails(tails, n_tails, patch_offset, as_dev_batch(b), (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return HPMVS_OK;
+}
 // ncclAllGather(sendbuff, recvbuff, sendcount, datatype, comm, stream); ncclUint8 = 1, ncclSuccess = 0 (rccl.h)
 typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
 static nccl_allgather_fn find_allgather() {

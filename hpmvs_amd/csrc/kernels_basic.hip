@@ -398,6 +398,78 @@ __global__ void __launch_bounds__(256) unpack_records_kernel(const DevRecord* __
         b.images[(size_t)i * b.max_images + k] = (k < kMaxImages && r.images[k] != 0xFFFF) ? (int32_t)r.images[k] : -1;
 }
 
+// Tails of the records whose list is longer than the record's 64 ids (include/hpmvs_amd.h: hpmvs_record_tail, 392 bytes).
+// One wavefront per 64 patches: the refined patches with more than 64 images are ranked by a ballot prefix inside the wavefront
+// and by an exclusive scan over the wavefronts' counts (counts[] filled by a first pass), so that the tails come out in PATCH ORDER.
+struct DevTail { int32_t patch; uint16_t count, pad; uint16_t images[kWideImages - kMaxImages]; };
+static_assert(sizeof(DevTail) == 392, "tail layout");
+__device__ __forceinline__ bool has_tail(const DevBatch& b, int i) {
+    return i < b.n && (!b.ok || b.ok[i]) && b.n_images[i] > kMaxImages && b.n_images[i] <= b.max_images && b.n_images[i] <= kWideImages;
+}
+__global__ void __launch_bounds__(64) tail_count_kernel(DevBatch b, int32_t* __restrict__ counts) {
+    const int i = blockIdx.x * 64 + (int)threadIdx.x;
+    const unsigned long long mk = __ballot(has_tail(b, i));
+    if (threadIdx.x == 0) counts[blockIdx.x] = __popcll(mk);
+}
+__global__ void __launch_bounds__(256) tail_scan_kernel(int32_t* __restrict__ counts, int nblocks, int32_t* __restrict__ total) {
+    // (one workgroup: the number of 64-patch blocks is small next to the work of a round; sequential chunks of 256)
+    __shared__ int32_t part[256];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 256) {
+        const int k = base + (int)threadIdx.x;
+        const int32_t v = k < nblocks ? counts[k] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const int32_t a = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += a;
+            __syncthreads();
+        }
+        if (k < nblocks) counts[k] = carry + part[threadIdx.x] - v;   // exclusive
+        __syncthreads();
+        if (threadIdx.x == 255) carry += part[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ void __launch_bounds__(64) tail_pack_kernel(DevBatch b, const int32_t* __restrict__ offs, DevTail* __restrict__ out, int cap) {
+    const int i = blockIdx.x * 64 + (int)threadIdx.x;
+    const bool t = has_tail(b, i);
+    const unsigned long long mk = __ballot(t);
+    if (!t) return;
+    const int pos = offs[blockIdx.x] + __popcll(mk & ((1ull << threadIdx.x) - 1ull));
+    if (pos >= cap) return;
+    DevTail r;
+    const int nim = b.n_images[i];
+    r.patch = i; r.count = (uint16_t)(nim - kMaxImages); r.pad = 0;
+    for (int k = 0; k < kWideImages - kMaxImages; k++)
+        r.images[k] = (kMaxImages + k < nim) ? (uint16_t)b.images[(size_t)i * b.max_images + kMaxImages + k] : (uint16_t)0xFFFF;
+    out[pos] = r;
+}
+__global__ void __launch_bounds__(256) tail_unpack_kernel(const DevTail* __restrict__ in, int n_tails, int patch_offset, DevBatch b) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tails) return;
+    const DevTail r = in[t];
+    const long long i = (long long)patch_offset + r.patch;
+    if (i < 0 || i >= b.n) return;
+    for (int k = 0; k < (int)r.count && kMaxImages + k < b.max_images; k++)
+        b.images[(size_t)i * b.max_images + kMaxImages + k] = (int32_t)r.images[k];
+}
+void launch_pack_record_tails(const DevBatch& b, void* tails, int cap, int32_t* scratch_counts, int32_t* total, hipStream_t st) {
+    if (b.n <= 0) return;
+    const int nblocks = (b.n + 63) / 64;
+    hipLaunchKernelGGL(tail_count_kernel, dim3(nblocks), dim3(64), 0, st, b, scratch_counts);
+    hipLaunchKernelGGL(tail_scan_kernel, dim3(1), dim3(256), 0, st, scratch_counts, nblocks, total);
+    hipLaunchKernelGGL(tail_pack_kernel, dim3(nblocks), dim3(64), 0, st, b, scratch_counts, (DevTail*)tails, cap);
+}
+void launch_unpack_record_tails(const void* tails, int n_tails, int patch_offset, const DevBatch& b, hipStream_t st) {
+    if (n_tails <= 0) return;
+    hipLaunchKernelGGL(tail_unpack_kernel, dim3((n_tails + 255) / 256), dim3(256), 0, st, (const DevTail*)tails, n_tails, patch_offset, b);
+}
+
 void launch_pack_records(const DevBatch& b, void* records, hipStream_t st) {
     if (b.n <= 0) return;
     hipLaunchKernelGGL(pack_records_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b, (DevRecord*)records);

@@ -49,6 +49,9 @@ void launch_depth_footprints(const DevScene& sc, const DevDepthView* depths, con
 // refined-patch records of the multi-GPU exchange (include/hpmvs_amd.h: hpmvs_record, 192 bytes)
 void launch_pack_records(const DevBatch& b, void* records, hipStream_t st);
 void launch_unpack_records(const void* records, int n, const DevBatch& b, hipStream_t st);
+// ... and the tails of the lists longer than a record's 64 ids (scratch_counts: one int per 64 patches, total: one device int)
+void launch_pack_record_tails(const DevBatch& b, void* tails, int cap, int32_t* scratch_counts, int32_t* total, hipStream_t st);
+void launch_unpack_record_tails(const void* tails, int n_tails, int patch_offset, const DevBatch& b, hipStream_t st);
 // diagnostics: the BOBYQA state machine on analytic objectives (kernel_selftest.hip); device pointers
 void launch_selftest(int n, const int* kind, const double* params, const double* x0, const double* lb, const double* ub,
                      int maxeval, double* xfinal, double* minf, int* rc, int* nevals, int* rescues, double* trace,

@@ -285,6 +285,21 @@ typedef struct hpmvs_record {
     uint8_t pad1[4];
     uint16_t images[HPMVS_RECORD_IMAGES]; /* unused slots 0xFFFF; n_images > HPMVS_RECORD_IMAGES: the first 64 ids */
 } hpmvs_record;                        /* 192 bytes */
+/* Lists longer than the record's HPMVS_RECORD_IMAGES ids (rare: a refined list of a dense scene): the record keeps the true
+ * n_images and the first 64 ids, the ids from 64 on travel in a TAIL of the sender's overflow segment -- one more all-gather,
+ * made only when some rank has a tail (every rank can tell from the gathered records: n_images > 64 with ok set).  The 192-byte
+ * record is unchanged (format version 1 = no tails anywhere = what rounds 1-5 sent).
+ *   hpmvs_pack_record_tails    tails of the refined patches (ok != 0) with n_images > 64, in patch order; *n_tails (host int) is
+ *                              their number (the call synchronises the stream); HPMVS_ERR_ARG when `cap` tails do not hold them
+ *   hpmvs_unpack_record_tails  ids 64.. of patch (patch_offset + tail.patch) of a batch that hpmvs_unpack_records has filled */
+typedef struct hpmvs_record_tail {
+    int32_t patch;   /* index of the patch in the sender's shard */
+    uint16_t count;  /* ids in this tail = n_images - 64 */
+    uint16_t pad;
+    uint16_t images[HPMVS_MAX_IMAGES - HPMVS_RECORD_IMAGES];
+} hpmvs_record_tail; /* 392 bytes */
+int hpmvs_pack_record_tails(const hpmvs_patch_batch *b, hpmvs_record_tail *tails, int32_t cap, int32_t *n_tails, void *stream);
+int hpmvs_unpack_record_tails(const hpmvs_record_tail *tails, int32_t n_tails, int32_t patch_offset, hpmvs_patch_batch *b, void *stream);
 int hpmvs_pack_records(const hpmvs_patch_batch *b, hpmvs_record *records, void *stream);
 int hpmvs_unpack_records(const hpmvs_record *records, int n, hpmvs_patch_batch *b, void *stream);
 int hpmvs_allgather_records(void *nccl_comm, const hpmvs_record *send, size_t count, hpmvs_record *recv, void *stream);

@@ -113,8 +113,8 @@ def test_records_refuse_what_they_cannot_carry():
         dd.pack_records(*base(1), t(np.array([2], np.int32)), t(np.array([[1, 70000] + [0] * 30], np.int32)))
     with pytest.raises(ValueError):  # 0xFFFF is the "no image" marker
         dd.pack_records(*base(1), t(np.array([1], np.int32)), t(np.array([[65535] + [0] * 31], np.int32)))
-    with pytest.raises(ValueError):  # wider than the ABI's 64
-        dd.pack_records(*base(1), t(np.array([1], np.int32)), t(np.zeros((1, 65), np.int32)))
+    with pytest.raises(ValueError):  # wider than the ABI's 256
+        dd.pack_records(*base(1), t(np.array([1], np.int32)), t(np.zeros((1, 257), np.int32)))
 
 
 # ---- bench.py's own multi-rank logic: Plan (workload default, counts, lo/hi), the slicing of the seed
@@ -279,3 +279,84 @@ def test_bench_main_eight_ranks_on_gloo_ragged_shards_in_tile_order():
     assert co["gathered_records"] == 61 and co["gathered_equals_job"] and co["shards_sum_to_job"]
     assert out0["n_gpus"] == 8 and out0["config"]["order"] == "tiles" and out0["config"]["seeds_per_step_all_gpus"] == 61
     assert all(abs(eight[r][0]["ms_per_step"] - out0["ms_per_step"]) < 1e-9 for r in range(8))   # MAX over ranks, on every rank
+
+
+# ---- lists longer than the record's 64 ids: tails (round 6; include/hpmvs_amd.h: hpmvs_record_tail)
+def _wide_round(n, seed):
+    rng = np.random.default_rng(seed)
+    nim = rng.integers(3, 40, n).astype(np.int32)
+    long = rng.random(n) < 0.2
+    nim[long] = rng.integers(65, 201, int(long.sum()))
+    ok = (rng.random(n) < 0.8).astype(np.uint8)
+    images = np.full((n, 200), -1, np.int32)
+    for k in range(n):
+        images[k, :nim[k]] = rng.permutation(300)[:nim[k]]
+    f = lambda *sh: rng.standard_normal(sh).astype(np.float32)
+    return dict(center=f(n, 4), normal=f(n, 4), color=f(n, 3), scale=f(n), fmin=rng.standard_normal(n), ok=ok, n_images=nim, images=images)
+
+
+def test_tails_carry_the_ids_beyond_64_through_pack_and_unpack():
+    from hpmvs_amd import distributed as dd
+    R = _wide_round(57, 5)
+    t = torch.from_numpy
+    rec = dd.pack_records(t(R["center"]), t(R["normal"]), t(R["color"]), t(R["scale"]), t(R["fmin"]), t(R["ok"]), t(R["n_images"]), t(R["images"]))
+    tails = dd.pack_tails(t(R["ok"]), t(R["n_images"]), t(R["images"]))
+    want = np.nonzero((R["ok"] != 0) & (R["n_images"] > 64))[0]
+    assert rec.shape == (57, dd.RECORD_BYTES) and tails.shape == (len(want), dd.TAIL_BYTES) and len(want) >= 3
+    u = dd.unpack_records(rec, tails)
+    assert np.array_equal(u["n_images"], R["n_images"])
+    for k in range(57):
+        m = R["n_images"][k]
+        if R["ok"][k] or m <= 64:
+            assert list(u["images"][k, :m]) == list(R["images"][k, :m]), k
+        else:   # not refined: no tail travels for it (its record says ok = 0)
+            assert list(u["images"][k, :64]) == list(R["images"][k, :64])
+    # no long list anywhere: the exchange is exactly rounds 1-5's (no tails, 64 columns)
+    S = _wide_round(20, 6); S["n_images"] = np.minimum(S["n_images"], 30)
+    assert dd.pack_tails(t(S["ok"]), t(S["n_images"]), t(S["images"])).shape[0] == 0
+
+
+def _tails_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    from hpmvs_amd import distributed as dd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    R = _wide_round(41, 9)   # the same round on every rank
+    counts = [dd.shard_range(41, r, world)[1] - dd.shard_range(41, r, world)[0] for r in range(world)]
+    lo, hi = dd.shard_range(41, rank, world)
+    t = lambda a: torch.from_numpy(a[lo:hi].copy())
+    rec = dd.pack_records(t(R["center"]), t(R["normal"]), t(R["color"]), t(R["scale"]), t(R["fmin"]), t(R["ok"]), t(R["n_images"]), t(R["images"]))
+    tails = dd.pack_tails(t(R["ok"]), t(R["n_images"]), t(R["images"]))
+    g, gt = dd.all_gather_round(rec, tails, counts)
+    u = dd.unpack_records(g, gt)
+    q.put((rank, g.numpy().copy(), gt.numpy().copy(), u["images"].copy(), u["n_images"].copy()))
+    dist.destroy_process_group()
+
+
+def test_three_rank_round_with_tails_equals_the_one_rank_round():
+    """Ragged shards of a round in which a fifth of the lists is longer than 64 ids: every rank ends with the same records and
+    the same tails (patch indices rebased to the round), and unpacking gives back every refined list in full."""
+    from hpmvs_amd import distributed as dd
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33100 + (os.getpid() % 1500)
+    procs = [ctx.Process(target=_tails_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(3):
+        r, g, gt, img, nim = q.get(timeout=300)
+        got[r] = (g, gt, img, nim)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    R = _wide_round(41, 9)
+    t = torch.from_numpy
+    one = dd.pack_records(t(R["center"]), t(R["normal"]), t(R["color"]), t(R["scale"]), t(R["fmin"]), t(R["ok"]), t(R["n_images"]), t(R["images"])).numpy()
+    one_t = dd.pack_tails(t(R["ok"]), t(R["n_images"]), t(R["images"])).numpy()
+    for r in range(3):
+        g, gt, img, nim = got[r]
+        assert np.array_equal(g, one) and np.array_equal(gt, one_t), r
+        for k in range(41):
+            if R["ok"][k]:
+                assert list(img[k, :R["n_images"][k]]) == list(R["images"][k, :R["n_images"][k]]), (r, k)

@@ -89,3 +89,69 @@ def test_c_and_python_record_codecs_agree_including_rejection_codes():
     got = out["images"].cpu().numpy()
     assert np.array_equal(got[live], imgs[live]) and np.all(got[~live] == -1)
     assert np.array_equal(out["center"].cpu().numpy(), host["center"])
+
+
+def test_c_and_python_tail_codecs_agree_for_lists_longer_than_64_ids():
+    """Round 6: rows of up to HPMVS_MAX_IMAGES = 256 ids.  The record keeps the first 64, the rest travels as a 392-byte tail
+    (hpmvs_pack_record_tails / hpmvs_unpack_record_tails = hpmvs_amd.distributed.pack_tails / unpack_records): same bytes from
+    both packers, tails in patch order and only for refined patches, and unpacking restores every refined list in full."""
+    import ctypes as C
+    import torch
+    from hpmvs_amd import api
+    from hpmvs_amd import distributed as dd
+    L = api.lib()
+    dev = torch.device("cuda", 0)
+    n, m = 700, 200
+    rng = np.random.default_rng(11)
+    nim = rng.integers(3, 50, n).astype(np.int32)
+    long = rng.random(n) < 0.15
+    nim[long] = rng.integers(65, m + 1, int(long.sum()))
+    imgs = np.full((n, m), -1, np.int32)
+    for k in range(n):
+        imgs[k, :nim[k]] = rng.permutation(400)[:nim[k]]
+    host = dict(center=rng.random((n, 4), np.float32), normal=rng.random((n, 4), np.float32), scale=rng.random(n, np.float32),
+                n_images=nim, images=imgs, ok=(rng.random(n) < 0.8).astype(np.uint8), color=rng.random((n, 3), np.float32),
+                ncc=np.zeros(n, np.float32), fmin=rng.random(n), x=np.zeros((n, 3)), result=np.zeros(n, np.int32),
+                nevals=np.zeros(n, np.int32), stage=np.zeros(n, np.int32), ngrabs=np.zeros(n, np.int32))
+    t = {k: torch.from_numpy(v).to(dev) for k, v in host.items()}
+
+    def c_batch(tt):
+        b = api.PatchBatch()
+        b.n, b.max_images = n, m
+        for k in host:
+            setattr(b, k, tt[k].data_ptr())
+        return b
+
+    tp = torch.from_numpy
+    want_rec = dd.pack_records(tp(host["center"]), tp(host["normal"]), tp(host["color"]), tp(host["scale"]), tp(host["fmin"]),
+                               tp(host["ok"]), tp(nim), tp(imgs))
+    want_tails = dd.pack_tails(tp(host["ok"]), tp(nim), tp(imgs))
+    assert want_tails.shape[0] >= 20
+    rec = torch.empty((n, dd.RECORD_BYTES), dtype=torch.uint8, device=dev)
+    tails = torch.zeros((n, dd.TAIL_BYTES), dtype=torch.uint8, device=dev)
+    b = c_batch(t)
+    nt = C.c_int32(-1)
+    L.hpmvs_pack_record_tails.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p]
+    L.hpmvs_unpack_record_tails.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    assert L.hpmvs_pack_records(C.byref(b), C.c_void_p(rec.data_ptr()), None) == 0, L.hpmvs_last_error()
+    assert L.hpmvs_pack_record_tails(C.byref(b), C.c_void_p(tails.data_ptr()), n, C.byref(nt), None) == 0, L.hpmvs_last_error()
+    torch.cuda.synchronize()
+    assert nt.value == want_tails.shape[0]
+    assert torch.equal(rec.cpu(), want_rec) and torch.equal(tails.cpu()[:nt.value], want_tails)
+    assert L.hpmvs_pack_record_tails(C.byref(b), C.c_void_p(tails.data_ptr()), 3, C.byref(nt), None) == -2   # too small a segment: refused
+    # unpack on the device: records, then the tails (as if this shard sat at offset 0 of the round)
+    out = {k: torch.zeros_like(v) for k, v in t.items()}
+    out["images"].fill_(-7)
+    ob = c_batch(out)
+    assert L.hpmvs_unpack_records(C.c_void_p(rec.data_ptr()), n, C.byref(ob), None) == 0, L.hpmvs_last_error()
+    assert L.hpmvs_unpack_record_tails(C.c_void_p(tails.data_ptr()), want_tails.shape[0], 0, C.byref(ob), None) == 0, L.hpmvs_last_error()
+    torch.cuda.synchronize()
+    got = out["images"].cpu().numpy()
+    assert np.array_equal(out["n_images"].cpu().numpy(), nim)
+    for k in range(n):
+        upto = nim[k] if host["ok"][k] else min(nim[k], 64)   # (a patch that was not refined sends no tail)
+        assert np.array_equal(got[k, :upto], imgs[k, :upto]), k
+    u = dd.unpack_records(rec.cpu(), tails.cpu()[:want_tails.shape[0]])
+    for k in range(n):
+        if host["ok"][k]:
+            assert list(u["images"][k, :nim[k]]) == list(imgs[k, :nim[k]]), k
