@@ -192,6 +192,20 @@ class GpuBackend:
         if rc != 0:
             raise RuntimeError(self.L.hpmvs_last_error().decode())
 
+    def pack_tails(self, work, n, max_images):
+        """The tails of the lists longer than a record's 64 ids (rows wider than 64 only: a 200-view scene); a device tensor."""
+        if max_images <= dd.MAX_RECORD_IMAGES:
+            return torch.zeros((0, dd.TAIL_BYTES), dtype=torch.uint8, device=self.device)
+        if getattr(self, "_tails", None) is None or self._tails.shape[0] < n:
+            self._tails = torch.zeros((n, dd.TAIL_BYTES), dtype=torch.uint8, device=self.device)
+        b = c_batch(work, n, max_images)
+        nt = C.c_int32(0)
+        self.L.hpmvs_pack_record_tails.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p]
+        rc = self.L.hpmvs_pack_record_tails(C.byref(b), C.c_void_p(self._tails.data_ptr()), n, C.byref(nt), C.c_void_p(self.stream()))
+        if rc != 0:
+            raise RuntimeError(self.L.hpmvs_last_error().decode())
+        return self._tails[:nt.value]
+
     def sync(self):
         torch.cuda.synchronize()
 
@@ -254,6 +268,7 @@ def main(argv=None, backend=None):
     pristine = device_batch(seeds, dev, max_images)
     work = {k: v.clone() for k, v in pristine.items()}
     gathered = None
+    gathered_tails = None
     # the round's exchange buffer: n_seeds records of 192 bytes, filled by the product's own packing kernel
     records = torch.empty((n_seeds, RECORD_BYTES), dtype=torch.uint8, device=dev) if use_dist else None
 
@@ -272,7 +287,12 @@ def main(argv=None, backend=None):
             if not timed:
                 check_record_ranges(work)
             be.pack(work, n_seeds, max_images, records)
-            gathered = dd.all_gather_records(records, counts)  # ONE collective per round
+            if max_images > dd.MAX_RECORD_IMAGES and hasattr(be, "pack_tails"):
+                # rows wider than a record's 64 ids (a 200-view scene): a second all-gather, made only if some list IS longer
+                nonlocal gathered_tails
+                gathered, gathered_tails = dd.all_gather_round(records, be.pack_tails(work, n_seeds, max_images), counts)
+            else:
+                gathered = dd.all_gather_records(records, counts)  # ONE collective per round
             m2 = be.mark()
         if timed:
             marks.append((m0, m1, m2))
