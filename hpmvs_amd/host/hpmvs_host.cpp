@@ -64,21 +64,23 @@ struct PinnedCache {
             if (lru_[i].cls == c) { void* p = lru_[i].p; cached_ -= lru_[i].bytes; lru_.erase(lru_.begin() + (long)i); return p; }
         return hpmvs_host_alloc(*rounded);
     }
+    // Over the cap the least recently returned blocks go back to the system -- but never the block that was returned last (ADVICE
+    // r5): a working set whose single blocks are larger than the cap (a 1e7-patch batch: images[] alone is GBs) would otherwise be
+    // unpinned and re-pinned by every call, hundreds of milliseconds each; this way the cap follows the last call's largest block.
+    // `keep_newest` entries at the back survive; the survivors are compacted once, not erased one by one from the front.
+    void trim(size_t keep_newest) {
+        size_t drop = 0;
+        while (cached_ > cap_ && drop + keep_newest < lru_.size()) { cached_ -= lru_[drop].bytes; hpmvs_host_free(lru_[drop].p); drop++; }
+        if (drop) lru_.erase(lru_.begin(), lru_.begin() + (long)drop);
+    }
     void put(void* p, size_t rounded) {
         size_t r;
         lru_.push_back(Entry{p, cls(rounded, &r), rounded});
         cached_ += rounded;
-        while (cached_ > cap_ && !lru_.empty()) {  // over the cap: the oldest blocks go back to the system
-            cached_ -= lru_.front().bytes;
-            hpmvs_host_free(lru_.front().p);
-            lru_.erase(lru_.begin());
-        }
+        trim(1);
     }
     size_t cached_bytes() const { return cached_; }
-    void set_cap(size_t bytes) {
-        cap_ = bytes;
-        while (cached_ > cap_ && !lru_.empty()) { cached_ -= lru_.front().bytes; hpmvs_host_free(lru_.front().p); lru_.erase(lru_.begin()); }
-    }
+    void set_cap(size_t bytes) { cap_ = bytes; trim(0); }
 };
 thread_local PinnedCache tl_pins;
 // Whether a block is pinned is recorded IN the block (a 64-byte header in front of the data), not in the allocator object:

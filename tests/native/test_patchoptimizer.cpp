@@ -143,7 +143,7 @@ int main(int argc, char** argv) {
     {
         const size_t cap = (size_t)8 << 20;
         mo3d::PatchOptimizer::setPinnedCacheCap(cap);
-        size_t worst = 0;
+        size_t worst = 0, biggest = 0;   // (the block returned last stays even when it alone exceeds the cap: ADVICE r5)
         std::vector<mo3d::Patch3d> copies;
         for (int rep = 0; rep < 12; rep++) {
             const size_t m = 4100 + 3000 * (size_t)rep;  // above the pinning threshold, a different size class every round
@@ -155,11 +155,12 @@ int main(int argc, char** argv) {
             optimizers[0].optimizeBatch(ptrs.data(), m, okm.data());
             const size_t held = mo3d::PatchOptimizer::pinnedCacheBytes();
             worst = held > worst ? held : worst;
+            biggest = m * 64 * 4 * 5 / 4 + 4096;   // images[]: the round's largest block, rounded up to its size class
             int same = 1;
             for (size_t i = 0; i < m; i++) same &= (okm[i] == ok[i % np]);
             if (!same) { printf("pincache results differ in round %d\n", rep); break; }
         }
-        printf("pincache cap %zu worst %zu\n", cap, worst);
+        printf("pincache cap %zu worst %zu largest_block %zu\n", cap, worst, biggest);
     }
     printf("good %zu\n", good);
     return 0;

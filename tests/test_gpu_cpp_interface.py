@@ -67,10 +67,11 @@ def test_cpp_patchoptimizer_equals_c_abi(tiny_scene, tiny_seeds, gpu_scene, tmp_
                 assert np.array_equal(vals, np.concatenate([batch.center[k, :3], batch.normal[k, :3]]).astype(np.float32)), (tag, k)
                 assert int(r[9]) == batch.n_images[k]
     assert int(out[-1].split()[1]) == int(batch.ok.sum())
-    # twelve optimizeBatch rounds of twelve different sizes: the thread's cache of pinned blocks never exceeds its cap
+    # twelve optimizeBatch rounds of twelve different sizes: the thread's cache of pinned blocks never exceeds its cap (or its single largest block)
     pc = [l.split() for l in out if l.startswith("pincache")]
     assert len(pc) == 1 and pc[0][1] == "cap", pc
-    assert int(pc[0][4]) <= int(pc[0][2]), pc
+    # (the cap, or -- when one block alone is larger -- that one block: the block returned last is never unpinned)
+    assert int(pc[0][4]) <= max(int(pc[0][2]), int(pc[0][6])), pc
     # PatchOptimizer::expandBatch (CellProcessor::extend candidates for every refined patch) == hpmvs_expand_batch
     keep = np.nonzero(batch.ok)[0]
     par = api.Batch(batch.center[keep], batch.normal[keep], batch.scale[keep], batch.n_images[keep], batch.images[keep])
