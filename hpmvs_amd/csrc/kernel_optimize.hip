@@ -147,6 +147,7 @@ constexpr int kPark16 = HPMVS_REGION_16;  // 16-byte chunks of a wavefront's par
 #endif
 constexpr int kAuxDoubles = 64;  // a slot's proxy row: [0..17] prelim_'s start points 2..7, [18..24] the values this round's proxies
 constexpr int kAuxVal = 18;      // delivered; as floats from kAuxCtx: scale, nimg, setRefImage's c / n, then c / n of the
+constexpr int kAuxGrabs = 25;    // [25..31]: the grabs those evaluations took
 constexpr int kAuxCtx = 64;      // start points 2..7
 constexpr int kMaxExtra = 7;     // values a lane takes from proxies per round
 typedef __attribute__((address_space(1))) double gdouble;
@@ -490,6 +491,7 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
                 if (kProxy) {
                     for (int k = 0; k < extra; k++) {  // the candidates my proxies evaluated, in index order
                         const float sx = (float)aux[kAuxVal + k];
+                        ngrabs += (int)aux[kAuxGrabs + k];
                         if (sx < refbest) { refbest = sx; refindex = ii; }
                         ii++;
                     }
@@ -659,7 +661,7 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
                     if (stepping) { ret = bq_step(B, fcur); pre_nf += pre ? 1 : 0; }
                     stepping = pre && kx < extra && ret == BQ_CONTINUE;
                     if (!__any(stepping)) break;
-                    if (stepping) { fcur = (double)aux[kAuxVal + kx]; kx++; }
+                    if (stepping) { fcur = (double)aux[kAuxVal + kx]; ngrabs += (int)aux[kAuxGrabs + kx]; kx++; }
                 }
                 if (pre) { if (pre_nf > 7 || ret != BQ_CONTINUE) pre_nf = 0; extra = 0; }  // (> 7: prelim_ is over)
             } else {
@@ -817,7 +819,9 @@ __device__ __forceinline__ void optimize_body(DevScene sc, DevOptions o, DevBatc
                         const int p = bcast_i(px_owner, fl), k = bcast_i(px_k, fl), g = bcast_i(r.ngrabs, fl), kind = bcast_i(q.obj_mode, fl);
                         const double vf = bcast_d(res_f, fl);
                         const float vs = bcast_f(res_sum, fl);
-                        if (lane == p) { aux[kAuxVal + k] = kind ? vf : (double)vs; ngrabs += g; }
+                        // (the proxy's grabs wait beside its value and are counted when the owner CONSUMES the value -- a value that is
+                        //  dropped because bq_step stopped inside prelim_ was never part of the reference's run: ADVICE r5)
+                        if (lane == p) { aux[kAuxVal + k] = kind ? vf : (double)vs; aux[kAuxGrabs + k] = (double)g; }
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the owners read these values in their next phase A
                     px_owner = -1;

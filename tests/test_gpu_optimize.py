@@ -248,7 +248,7 @@ def test_non_default_options_are_honoured_identically(opts, tiny_seeds, oracle_s
     stage_cpu = np.array([p.stage for p in P])
     assert np.array_equal(stage_cpu, b.stage)
     ok = np.nonzero(b.ok)[0]
-    assert len(ok) >= (20 if "MAXLEVEL" not in opts and "MINLEVEL" not in opts else 1), len(ok)
+    assert len(ok) >= (50 if ("MAXLEVEL" in opts or "MINLEVEL" in opts) else 20), len(ok)   # (the oracle refines 119-186 of the 200 under the level options)
     for k in ok:
         assert np.array_equal(np.array(P[k].center[:], dtype=np.float32), b.center[k])
         assert np.array_equal(np.array(P[k].normal[:], dtype=np.float32), b.normal[k])

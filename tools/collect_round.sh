@@ -22,11 +22,13 @@ echo "library build $ID" | tee $O/BUILD_ID.txt
 keep() {
   local secs=$1 dst=$2; shift 2
   local tmp=$(mktemp)
-  if timeout $secs "$@" > $tmp 2> $tmp.err && ! grep -q "^Traceback" $tmp $tmp.err; then
+  timeout $secs "$@" > $tmp 2> $tmp.err
+  local status=$?   # (the command's own status, not the grep's: ADVICE r5)
+  if [ $status = 0 ] && ! grep -q "^Traceback" $tmp $tmp.err; then
     { cat $tmp; } > $dst
     case $dst in *.json) ;; *) echo "# library build $ID" >> $dst ;; esac
   else
-    echo "FAILED ($?): $*" | tee -a $O/FAILED.txt; tail -5 $tmp.err | tee -a $O/FAILED.txt
+    echo "FAILED ($status): $*" | tee -a $O/FAILED.txt; tail -5 $tmp.err | tee -a $O/FAILED.txt
     FAILED=1; rm -f $dst
   fi
   rm -f $tmp $tmp.err
