@@ -11,6 +11,7 @@
 #include <iomanip>
 #include <iostream>
 #include <strings.h>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -591,6 +592,55 @@ bool Scene::depthGates(const Patch3d* const* patches, size_t n, float margin, st
     return true;
 }
 
+bool Scene::depthFootprints(const Patch3d* const* patches, size_t n, std::vector<std::vector<uint64_t> >& reads,
+                            std::vector<std::vector<uint64_t> >& writes, int nLevels) const {
+    reads.assign(n, std::vector<uint64_t>());
+    writes.assign(n, std::vector<uint64_t>());
+    hpmvs_scene* dev = deviceScene();
+    if (!dev) return false;
+    if (n == 0) return true;
+    HostBatch hb(patches, n);
+    const size_t M = (size_t)hb.b.max_images, V = cameras_.size();
+    const PinnedAlloc<char> pin(true);
+    PVec<int32_t> wr(n * M * 4, pin), fr(n * M * 4, pin), at(n * M * 3, pin), vb(n * V * 3, pin);
+    if (hpmvs_depth_footprints_batch(dev, &hb.b, wr.data(), fr.data(), at.data(), vb.data(), 0, nullptr) != HPMVS_OK) {
+        std::cerr << "hpmvs: " << hpmvs_last_error() << std::endl;
+        return false;
+    }
+    auto cell = [](int view, int level, int x, int y) {
+        return ((uint64_t)(((unsigned)view << 3) | (unsigned)level) << 48) | ((uint64_t)((unsigned)x & 0xFFFFFFu) << 24) | (uint64_t)((unsigned)y & 0xFFFFFFu);
+    };
+    // the cells Scene::getFullDepth visits for the 3x3 level-0 pixel block from (ix0, iy0) (Scene.cpp:406-432, 538-550)
+    auto full = [&](int view, int ix0, int iy0, std::vector<uint64_t>& out) {
+        int seen[9][2], ns = 0;
+        for (int dy = 0; dy < 3; dy++) for (int dx = 0; dx < 3; dx++) {
+            const int px = ix0 + dx, py = iy0 + dy;
+            if (px < 0 || py < 0) continue;   // (never looked up: depthTest returns first)
+            const int cx = px >> 1, cy = py >> 1;
+            bool dup = false;
+            for (int k = 0; k < ns; k++) dup |= (seen[k][0] == cx && seen[k][1] == cy);
+            if (dup) continue;
+            seen[ns][0] = cx; seen[ns][1] = cy; ns++;
+            int x = cx, y = cy;
+            for (int l = 0; l < nLevels; l++) { out.push_back(cell(view, l, x, y)); x >>= 1; y >>= 1; }
+        }
+    };
+    for (size_t i = 0; i < n; i++) {
+        const size_t m = (size_t)hb.nimg[i];
+        for (size_t k = 0; k < m; k++) {
+            const int32_t* w = &wr[(i * M + k) * 4]; const int32_t* f = &fr[(i * M + k) * 4]; const int32_t* a = &at[(i * M + k) * 3];
+            if (w[0] >= 0) writes[i].push_back(cell(w[0], w[1], w[2], w[3]));
+            if (f[0] >= 0) reads[i].push_back(cell(f[0], f[1], f[2], f[3]));
+            if (a[0] >= 0) full(a[0], a[1], a[2], reads[i]);
+        }
+        for (size_t v = 0; v < V; v++) {
+            const int32_t* b = &vb[(i * V + v) * 3];
+            if (b[0]) full((int)v, b[1], b[2], reads[i]);
+        }
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------- PatchOptimizer
 PatchOptimizer::PatchOptimizer(const mo3d::HpmvsOptions& options, const mo3d::Scene* scene)
     : options_p(&options), scene_p(scene) {}
@@ -805,6 +855,102 @@ int PatchOptimizer::expandBatch(ExpandMode mode, const mo3d::Patch3d* const* par
         }
     }
     return N;
+}
+
+static uint64_t grid_leaf_key(const Eigen::Vector3f& p, float width, void*) {
+    const long long ix = (long long)std::floor(p[0] / width), iy = (long long)std::floor(p[1] / width), iz = (long long)std::floor(p[2] / width);
+    return (uint64_t)(((ix + (1 << 20)) << 42) | ((iy + (1 << 20)) << 21) | (iz + (1 << 20)));
+}
+
+bool PatchOptimizer::extendLevel(const mo3d::Patch3d* const* parents, size_t n, float width, std::unordered_set<uint64_t>& occupied,
+                                 float margin, bool absInt, LevelResult& R, bool sequential, LeafKeyFn leafKey, void* user) {
+    if (!leafKey) leafKey = grid_leaf_key;
+    const size_t N = 6, T = n * N;
+    R = LevelResult();
+    if (n == 0) return true;
+    std::vector<CellRef> cells(n);
+    for (size_t i = 0; i < n; i++) { cells[i].c = Eigen::Vector3f(0.0f, 0.0f, 0.0f); cells[i].width = width; }
+    // the candidates before optimize (everything skipped: constructed only) -> their leaves
+    std::vector<uint8_t> all(T, 1), acc0, skip(T, 0), refined;
+    std::vector<mo3d::Patch3d> pre;
+    expandBatch(EXTEND, parents, cells.data(), n, all.data(), pre, acc0);
+    if (pre.size() != T) return false;
+    std::vector<uint64_t> preKey(T), postKey(T, 0);
+    for (size_t t = 0; t < T; t++) {
+        preKey[t] = leafKey(Eigen::Vector3f(pre[t].center_[0], pre[t].center_[1], pre[t].center_[2]), width, user);
+        skip[t] = occupied.count(preKey[t]) ? 1 : 0;   // level-start occupancy: those are never refined
+    }
+    expandBatch(EXTEND, parents, cells.data(), n, skip.data(), R.candidates, refined);
+    if (R.candidates.size() != T) return false;
+    std::vector<const Patch3d*> ptr(T);
+    for (size_t t = 0; t < T; t++) {
+        ptr[t] = &R.candidates[t];
+        if (skip[t]) refined[t] = 0;
+        if (refined[t]) postKey[t] = leafKey(Eigen::Vector3f(R.candidates[t].center_[0], R.candidates[t].center_[1], R.candidates[t].center_[2]), width, user);
+    }
+    std::vector<std::vector<uint64_t> > reads, writes;
+    if (!scene_p->depthFootprints(ptr.data(), T, reads, writes)) return false;
+    R.stage.assign(T, 1);
+    R.counts.assign(3 * T, -1);
+    std::vector<size_t> pending;
+    for (size_t t = 0; t < T; t++) { if (skip[t]) R.stage[t] = 20; else pending.push_back(t); }
+    const int MIN = options_p->MIN_IMAGES_PER_PATCH;
+    auto hits = [](const std::vector<uint64_t>& cellsOf, const std::unordered_set<uint64_t>& set) {
+        if (set.empty()) return false;
+        for (uint64_t c : cellsOf) if (set.count(c)) return true;
+        return false;
+    };
+    while (!pending.empty()) {
+        R.waves++;
+        std::vector<size_t> todo;
+        for (size_t t : pending) if (refined[t]) todo.push_back(t);
+        std::vector<int> v, b, f;
+        std::vector<const Patch3d*> sub(todo.size());
+        for (size_t k = 0; k < todo.size(); k++) sub[k] = ptr[todo[k]];
+        if (!todo.empty() && !scene_p->depthGates(sub.data(), sub.size(), margin, v, b, f, absInt)) return false;
+        std::vector<int> slot(T, -1);
+        for (size_t k = 0; k < todo.size(); k++) slot[todo[k]] = (int)k;
+        std::unordered_set<uint64_t> dirty, guard, maybeOcc, occGuard;
+        std::vector<size_t> deferred, accNow;
+        auto defer = [&](size_t t) {
+            deferred.push_back(t);
+            occGuard.insert(preKey[t]);
+            if (refined[t]) {
+                dirty.insert(writes[t].begin(), writes[t].end()); guard.insert(reads[t].begin(), reads[t].end());
+                maybeOcc.insert(postKey[t]); occGuard.insert(postKey[t]);
+            }
+        };
+        for (size_t t : pending) {
+            if (occupied.count(preKey[t])) { R.stage[t] = 20; continue; }   // its leaf was taken by an earlier candidate
+            if (sequential && maybeOcc.count(preKey[t])) { defer(t); continue; }
+            if (!refined[t]) { R.stage[t] = 1; continue; }                  // failed in optimize or at the scale / drift gates
+            if (sequential && hits(reads[t], dirty)) { defer(t); continue; }
+            const int k = slot[t];
+            const int cv = v[k], cb = b[k], cf = f[k];
+            R.counts[3 * t] = cv; R.counts[3 * t + 1] = cb; R.counts[3 * t + 2] = cf;
+            if (!(cv >= MIN)) R.stage[t] = 23;
+            else if (!(cb < MIN)) R.stage[t] = 24;
+            else if (!(cf >= MIN - 1 && cf * 1.0 / (double)R.candidates[t].images_.size() > 0.75)) R.stage[t] = 25;
+            else if (occupied.count(postKey[t])) R.stage[t] = 26;
+            else if (sequential && (maybeOcc.count(postKey[t]) || occGuard.count(postKey[t]) || hits(writes[t], guard))) {
+                R.counts[3 * t] = R.counts[3 * t + 1] = R.counts[3 * t + 2] = -1;
+                defer(t);
+            } else {
+                occupied.insert(postKey[t]);
+                R.stage[t] = 0;
+                R.accepted.push_back(t); accNow.push_back(t);
+                dirty.insert(writes[t].begin(), writes[t].end());
+            }
+        }
+        if (!accNow.empty()) {
+            std::vector<const Patch3d*> ap(accNow.size());
+            for (size_t k = 0; k < accNow.size(); k++) ap[k] = ptr[accNow[k]];
+            if (!scene_p->setDepths(ap.data(), ap.size())) return false;
+        }
+        pending.swap(deferred);
+    }
+    std::sort(R.accepted.begin(), R.accepted.end());
+    return true;
 }
 
 }  // namespace mo3d

@@ -8,6 +8,7 @@
 #define HPMVS_PATCHOPTIMIZER_H
 #include <cstddef>
 #include <cstdint>
+#include <unordered_set>
 #include <vector>
 #include <hpmvs/Patch3d.h>
 namespace mo3d {
@@ -33,6 +34,26 @@ public:
     struct CellRef { Eigen::Vector3f c; float width; };
     int expandBatch(ExpandMode mode, const mo3d::Patch3d* const* parents, const CellRef* cells, size_t n,
                     const uint8_t* skip, std::vector<mo3d::Patch3d>& candidates, std::vector<uint8_t>& accepted);
+    // One priority level of CellProcessor::extend (reference src/hpmvs/CellProcessor.cpp:84-178; main.cpp:146-181 pops the leaves of
+    // one priority and runs it on each, one after the other) as a BATCHED frontier with the reference's SEQUENTIAL result: ONE
+    // expandBatch for the level, then conflict-free waves of depthGates / walk in the reference's order / setDepths (a candidate is
+    // decided unless a map cell it reads or would write, or its leaf, still depends on an undecided earlier candidate -- then it
+    // waits for the next wave; hpmvs_amd/frontier.py is the same walk in Python, INTEGRATION.md has the argument).  parents: the
+    // leaves' patches in the scheduler's order; width: the leaves' width; `occupied`: the scheduler's occupancy as a set of leaf
+    // keys, updated in place (the octree itself stays with the scheduler: `leafKey` maps a point to its leaf, default = the
+    // uniform grid floor(p / width)); the scene's depth maps (Scene::resetDepths / setDepths) receive the accepted candidates.
+    // stage: 0 accepted and inserted, 20 leaf already taken (no refinement), 1 refinement or the scale / drift gates failed,
+    // 23 / 24 / 25 depthTests / viewBlockTest / pixelFreeTests, 26 addConditional found the refined patch's leaf taken.
+    struct LevelResult {
+        std::vector<mo3d::Patch3d> candidates;   // 6 per parent
+        std::vector<int> stage;
+        std::vector<int> counts;                 // 3 per candidate: the counts at decision time (-1: not reached)
+        std::vector<size_t> accepted;            // candidate indices, the reference's order
+        int waves = 0;
+    };
+    typedef uint64_t (*LeafKeyFn)(const Eigen::Vector3f& p, float width, void* user);
+    bool extendLevel(const mo3d::Patch3d* const* parents, size_t n, float width, std::unordered_set<uint64_t>& occupied,
+                     float margin, bool absInt, LevelResult& out, bool sequential = true, LeafKeyFn leafKey = nullptr, void* user = nullptr);
     // diagnostics of the last optimize()/optimizeBatch() call that the reference computes and drops
     // (final mean robust INCC f*, PatchOptimizer.cpp:365,376): one entry per patch
     const std::vector<double>& lastObjective() const { return lastF_; }

@@ -40,6 +40,12 @@ public:
     bool setDepths(const Patch3d* const* patches, size_t n) const;
     bool depthGates(const Patch3d* const* patches, size_t n, float margin, std::vector<int>& nVisible,
                     std::vector<int>& nBlocking, std::vector<int>& nFree, bool absInt = false) const;
+    // The map cells those tests READ and the cells setDepths would WRITE, per patch, as packed keys -- what a scheduler needs to
+    // run one priority level in conflict-free waves and still end with the reference's sequential result
+    // (PatchOptimizer::extendLevel).  reads[i]: every cell depthTests / viewBlockTest reach through getFullDepth (3x3 level-0
+    // pixels, every pyramid level) and pixelFreeTests' cell; writes[i]: the cell per attached image.  nLevels: pyramid levels.
+    bool depthFootprints(const Patch3d* const* patches, size_t n, std::vector<std::vector<uint64_t> >& reads,
+                         std::vector<std::vector<uint64_t> >& writes, int nLevels = 6) const;
     std::map<std::string, int> dict_;
     std::vector<Camera> cameras_;
     std::vector<Image> images_;

@@ -5,6 +5,8 @@
 #include <omp.h>
 #include <cstdio>
 #include <cstdlib>
+#include <unordered_set>
+#include <cmath>
 #include <vector>
 
 #include <hpmvs/HpmvsOptions.h>
@@ -137,6 +139,30 @@ int main(int argc, char** argv) {
         for (size_t t = 0; t < acc.size() && fine; t++)
             printf("depth %zu %d %d %d %d %d %d\n", t, vis[t], blk[t], fre[t], vis2[t], blk2[t], fre2[t]);
         if (!fine) printf("depth failed\n");
+    }
+    // (6) one priority level of CellProcessor::extend as a batched frontier with the reference's sequential result
+    //     (PatchOptimizer::extendLevel): the first 60 refined patches are the level's leaves, their depths are in the maps
+    {
+        std::vector<const mo3d::Patch3d*> leaves;
+        for (int i = 0; i < np && leaves.size() < 60; i++) if (ok[i]) leaves.push_back(patches[i].get());
+        if (!leaves.empty()) {
+            const float width = leaves[0]->scale_3dx_ * (2.0f / 0.9f);
+            std::unordered_set<uint64_t> occupied;
+            auto key = [&](const mo3d::Patch3d& p) {
+                const long long ix = (long long)std::floor(p.center_[0] / width), iy = (long long)std::floor(p.center_[1] / width), iz = (long long)std::floor(p.center_[2] / width);
+                return (uint64_t)(((ix + (1 << 20)) << 42) | ((iy + (1 << 20)) << 21) | (iz + (1 << 20)));
+            };
+            for (const mo3d::Patch3d* p : leaves) occupied.insert(key(*p));
+            mo3d::PatchOptimizer::LevelResult R;
+            bool fine = scene.resetDepths() && scene.setDepths(leaves.data(), leaves.size());
+            fine = fine && optimizers[1].extendLevel(leaves.data(), leaves.size(), width, occupied, 1.0f, false, R);
+            if (!fine) printf("level failed\n");
+            else {
+                for (size_t t = 0; t < R.stage.size(); t++)
+                    printf("level %zu %d %d %d %d\n", t, R.stage[t], R.counts[3 * t], R.counts[3 * t + 1], R.counts[3 * t + 2]);
+                printf("levelsummary %d %zu %zu %.9g\n", R.waves, R.accepted.size(), occupied.size(), width);
+            }
+        }
     }
     // (5) the per-thread cache of pinned blocks stays under its cap whatever sizes the rounds have (a frontier
     //     loop whose round size changes every round must not pile up one pinned block per size class)

@@ -98,6 +98,27 @@ def test_cpp_patchoptimizer_equals_c_abi(tiny_scene, tiny_seeds, gpu_scene, tmp_
     got = np.array([[int(t) for t in r[2:8]] for r in rows])
     assert np.array_equal(got, np.stack([v0, b0, f0, v1, b1, f1], axis=1))
     assert (f1 < f0).any() and b0.max() == 0
+    # PatchOptimizer::extendLevel (C++: one level as conflict-free waves) == hpmvs_amd.frontier.extend_level on the same leaves
+    from hpmvs_amd import frontier
+    rows = [l.split() for l in out if l.startswith("level ")]
+    summ = [l.split() for l in out if l.startswith("levelsummary")]
+    assert len(summ) == 1 and rows, [l for l in out if l.startswith("level")][:3]
+    k60 = keep[:60]
+    leaves = api.Batch(batch.center[k60], batch.normal[k60], batch.scale[k60], batch.n_images[k60], batch.images[k60])
+    width = float(np.float32(summ[0][4]))
+    assert np.float32(width) == np.float32(leaves.scale[0] * np.float32(2.0 / 0.9))
+    occ = {frontier.cell_key(leaves.center[k], width) for k in range(leaves.n)}
+    api.depth_reset(gpu_scene)
+    leaves.ok[:] = 1
+    api.set_depths_batch(gpu_scene, leaves)
+    res = frontier.extend_level(gpu_scene, leaves, width, occ, 1.0, 0)
+    assert len(rows) == 6 * leaves.n
+    st_cpp = np.array([int(r[2]) for r in rows]); cnt_cpp = np.array([[int(v) for v in r[3:6]] for r in rows])
+    st_py = np.where(np.isin(res.stage, (0, 20, 23, 24, 25, 26)), res.stage, 1)   # (C++ folds the refinement / gate failures into 1)
+    assert np.array_equal(st_cpp, st_py), np.nonzero(st_cpp != st_py)[0][:10]
+    assert np.array_equal(cnt_cpp, res.counts)
+    assert int(summ[0][1]) == res.waves and int(summ[0][2]) == len(res.accepted) and int(summ[0][3]) == len(occ)
+    assert res.waves > 1 and len(res.accepted) >= 20
 
 
 def _dump_scene(path, scene, seeds, n):
