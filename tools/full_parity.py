@@ -19,6 +19,7 @@ def run(V, W_, H_, N_, SL=4, MI=32, verbose=False):
     b = api.Batch.from_seeds(seeds)
     t0 = time.perf_counter(); api.optimize_batch(g, b); t_gpu = time.perf_counter() - t0
     kernel_ms = g.last_kernel_ms()
+    n_wide = g.last_wide_patches()   # patches whose list outgrew the batch kernel's 64-id rows (redone by kernel_wide.hip)
     osc = orc.OracleScene(scene)
     cores = min(16, os.cpu_count() or 1)
     try:
@@ -84,6 +85,7 @@ def run(V, W_, H_, N_, SL=4, MI=32, verbose=False):
             rows.append(dict(patch=k, stage_oracle=so, stage_gpu=sg, nevals_oracle=no, nevals_gpu=ng, oracle_equals_gpu_with=why))
     known, other = len(ks) - tally['still_differing'], tally['still_differing']
     rec = dict(scene=f"{V} x {W_}x{H_}", start_level=SL, max_images=MI, patches=N_, refined_gpu=int(b.ok.sum()), refined_by_both=refined_both,
+               redone_by_the_wide_kernel=int(n_wide), stage_100_gpu=int((b.stage == 100).sum()), longest_refined_list=int(b.n_images[b.ok.astype(bool)].max()) if b.ok.any() else 0,
                differing=len(differing), attributed_to_libm=int(known), unexplained=int(other), attribution=tally,
                bit_identical_fraction_of_refined=1.0 - len(differing) / max(1, refined_both),
                gpu_kernel_ms=kernel_ms, gpu_call_s=round(t_gpu, 3), oracle_s=round(t_cpu, 1), oracle_threads=cores,
