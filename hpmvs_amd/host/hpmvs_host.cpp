@@ -439,6 +439,7 @@ bool Scene::extractCoVisiblilty(const NVM_Model& model, const HpmvsOptions&) {
 // than the scene's views (addImages never attaches a view twice), so rows of min(views, HPMVS_MAX_IMAGES) ids hold every list
 // that can come back -- but never fewer than HPMVS_FAST_IMAGES, and exactly that for up to four patches (the unchanged
 // callers' optimize()): 64-id rows are what the open batch behind single-patch calls takes.
+static thread_local bool tl_full_rows = false;
 static int list_stride(size_t n_views, size_t n_patches, size_t longest_input) {
     size_t m = n_views > longest_input ? n_views : longest_input;
     if (n_patches <= 4 && longest_input <= (size_t)HPMVS_FAST_IMAGES) m = HPMVS_FAST_IMAGES;
@@ -738,10 +739,12 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
     if (!dev) return 0;
     size_t longest_in = 0;
     for (size_t i = 0; i < n; i++) longest_in = std::max(longest_in, patches[i]->images_.size());
-    const int stride = list_stride(scene_p->cameras_.size(), n, longest_in);
+    // (tl_full_rows: the retry below -- rows as wide as a list can get, whatever the batch size)
+    const int full = list_stride(scene_p->cameras_.size(), (size_t)-1, longest_in);
+    const int stride = tl_full_rows ? full : list_stride(scene_p->cameras_.size(), n, longest_in);
     const PinnedAlloc<char> pin(n > kPinFrom);
     PVec<float> center(4 * n, pin), normal(4 * n, pin), scale(n, pin), color(3 * n, pin), ncc(n, pin);
-    PVec<int32_t> nimg(n, pin), images(n * stride, -1, pin), evals(n, pin);
+    PVec<int32_t> nimg(n, pin), images(n * stride, -1, pin), evals(n, pin), stage(n, pin);
     PVec<double> fmin(n, pin);
     PVec<uint8_t> okp(n, pin);  // (the caller's ok[] is ordinary memory: a copy here keeps the call free of device allocations)
     for (size_t i = 0; i < n; i++) {
@@ -763,12 +766,19 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
     b.center = center.data(); b.normal = normal.data(); b.scale = scale.data();
     b.n_images = nimg.data(); b.images = images.data();
     b.ok = okp.data(); b.color = color.data(); b.ncc = ncc.data(); b.fmin = fmin.data(); b.nevals = evals.data();
+    b.stage = stage.data();
     if (hpmvs_optimize_batch(dev, &o, &b, 0, nullptr) != HPMVS_OK) {
         std::cerr << "patch optimization failed: <" << hpmvs_last_error() << ">" << std::endl;
         for (size_t i = 0; i < n; i++) ok[i] = 0;
         return 0;
     }
     memcpy(ok, okp.data(), n);
+    // The rows of a call of up to four patches are the open batch's 64 ids.  A patch that ends at stage 100 there (its refined
+    // list is longer than that: a dense scene) was left untouched; the reference's list is unbounded, so it is refined again
+    // with rows as wide as a list can get.
+    std::vector<size_t> again;
+    if (stride < full)
+        for (size_t i = 0; i < n; i++) if (!ok[i] && stage[i] == 100) again.push_back(i);
     size_t good = 0;
     for (size_t i = 0; i < n; i++) {
         lastF_[i] = fmin[i];
@@ -781,6 +791,20 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
         p.ncc_ = ncc[i];
         p.color_ = Eigen::Vector3f(color[3 * i], color[3 * i + 1], color[3 * i + 2]);
         good++;
+    }
+    if (!again.empty()) {
+        std::vector<mo3d::Patch3d*> sub(again.size());
+        std::vector<uint8_t> sok(again.size(), 0);
+        for (size_t k = 0; k < again.size(); k++) sub[k] = patches[again[k]];
+        const std::vector<double> f0 = lastF_;
+        const std::vector<int> e0 = lastEvals_;
+        tl_full_rows = true;
+        good += optimizeBatch(sub.data(), sub.size(), sok.data());
+        tl_full_rows = false;
+        const std::vector<double> f1 = lastF_;
+        const std::vector<int> e1 = lastEvals_;
+        lastF_ = f0; lastEvals_ = e0;
+        for (size_t k = 0; k < again.size(); k++) { ok[again[k]] = sok[k]; lastF_[again[k]] = f1[k]; lastEvals_[again[k]] = e1[k]; }
     }
     return good;
 }

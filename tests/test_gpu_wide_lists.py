@@ -97,3 +97,29 @@ def test_seed_lists_longer_than_64_ids_and_rows_of_every_width():
                 assert one64.ok[0] == 1 and np.array_equal(one64.center[0], b.center[k]) and one64.nevals[0] == b.nevals[k]
     finally:
         gpu.close()
+
+
+def test_unchanged_single_patch_callers_on_a_dense_scene(tmp_path):
+    """The reference's calling pattern -- optimize(patch), one patch per call (CellProcessor.cpp:129,256) -- on a scene where the
+    lists outgrow 64 ids: a call goes through the open batch (64-id records), comes back with stage 100, is re-run through a batch
+    launch of its own (capi.hip) and, if its REFINED list is longer than 64 ids, once more with rows as wide as the scene's views
+    (hpmvs_host.cpp).  Every call must give the patch that one optimizeBatch() over all of them gives (rows of min(views, 256))."""
+    import json
+    import subprocess
+    import sys
+    from hpmvs_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    from test_gpu_cpp_interface import _dump_scene
+    exe = os.path.join(root, "tests", "native", "bench_callers")
+    scene = synth.make_scene(120, 640, 360, n_waves=16)
+    n = 160
+    seeds = synth.make_seeds(scene, n, start_level=1, max_images=256, seed=synth.SEED + 22)
+    dump = tmp_path / "dense.bin"
+    _dump_scene(dump, scene, seeds, n)
+    env = dict(os.environ, HPMVS_SERVICE="1", OMP_WAIT_POLICY="passive")
+    r = subprocess.run([exe, str(dump), "8"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    row = json.loads(r.stdout.strip().splitlines()[-1])
+    print(row)
+    assert row["mismatches"] == 0 and row["refined"] > n // 2, row
