@@ -666,9 +666,14 @@ static ref_bobyqa_fn load_port_bobyqa(void);
 static ref_bobyqa_fn g_ref_bobyqa = NULL;
 static int g_ref_tried = 0;
 
+/* (first use may come from many OpenMP threads at once: the flag goes up only after the pointer is in place) */
 static ref_bobyqa_fn load_ref_bobyqa(void) {
-    if (g_ref_tried) return g_ref_bobyqa;
-    g_ref_tried = 1;
+    if (__atomic_load_n(&g_ref_tried, __ATOMIC_ACQUIRE) == 2) return g_ref_bobyqa;
+    int expected = 0;
+    if (!__atomic_compare_exchange_n(&g_ref_tried, &expected, 1, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+        while (__atomic_load_n(&g_ref_tried, __ATOMIC_ACQUIRE) != 2) { }
+        return g_ref_bobyqa;
+    }
     Dl_info info;
     char path[4096];
     if (dladdr((void *)&load_ref_bobyqa, &info) && info.dli_fname) {
@@ -679,12 +684,17 @@ static ref_bobyqa_fn load_ref_bobyqa(void) {
         void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
         if (h) g_ref_bobyqa = (ref_bobyqa_fn)dlsym(h, "ref_bobyqa_run");
     }
+    __atomic_store_n(&g_ref_tried, 2, __ATOMIC_RELEASE);
     return g_ref_bobyqa;
 }
 
 static ref_bobyqa_fn load_port_bobyqa(void) {
-    if (g_port_tried) return g_port_bobyqa;
-    g_port_tried = 1;
+    if (__atomic_load_n(&g_port_tried, __ATOMIC_ACQUIRE) == 2) return g_port_bobyqa;
+    int expected = 0;
+    if (!__atomic_compare_exchange_n(&g_port_tried, &expected, 1, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+        while (__atomic_load_n(&g_port_tried, __ATOMIC_ACQUIRE) != 2) { }
+        return g_port_bobyqa;
+    }
     Dl_info info;
     char path[4096];
     if (dladdr((void *)&load_port_bobyqa, &info) && info.dli_fname) {
@@ -695,6 +705,7 @@ static ref_bobyqa_fn load_port_bobyqa(void) {
         void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
         if (h) g_port_bobyqa = (ref_bobyqa_fn)dlsym(h, "orc_port_bobyqa");
     }
+    __atomic_store_n(&g_port_tried, 2, __ATOMIC_RELEASE);
     return g_port_bobyqa;
 }
 

@@ -123,3 +123,65 @@ def test_unchanged_single_patch_callers_on_a_dense_scene(tmp_path):
     row = json.loads(r.stdout.strip().splitlines()[-1])
     print(row)
     assert row["mismatches"] == 0 and row["refined"] > n // 2, row
+
+
+def test_hostile_and_overflowing_patches_in_the_wide_kernel():
+    """What the batch kernel survives (tests/test_gpu_hostile_patches.py) the wide kernel must survive too, with the oracle's decision:
+    non-finite and degenerate patches whose lists are long enough to be redone by it, an image attached several times, and lists
+    that would outgrow even 256 ids (a 300-view scene: both sides end at stage 100, patch untouched).  The neighbours are unaffected."""
+    import torch
+    from hpmvs_amd import api, synth
+    from oracle import oracle as orc
+    scene = synth.make_scene(300, 320, 180, n_waves=12, device=torch.device("cuda", 0))
+    gpu = api.Scene(scene, device=0)
+    try:
+        n = 240
+        seeds = synth.make_seeds(scene, n, start_level=0, max_images=256, max_seed_images=100, seed=synth.SEED + 23)
+        assert seeds.n_images.max() > 64
+        clean = api.Batch.from_seeds(seeds)
+        api.optimize_batch(gpu, clean)
+        n_wide_clean = gpu.last_wide_patches()
+        mixed = api.Batch.from_seeds(seeds)
+        nan, inf = np.float32(np.nan), np.float32(np.inf)
+        long_ones = [int(k) for k in np.nonzero(seeds.n_images > 70)[0][:8]]
+        assert len(long_ones) == 8
+        hostile = {
+            long_ones[0]: lambda b, k: b.center.__setitem__((k, 0), nan),
+            long_ones[1]: lambda b, k: b.normal.__setitem__((k, slice(0, 3)), 0.0),
+            long_ones[2]: lambda b, k: b.scale.__setitem__(k, 0.0),
+            long_ones[3]: lambda b, k: b.scale.__setitem__(k, nan),
+            long_ones[4]: lambda b, k: b.center.__setitem__((k, slice(0, 3)), inf),
+            long_ones[5]: lambda b, k: b.images.__setitem__((k, slice(0, 5)), b.images[k, 0]),   # the same image five times
+            long_ones[6]: lambda b, k: b.scale.__setitem__(k, np.float32(1e30)),
+            long_ones[7]: lambda b, k: b.normal.__setitem__((k, 1), nan),
+        }
+        for k, f in hostile.items():
+            f(mixed, k)
+        before = {f: getattr(mixed, f).copy() for f in ("center", "normal", "scale", "n_images", "images")}
+        api.optimize_batch(gpu, mixed)    # must return
+        assert gpu.last_wide_patches() >= 8
+        good = np.array([k for k in range(n) if k not in hostile])
+        for f in ("ok", "center", "normal", "n_images", "images", "color", "fmin", "nevals", "stage", "ngrabs"):
+            assert np.array_equal(getattr(mixed, f)[good], getattr(clean, f)[good]), f
+        osc = orc.OracleScene(scene)
+        hs = synth.Seeds(center=before["center"], normal=before["normal"], scale=before["scale"], n_images=before["n_images"],
+                         images=before["images"], truth=np.zeros((n, 3)))
+        P = orc.patches_from_seeds(hs)
+        orc.optimize_batch(osc, P, which=orc.OPT_REF, n_threads=os.cpu_count() or 8)
+        st = np.array([p.stage for p in P])
+        assert np.array_equal(st, mixed.stage), (np.nonzero(st != mixed.stage)[0][:10], st[st != mixed.stage][:10], mixed.stage[st != mixed.stage][:10])
+        for k in range(n):
+            if mixed.ok[k]:
+                assert np.all(np.isfinite(mixed.center[k])) and np.all(np.isfinite(mixed.normal[k]))
+                assert np.array_equal(np.array(P[k].center[:], dtype=np.float32), mixed.center[k]), k
+                assert list(P[k].images[:P[k].n_images]) == list(mixed.images[k, :mixed.n_images[k]]) and P[k].nevals == mixed.nevals[k], k
+            else:
+                assert mixed.center[k].tobytes() == before["center"][k].tobytes() and np.array_equal(mixed.images[k], before["images"][k]), k
+        rep = dict(tag="300v_320x180_start_level_0_hostile", patches=n, redone_by_the_wide_kernel_clean=int(n_wide_clean), refined=int(mixed.ok.sum()),
+                   stage_histogram={int(s): int(c) for s, c in zip(*np.unique(mixed.stage, return_counts=True))},
+                   hostile={int(k): (int(mixed.ok[k]), int(mixed.stage[k])) for k in hostile})
+        print(rep)
+        with open("gpurun_out/wide_lists.jsonl", "a") as fh:
+            fh.write(json.dumps(rep) + "\n")
+    finally:
+        gpu.close()
