@@ -32,7 +32,7 @@ __device__ __forceinline__ int level_rounded(const DevView& V, const float* c, f
     const float d0 = c[0] - V.center[0], d1 = c[1] - V.center[1], d2 = c[2] - V.center[2];
     const float fz = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
     const float lv = (float)log2((double)(scale * V.fsum) / (2.0 * (double)fz));
-    return (int)roundf(lv);
+    return cvt_i32_x86(roundf(lv));
 }
 // Camera::mult at `level` (Camera.h:76-78): P[level] = diag(2^-l, 2^-l, 1) * P0 exactly
 __device__ __forceinline__ void mult_level(const DevView& V, const float* c, int level, float* r) {
@@ -70,7 +70,7 @@ __device__ __forceinline__ void depth_test_block(const DevView& V, const float* 
     float m[3];
     mult_level(V, c, 0, m);
     depth = m[2];
-    ix0 = (int)((double)(m[0] / m[2]) + 0.5) - 1; iy0 = (int)((double)(m[1] / m[2]) + 0.5) - 1;
+    ix0 = cvt_i32_x86((double)(m[0] / m[2]) + 0.5) - 1; iy0 = cvt_i32_x86((double)(m[1] / m[2]) + 0.5) - 1;
 }
 // the one cell Scene::pixelFreeTest reads (Scene.cpp:590-604); false: it returns before reading a cell
 __device__ __forceinline__ bool pixel_free_cell(const DevView& V, const DevDepthView& D, const float* c, float scale, int& level, int& x, int& y) {
@@ -78,7 +78,7 @@ __device__ __forceinline__ bool pixel_free_cell(const DevView& V, const DevDepth
     if (!(level >= 0 && level < V.n_levels)) return false;
     float r[3];
     project_level(V, c, level, r);
-    const int ix = (int)((double)(r[0] / r[2]) + 0.5), iy = (int)((double)(r[1] / r[2]) + 0.5);
+    const int ix = cvt_i32_x86((double)(r[0] / r[2]) + 0.5), iy = cvt_i32_x86((double)(r[1] / r[2]) + 0.5);
     if (ix < 0 || ix >= V.w[level] || iy < 0 || iy >= V.h[level]) return false;
     x = sub_index(ix); y = sub_index(iy);
     return !(x < 0 || x >= D.cols[level] || y < 0 || y >= D.rows[level]);
@@ -90,7 +90,7 @@ __device__ __forceinline__ bool set_depths_cell(const DevScene& sc, const DevVie
     level = level_clamped(sc, scale, V.fsum, sqrtf((d0 * d0 + d1 * d1) + d2 * d2), V.n_levels - 1);
     float m[3];
     mult_level(V, c, level, m);
-    x = sub_index((int)((double)(m[0] / m[2]) + 0.5)); y = sub_index((int)((double)(m[1] / m[2]) + 0.5));
+    x = sub_index(cvt_i32_x86((double)(m[0] / m[2]) + 0.5)); y = sub_index(cvt_i32_x86((double)(m[1] / m[2]) + 0.5));
     d = m[2];
     if (x < 0 || x >= D.cols[level] || y < 0 || y >= D.rows[level]) return false;
     return m[2] >= 0.0f;  // (the reference CHECK-fails on a negative depth)
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) depth_gates_kernel(DevScene sc, const Dev
                 if (level >= 0 && level < V.n_levels) {
                     float r[3];
                     project_level(V, c, level, r);
-                    const int ix = (int)((double)(r[0] / r[2]) + 0.5), iy = (int)((double)(r[1] / r[2]) + 0.5);
+                    const int ix = cvt_i32_x86((double)(r[0] / r[2]) + 0.5), iy = cvt_i32_x86((double)(r[1] / r[2]) + 0.5);
                     if (!(ix < 0 || ix >= V.w[level] || iy < 0 || iy >= V.h[level])) {
                         const DevDepthView& D = depths[idx];
                         int fl, x, y;

@@ -158,7 +158,7 @@ __device__ __noinline__ int wide_sort_images(ListEnv le, int m, const float* c, 
     const DevView& V0 = le.views[w_list[0]];
     const float dd[3] = {c[0] - V0.center[0], c[1] - V0.center[1], c[2] - V0.center[2]};
     const float fz0 = sqrtf(dot3f(dd, dd));
-    int refLevel = (int)roundf((float)log2((double)(scale * V0.fsum) / (2.0 * (double)fz0)));
+    int refLevel = cvt_i32_x86(roundf((float)log2((double)(scale * V0.fsum) / (2.0 * (double)fz0))));
     refLevel = refLevel < le.MAXLEVEL - 1 ? refLevel : le.MAXLEVEL - 1;
     refLevel = refLevel > 0 ? refLevel : 0;
     float nn[3];

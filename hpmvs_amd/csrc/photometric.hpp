@@ -63,6 +63,13 @@ __device__ __forceinline__ const uint8_t* bcast_p(const uint8_t* p, int src_lane
     return (const uint8_t*)(((unsigned long long)hi << 32) | lo);
 }
 
+// `(int)x` as the reference's x86 code executes it (cvttss2si / cvttsd2si): truncation towards zero, and the "integer indefinite"
+// 0x80000000 for a NaN or a value outside the int range -- where the GPU's v_cvt_i32_* gives 0 / saturates.  Used wherever a
+// float that a hostile patch can make non-finite becomes a pyramid level or a pixel index that GATES something (round 6: a NaN scale
+// made addImages attach views on the device -- level "0" passes its level gate -- that the reference, with level INT_MIN, skips).
+__device__ __forceinline__ int cvt_i32_x86(float v) { return (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000; }
+__device__ __forceinline__ int cvt_i32_x86(double v) { return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : (int)0x80000000; }
+
 // ------------------------------------------------------------------------------------------
 // per-lane scalar helpers (float32 in the reference's evaluation order)
 

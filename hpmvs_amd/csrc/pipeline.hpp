@@ -91,7 +91,7 @@ __device__ __forceinline__ bool add_images_test(const DevView& V, const OP& o, c
     const float dd[3] = {c[0] - V.center[0], c[1] - V.center[1], c[2] - V.center[2]};
     const float fz = sqrtf(dot3f(dd, dd));
     const float lv = (float)log2((double)(scale * V.fsum) / (2.0 * (double)fz));
-    const int il = (int)roundf(lv);
+    const int il = cvt_i32_x86(roundf(lv));
     if (il < o.MINLEVEL || il >= o.MAXLEVEL - 2) return false;
     float P[12];
     for (int k = 0; k < 12; k++) P[k] = V.P0[k];
@@ -142,7 +142,7 @@ __device__ __forceinline__ int coop_sort_images(const SC& sc, const OP& o, int& 
         const DevView& V0 = sc.views[bcast_i(id, 0)];
         const float dd[3] = {c[0] - V0.center[0], c[1] - V0.center[1], c[2] - V0.center[2]};
         const float fz0 = sqrtf(dot3f(dd, dd));
-        int refLevel = (int)roundf((float)log2((double)(scale * V0.fsum) / (2.0 * (double)fz0)));
+        int refLevel = cvt_i32_x86(roundf((float)log2((double)(scale * V0.fsum) / (2.0 * (double)fz0))));
         refLevel = refLevel < o.MAXLEVEL - 1 ? refLevel : o.MAXLEVEL - 1;
         refLevel = refLevel > 0 ? refLevel : 0;
         float nn[3];

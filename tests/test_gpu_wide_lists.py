@@ -128,11 +128,11 @@ def test_unchanged_single_patch_callers_on_a_dense_scene(tmp_path):
 def test_hostile_and_overflowing_patches_in_the_wide_kernel():
     """What the batch kernel survives (tests/test_gpu_hostile_patches.py) the wide kernel must survive too, with the oracle's decision:
     non-finite and degenerate patches whose lists are long enough to be redone by it, an image attached several times, and lists
-    that would outgrow even 256 ids (a 300-view scene: both sides end at stage 100, patch untouched).  The neighbours are unaffected."""
+    that outgrow even 256 ids (a 600-view scene: both sides end at stage 100, patch untouched).  The neighbours are unaffected."""
     import torch
     from hpmvs_amd import api, synth
     from oracle import oracle as orc
-    scene = synth.make_scene(300, 320, 180, n_waves=12, device=torch.device("cuda", 0))
+    scene = synth.make_scene(600, 160, 90, n_waves=12, device=torch.device("cuda", 0))
     gpu = api.Scene(scene, device=0)
     try:
         n = 240
@@ -177,7 +177,8 @@ def test_hostile_and_overflowing_patches_in_the_wide_kernel():
                 assert list(P[k].images[:P[k].n_images]) == list(mixed.images[k, :mixed.n_images[k]]) and P[k].nevals == mixed.nevals[k], k
             else:
                 assert mixed.center[k].tobytes() == before["center"][k].tobytes() and np.array_equal(mixed.images[k], before["images"][k]), k
-        rep = dict(tag="300v_320x180_start_level_0_hostile", patches=n, redone_by_the_wide_kernel_clean=int(n_wide_clean), refined=int(mixed.ok.sum()),
+        assert (mixed.stage == 100).sum() >= 5, "the scene does not push any list beyond 256 ids"   # (both sides: st == mixed.stage above)
+        rep = dict(tag="600v_160x90_start_level_0_hostile", patches=n, redone_by_the_wide_kernel_clean=int(n_wide_clean), refined=int(mixed.ok.sum()),
                    stage_histogram={int(s): int(c) for s, c in zip(*np.unique(mixed.stage, return_counts=True))},
                    hostile={int(k): (int(mixed.ok[k]), int(mixed.stage[k])) for k in hostile})
         print(rep)
