@@ -16,6 +16,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <omp.h>
 
 #include <hpmvs/Camera.h>
 #include <hpmvs/HpmvsOptions.h>
@@ -593,51 +594,237 @@ bool Scene::depthGates(const Patch3d* const* patches, size_t n, float margin, st
     return true;
 }
 
+namespace {
+// A depth-map cell as a key: (view, pyramid level, x, y)
+inline uint64_t cell_key(int view, int level, int x, int y) {
+    return ((uint64_t)(((unsigned)view << 3) | (unsigned)level) << 48) | ((uint64_t)((unsigned)x & 0xFFFFFFu) << 24) | (uint64_t)((unsigned)y & 0xFFFFFFu);
+}
+// What hpmvs_depth_footprints_batch returns, kept as it comes (PatchOptimizer::extendLevel walks these arrays directly: a level of
+// 1e5 candidates of a 50-view scene is ~1e8 cell keys once every getFullDepth block is written out per pyramid level -- the
+// vectors of Scene::depthFootprints -- and building those took longer than everything the GPU does for the level).
+//   wr [n][M][4]: the cell setDepths would write per attached image (view, level, x, y; view < 0: none)
+//   fr [n][M][4]: pixelFreeTests' cell per attached image
+//   at [n][M][3]: depthTests' 3x3 level-0 pixel block per attached image (view, ix0, iy0)
+//   vb [n][V][3]: viewBlockTest's block per view of the scene (examined?, ix0, iy0)
+struct RawFootprints {
+    size_t n = 0, M = 0, V = 0;
+    PVec<int32_t> nimg, wr, fr, at, vb;
+    RawFootprints() : nimg(PinnedAlloc<int32_t>(true)), wr(PinnedAlloc<int32_t>(true)), fr(PinnedAlloc<int32_t>(true)),
+                      at(PinnedAlloc<int32_t>(true)), vb(PinnedAlloc<int32_t>(true)) {}
+};
+bool raw_footprints(const Scene& sc, const Patch3d* const* patches, size_t n, RawFootprints& F) {
+    hpmvs_scene* dev = sc.deviceScene();
+    if (!dev) return false;
+    F.n = n; F.V = sc.cameras_.size(); F.M = 1;
+    if (n == 0) return true;
+    HostBatch hb(patches, n);
+    F.M = (size_t)hb.b.max_images;
+    F.nimg.assign(hb.nimg.begin(), hb.nimg.end());
+    F.wr.resize(n * F.M * 4); F.fr.resize(n * F.M * 4); F.at.resize(n * F.M * 3); F.vb.resize(n * F.V * 3);
+    if (hpmvs_depth_footprints_batch(dev, &hb.b, F.wr.data(), F.fr.data(), F.at.data(), F.vb.data(), 0, nullptr) != HPMVS_OK) {
+        std::cerr << "hpmvs: " << hpmvs_last_error() << std::endl;
+        return false;
+    }
+    return true;
+}
+// The cells Scene::getFullDepth visits for the 3x3 level-0 pixel block from (ix0, iy0) (Scene.cpp:406-432, 538-550): the pixel's
+// map cell is pixel / DEPTH_SUBSAMPLE, on level l that cell >> l; pixels with a negative coordinate are never looked up
+// (depthTest returns first).  Per level the block's cells are a rectangle of 1 or 2 cells each way: fn(key) for each of them,
+// once; stops and returns true as soon as fn does.
+template <class Fn>
+inline bool for_block_cells(int view, int ix0, int iy0, int nLevels, Fn&& fn) {
+    const int x1 = ix0 + 2, y1 = iy0 + 2;
+    if (x1 < 0 || y1 < 0) return false;
+    const int x0 = ix0 < 0 ? 0 : ix0, y0 = iy0 < 0 ? 0 : iy0;
+    for (int l = 0; l < nLevels; l++) {
+        const int xs = x0 >> (1 + l), xe = x1 >> (1 + l), ys = y0 >> (1 + l), ye = y1 >> (1 + l);
+        for (int y = ys; y <= ye; y++)
+            for (int x = xs; x <= xe; x++)
+                if (fn(cell_key(view, l, x, y))) return true;
+    }
+    return false;
+}
+// every cell candidate i READS (depthTests' and viewBlockTest's blocks on every level, pixelFreeTests' cells)
+template <class Fn>
+inline bool for_read_cells(const RawFootprints& F, size_t i, int nLevels, Fn&& fn) {
+    const size_t m = (size_t)F.nimg[i];
+    for (size_t k = 0; k < m; k++) {
+        const int32_t* f = &F.fr[(i * F.M + k) * 4]; const int32_t* a = &F.at[(i * F.M + k) * 3];
+        if (f[0] >= 0 && fn(cell_key(f[0], f[1], f[2], f[3]))) return true;
+        if (a[0] >= 0 && for_block_cells(a[0], a[1], a[2], nLevels, fn)) return true;
+    }
+    for (size_t v = 0; v < F.V; v++) {
+        const int32_t* b = &F.vb[(i * F.V + v) * 3];
+        if (b[0] && for_block_cells((int)v, b[1], b[2], nLevels, fn)) return true;
+    }
+    return false;
+}
+// every cell setDepths would WRITE for candidate i
+template <class Fn>
+inline bool for_write_cells(const RawFootprints& F, size_t i, Fn&& fn) {
+    const size_t m = (size_t)F.nimg[i];
+    for (size_t k = 0; k < m; k++) {
+        const int32_t* w = &F.wr[(i * F.M + k) * 4];
+        if (w[0] >= 0 && fn(cell_key(w[0], w[1], w[2], w[3]))) return true;
+    }
+    return false;
+}
+// a set of 64-bit keys: open addressing, linear probing (the walk of extendLevel does ~1e7 look-ups per wave)
+struct FlatSet {
+    std::vector<uint64_t> t;
+    size_t mask = 0, n = 0;
+    FlatSet() { t.assign(1024, 0); mask = 1023; }
+    static inline size_t mix(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return (size_t)k; }
+    void clear() { if (n) { if (t.size() > 4096 && 8 * n < t.size()) { t.assign(t.size() / 2, 0); mask = t.size() - 1; } else std::fill(t.begin(), t.end(), 0); n = 0; } }
+    bool empty() const { return n == 0; }
+    bool has(uint64_t k) const {
+        if (!n) return false;
+        k += 1;   // (0 marks an empty slot; no key is all ones)
+        for (size_t i = mix(k) & mask;; i = (i + 1) & mask) { const uint64_t v = t[i]; if (v == k) return true; if (!v) return false; }
+    }
+    void add(uint64_t k) {
+        if (2 * (n + 1) > t.size()) grow();
+        k += 1;
+        for (size_t i = mix(k) & mask;; i = (i + 1) & mask) { if (t[i] == k) return; if (!t[i]) { t[i] = k; n++; return; } }
+    }
+    void grow() {
+        std::vector<uint64_t> old; old.swap(t);
+        t.assign(old.size() * 2, 0); mask = t.size() - 1;
+        for (uint64_t k : old) if (k) { for (size_t i = mix(k) & mask;; i = (i + 1) & mask) if (!t[i]) { t[i] = k; break; } }
+    }
+};
+// Who can influence whom inside one level, computed ONCE from the footprints (they do not change between the waves):
+//   flow[t]: the candidates u < t that would WRITE a cell t reads   (t must wait while such a u is accepted in this wave or undecided)
+//   anti[t]: the candidates d < t that READ a cell t would write    (t must not be entered while such a d is undecided)
+// A read block (3x3 level-0 pixels, every pyramid level) meets a write (view, l, x, y) iff on level l the block's cell rectangle
+// contains (x, y); a pixelFreeTests read meets it iff it is that very cell.  Writes are indexed by (view, 2^S x 2^S level-0 cells)
+// buckets -- a write on level l <= S lies in exactly one -- and every read looks at the 1-4 buckets it touches: ~1e7 rectangle
+// tests for 1e5 candidates of a 50-view scene, where the sets of cell keys this replaces did ~1e7 hash insertions and look-ups
+// per wave.  Indices are positions in the footprint list, which is in candidate (= walk) order.
+struct ConflictGraph {
+    std::vector<uint32_t> flow_off, flow_adj, anti_off, anti_adj;
+};
+void build_conflict_graph(const RawFootprints& F, int nLevels, int maxW, int maxH, ConflictGraph& G) {
+    const size_t n = F.n;
+    const int S = nLevels - 1;
+    // bucket size: 2^B x 2^B level-0 cells, B = the level most writes are on (a write on level l <= B lies in one bucket, one on a
+    // higher level is entered in the (2^(l-B))^2 buckets it covers), coarser if that would be more than ~16 M buckets
+    size_t hist[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n_writes = 0;
+    for (size_t i = 0; i < n; i++)
+        for (size_t k = 0; k < (size_t)F.nimg[i]; k++) { const int32_t* w = &F.wr[(i * F.M + k) * 4]; if (w[0] >= 0 && (size_t)w[0] < F.V && w[1] >= 0 && w[1] < nLevels) { hist[w[1] & 7]++; n_writes++; } }
+    int B = 1;
+    { size_t acc = 0; for (int l = 0; l < nLevels; l++) { acc += hist[l]; if (2 * acc >= n_writes) { B = l; break; } } }
+    B = B < 1 ? 1 : (B > S ? S : B);
+    auto dims = [&](int b, int& nx, int& ny) { nx = (((maxW + 1) / 2) >> b) + 2; ny = (((maxH + 1) / 2) >> b) + 2; };
+    int nbx, nby;
+    dims(B, nbx, nby);
+    while (B < S && F.V * (size_t)nbx * (size_t)nby > ((size_t)1 << 24)) { B++; dims(B, nbx, nby); }
+    auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+    auto bucket = [&](int view, int bx, int by) { return ((size_t)view * (size_t)nby + (size_t)by) * (size_t)nbx + (size_t)bx; };
+    struct Wr { uint32_t cand; int32_t l, x, y; };
+    const size_t nb = F.V * (size_t)nbx * (size_t)nby;
+    std::vector<uint32_t> boff(nb + 1, 0);
+    // the buckets a cell (level l, x, y) covers: [bx0, bx1] x [by0, by1] (clamped: the buckets only preselect, the test is exact)
+    auto cover = [&](int l, int x, int y, int& bx0, int& bx1, int& by0, int& by1) {
+        if (l <= B) { bx0 = bx1 = clampi(x >> (B - l), nbx - 1); by0 = by1 = clampi(y >> (B - l), nby - 1); }
+        else {
+            const long long sx = (long long)x << (l - B), sy = (long long)y << (l - B), w = ((long long)1 << (l - B)) - 1;
+            bx0 = clampi((int)std::min<long long>(sx, nbx), nbx - 1); bx1 = clampi((int)std::min<long long>(sx + w, nbx), nbx - 1);
+            by0 = clampi((int)std::min<long long>(sy, nby), nby - 1); by1 = clampi((int)std::min<long long>(sy + w, nby), nby - 1);
+        }
+    };
+    auto each_write = [&](auto&& fn) {
+        for (size_t i = 0; i < n; i++)
+            for (size_t k = 0; k < (size_t)F.nimg[i]; k++) {
+                const int32_t* w = &F.wr[(i * F.M + k) * 4];
+                if (w[0] < 0 || (size_t)w[0] >= F.V || w[1] < 0 || w[1] >= nLevels) continue;   // (a level the gates never read)
+                int bx0, bx1, by0, by1;
+                cover(w[1], w[2], w[3], bx0, bx1, by0, by1);
+                for (int by = by0; by <= by1; by++) for (int bx = bx0; bx <= bx1; bx++) fn(bucket(w[0], bx, by), Wr{(uint32_t)i, w[1], w[2], w[3]});
+            }
+    };
+    each_write([&](size_t b, const Wr&) { boff[b + 1]++; });
+    for (size_t b = 0; b < nb; b++) boff[b + 1] += boff[b];
+    std::vector<Wr> wl(boff[nb]);
+    {
+        std::vector<uint32_t> fill(boff.begin(), boff.end() - 1);
+        each_write([&](size_t b, const Wr& w) { wl[fill[b]++] = w; });
+    }
+    // the readers, in parallel: every thread collects the edges of its share of the candidates
+    std::vector<std::pair<uint32_t, uint32_t> > e_flow, e_anti;   // (node, neighbour)
+    const int n_threads = n < 2048 ? 1 : std::min(omp_get_max_threads(), 32);   // (a cgroup quota is usually far below the hardware threads)
+#pragma omp parallel num_threads(n_threads)
+    {
+        std::vector<std::pair<uint32_t, uint32_t> > my_flow, my_anti;
+        std::vector<uint32_t> seen(n, 0xFFFFFFFFu);   // seen[writer] == reader: that pair is already in the lists
+        auto emit = [&](uint32_t reader, uint32_t writer) {
+            if (seen[writer] == reader) return;
+            seen[writer] = reader;
+            if (writer < reader) my_flow.emplace_back(reader, writer); else my_anti.emplace_back(writer, reader);
+        };
+        auto block = [&](uint32_t i, int view, int ix0, int iy0) {
+            const int x1 = ix0 + 2, y1 = iy0 + 2;
+            if (x1 < 0 || y1 < 0 || view < 0 || (size_t)view >= F.V) return;
+            const int x0 = ix0 < 0 ? 0 : ix0, y0 = iy0 < 0 ? 0 : iy0;
+            const int bxs = clampi((x0 >> 1) >> B, nbx - 1), bxe = clampi((x1 >> 1) >> B, nbx - 1), bys = clampi((y0 >> 1) >> B, nby - 1), bye = clampi((y1 >> 1) >> B, nby - 1);
+            for (int by = bys; by <= bye; by++)
+                for (int bx = bxs; bx <= bxe; bx++) {
+                    const size_t b = bucket(view, bx, by);
+                    for (uint32_t q = boff[b]; q < boff[b + 1]; q++) {
+                        const Wr& w = wl[q];
+                        if (w.cand == i) continue;
+                        const int sh = 1 + w.l;
+                        if (w.x >= (x0 >> sh) && w.x <= (x1 >> sh) && w.y >= (y0 >> sh) && w.y <= (y1 >> sh)) emit(i, w.cand);
+                    }
+                }
+        };
+#pragma omp for schedule(dynamic, 256) nowait
+        for (long long ii = 0; ii < (long long)n; ii++) {
+            const size_t i = (size_t)ii;
+            const size_t m = (size_t)F.nimg[i];
+            for (size_t k = 0; k < m; k++) {
+                const int32_t* f = &F.fr[(i * F.M + k) * 4]; const int32_t* a = &F.at[(i * F.M + k) * 3];
+                if (f[0] >= 0 && (size_t)f[0] < F.V && f[1] >= 0 && f[1] < nLevels) {   // pixelFreeTests: one cell on its own level
+                    int bx0, bx1, by0, by1;
+                    cover(f[1], f[2], f[3], bx0, bx1, by0, by1);
+                    const size_t b = bucket(f[0], bx0, by0);   // (any bucket the cell covers holds every write of that very cell)
+                    for (uint32_t q = boff[b]; q < boff[b + 1]; q++) { const Wr& w = wl[q]; if (w.cand != (uint32_t)i && w.l == f[1] && w.x == f[2] && w.y == f[3]) emit((uint32_t)i, w.cand); }
+                }
+                if (a[0] >= 0) block((uint32_t)i, a[0], a[1], a[2]);
+            }
+            for (size_t v = 0; v < F.V; v++) {
+                const int32_t* b = &F.vb[(i * F.V + v) * 3];
+                if (b[0]) block((uint32_t)i, (int)v, b[1], b[2]);
+            }
+        }
+#pragma omp critical
+        {
+            e_flow.insert(e_flow.end(), my_flow.begin(), my_flow.end());
+            e_anti.insert(e_anti.end(), my_anti.begin(), my_anti.end());
+        }
+    }
+    auto csr = [&](std::vector<std::pair<uint32_t, uint32_t> >& e, std::vector<uint32_t>& off, std::vector<uint32_t>& adj) {
+        off.assign(n + 1, 0);
+        for (auto& p : e) off[p.first + 1]++;
+        for (size_t i = 0; i < n; i++) off[i + 1] += off[i];
+        adj.resize(e.size());
+        std::vector<uint32_t> fill(off.begin(), off.end() - 1);
+        for (auto& p : e) adj[fill[p.first]++] = p.second;
+    };
+    csr(e_flow, G.flow_off, G.flow_adj);
+    csr(e_anti, G.anti_off, G.anti_adj);
+}
+}  // namespace
+
 bool Scene::depthFootprints(const Patch3d* const* patches, size_t n, std::vector<std::vector<uint64_t> >& reads,
                             std::vector<std::vector<uint64_t> >& writes, int nLevels) const {
     reads.assign(n, std::vector<uint64_t>());
     writes.assign(n, std::vector<uint64_t>());
-    hpmvs_scene* dev = deviceScene();
-    if (!dev) return false;
-    if (n == 0) return true;
-    HostBatch hb(patches, n);
-    const size_t M = (size_t)hb.b.max_images, V = cameras_.size();
-    const PinnedAlloc<char> pin(true);
-    PVec<int32_t> wr(n * M * 4, pin), fr(n * M * 4, pin), at(n * M * 3, pin), vb(n * V * 3, pin);
-    if (hpmvs_depth_footprints_batch(dev, &hb.b, wr.data(), fr.data(), at.data(), vb.data(), 0, nullptr) != HPMVS_OK) {
-        std::cerr << "hpmvs: " << hpmvs_last_error() << std::endl;
-        return false;
-    }
-    auto cell = [](int view, int level, int x, int y) {
-        return ((uint64_t)(((unsigned)view << 3) | (unsigned)level) << 48) | ((uint64_t)((unsigned)x & 0xFFFFFFu) << 24) | (uint64_t)((unsigned)y & 0xFFFFFFu);
-    };
-    // the cells Scene::getFullDepth visits for the 3x3 level-0 pixel block from (ix0, iy0) (Scene.cpp:406-432, 538-550)
-    auto full = [&](int view, int ix0, int iy0, std::vector<uint64_t>& out) {
-        int seen[9][2], ns = 0;
-        for (int dy = 0; dy < 3; dy++) for (int dx = 0; dx < 3; dx++) {
-            const int px = ix0 + dx, py = iy0 + dy;
-            if (px < 0 || py < 0) continue;   // (never looked up: depthTest returns first)
-            const int cx = px >> 1, cy = py >> 1;
-            bool dup = false;
-            for (int k = 0; k < ns; k++) dup |= (seen[k][0] == cx && seen[k][1] == cy);
-            if (dup) continue;
-            seen[ns][0] = cx; seen[ns][1] = cy; ns++;
-            int x = cx, y = cy;
-            for (int l = 0; l < nLevels; l++) { out.push_back(cell(view, l, x, y)); x >>= 1; y >>= 1; }
-        }
-    };
+    RawFootprints F;
+    if (!raw_footprints(*this, patches, n, F)) return false;
     for (size_t i = 0; i < n; i++) {
-        const size_t m = (size_t)hb.nimg[i];
-        for (size_t k = 0; k < m; k++) {
-            const int32_t* w = &wr[(i * M + k) * 4]; const int32_t* f = &fr[(i * M + k) * 4]; const int32_t* a = &at[(i * M + k) * 3];
-            if (w[0] >= 0) writes[i].push_back(cell(w[0], w[1], w[2], w[3]));
-            if (f[0] >= 0) reads[i].push_back(cell(f[0], f[1], f[2], f[3]));
-            if (a[0] >= 0) full(a[0], a[1], a[2], reads[i]);
-        }
-        for (size_t v = 0; v < V; v++) {
-            const int32_t* b = &vb[(i * V + v) * 3];
-            if (b[0]) full((int)v, b[1], b[2], reads[i]);
-        }
+        for_read_cells(F, i, nLevels, [&](uint64_t k) { reads[i].push_back(k); return false; });
+        for_write_cells(F, i, [&](uint64_t k) { writes[i].push_back(k); return false; });
     }
     return true;
 }
@@ -881,6 +1068,10 @@ int PatchOptimizer::expandBatch(ExpandMode mode, const mo3d::Patch3d* const* par
     return N;
 }
 
+// HPMVS_LEVEL_TIMES=1: extendLevel prints where its time went (stderr)
+static bool level_times() { static const bool on = [] { const char* e = getenv("HPMVS_LEVEL_TIMES"); return e && e[0] == '1'; }(); return on; }
+static double level_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 static uint64_t grid_leaf_key(const Eigen::Vector3f& p, float width, void*) {
     const long long ix = (long long)std::floor(p[0] / width), iy = (long long)std::floor(p[1] / width), iz = (long long)std::floor(p[2] / width);
     return (uint64_t)(((ix + (1 << 20)) << 42) | ((iy + (1 << 20)) << 21) | (iz + (1 << 20)));
@@ -892,6 +1083,7 @@ bool PatchOptimizer::extendLevel(const mo3d::Patch3d* const* parents, size_t n, 
     const size_t N = 6, T = n * N;
     R = LevelResult();
     if (n == 0) return true;
+    const double t_begin = level_now();
     std::vector<CellRef> cells(n);
     for (size_t i = 0; i < n; i++) { cells[i].c = Eigen::Vector3f(0.0f, 0.0f, 0.0f); cells[i].width = width; }
     // the candidates before optimize (everything skipped: constructed only) -> their leaves
@@ -904,28 +1096,53 @@ bool PatchOptimizer::extendLevel(const mo3d::Patch3d* const* parents, size_t n, 
         preKey[t] = leafKey(Eigen::Vector3f(pre[t].center_[0], pre[t].center_[1], pre[t].center_[2]), width, user);
         skip[t] = occupied.count(preKey[t]) ? 1 : 0;   // level-start occupancy: those are never refined
     }
+    const double t_pre = level_now();
     expandBatch(EXTEND, parents, cells.data(), n, skip.data(), R.candidates, refined);
     if (R.candidates.size() != T) return false;
+    const double t_ref = level_now();
     std::vector<const Patch3d*> ptr(T);
     for (size_t t = 0; t < T; t++) {
         ptr[t] = &R.candidates[t];
         if (skip[t]) refined[t] = 0;
         if (refined[t]) postKey[t] = leafKey(Eigen::Vector3f(R.candidates[t].center_[0], R.candidates[t].center_[1], R.candidates[t].center_[2]), width, user);
     }
-    std::vector<std::vector<uint64_t> > reads, writes;
-    if (!scene_p->depthFootprints(ptr.data(), T, reads, writes)) return false;
+    // footprints of the REFINED candidates only (the others read and write no map), as the device returns them
+    const int nLevels = 6;
+    std::vector<const Patch3d*> rptr;
+    std::vector<int> fpi(T, -1);
+    for (size_t t = 0; t < T; t++) if (refined[t]) { fpi[t] = (int)rptr.size(); rptr.push_back(ptr[t]); }
+    RawFootprints F;
+    if (!raw_footprints(*scene_p, rptr.data(), rptr.size(), F)) return false;
+    const double t_fp = level_now();
     R.stage.assign(T, 1);
     R.counts.assign(3 * T, -1);
     std::vector<size_t> pending;
     for (size_t t = 0; t < T; t++) { if (skip[t]) R.stage[t] = 20; else pending.push_back(t); }
     const int MIN = options_p->MIN_IMAGES_PER_PATCH;
-    auto hits = [](const std::vector<uint64_t>& cellsOf, const std::unordered_set<uint64_t>& set) {
-        if (set.empty()) return false;
-        for (uint64_t c : cellsOf) if (set.count(c)) return true;
+    // the level's conflict graph (who writes what whom reads): once, from the footprints
+    ConflictGraph G;
+    {
+        int maxW = 1, maxH = 1;
+        for (const Image& im : scene_p->images_) { maxW = std::max(maxW, im.getWidth()); maxH = std::max(maxH, im.getHeight()); }
+        build_conflict_graph(F, nLevels, maxW, maxH, G);
+    }
+    const double t_graph = level_now();
+    // open[i] == w: candidate i (footprint index) was accepted or deferred in wave w -- its writes are not in the maps this wave's
+    // counts were read from (`dirty`); defer_w[i] == w: it was deferred in wave w -- nobody may overwrite what it reads (`guard`)
+    std::vector<int> open(rptr.size(), 0), defer_w(rptr.size(), 0);
+    FlatSet maybeOcc, occGuard;
+    auto reads_hit_dirty = [&](size_t i, int wave) {
+        for (uint32_t q = G.flow_off[i]; q < G.flow_off[i + 1]; q++) if (open[G.flow_adj[q]] == wave) return true;
         return false;
     };
+    auto writes_hit_guard = [&](size_t i, int wave) {
+        for (uint32_t q = G.anti_off[i]; q < G.anti_off[i + 1]; q++) if (defer_w[G.anti_adj[q]] == wave) return true;
+        return false;
+    };
+    double t_gates = 0.0, t_walk = 0.0, t_set = 0.0;
     while (!pending.empty()) {
         R.waves++;
+        double w0 = level_now();
         std::vector<size_t> todo;
         for (size_t t : pending) if (refined[t]) todo.push_back(t);
         std::vector<int> v, b, f;
@@ -934,21 +1151,24 @@ bool PatchOptimizer::extendLevel(const mo3d::Patch3d* const* parents, size_t n, 
         if (!todo.empty() && !scene_p->depthGates(sub.data(), sub.size(), margin, v, b, f, absInt)) return false;
         std::vector<int> slot(T, -1);
         for (size_t k = 0; k < todo.size(); k++) slot[todo[k]] = (int)k;
-        std::unordered_set<uint64_t> dirty, guard, maybeOcc, occGuard;
+        double w1 = level_now();
+        t_gates += w1 - w0;
+        maybeOcc.clear(); occGuard.clear();
+        const int wave = R.waves;
         std::vector<size_t> deferred, accNow;
         auto defer = [&](size_t t) {
             deferred.push_back(t);
-            occGuard.insert(preKey[t]);
+            occGuard.add(preKey[t]);
             if (refined[t]) {
-                dirty.insert(writes[t].begin(), writes[t].end()); guard.insert(reads[t].begin(), reads[t].end());
-                maybeOcc.insert(postKey[t]); occGuard.insert(postKey[t]);
+                open[(size_t)fpi[t]] = wave; defer_w[(size_t)fpi[t]] = wave;
+                maybeOcc.add(postKey[t]); occGuard.add(postKey[t]);
             }
         };
         for (size_t t : pending) {
             if (occupied.count(preKey[t])) { R.stage[t] = 20; continue; }   // its leaf was taken by an earlier candidate
-            if (sequential && maybeOcc.count(preKey[t])) { defer(t); continue; }
+            if (sequential && maybeOcc.has(preKey[t])) { defer(t); continue; }
             if (!refined[t]) { R.stage[t] = 1; continue; }                  // failed in optimize or at the scale / drift gates
-            if (sequential && hits(reads[t], dirty)) { defer(t); continue; }
+            if (sequential && reads_hit_dirty((size_t)fpi[t], wave)) { defer(t); continue; }
             const int k = slot[t];
             const int cv = v[k], cb = b[k], cf = f[k];
             R.counts[3 * t] = cv; R.counts[3 * t + 1] = cb; R.counts[3 * t + 2] = cf;
@@ -956,23 +1176,33 @@ bool PatchOptimizer::extendLevel(const mo3d::Patch3d* const* parents, size_t n, 
             else if (!(cb < MIN)) R.stage[t] = 24;
             else if (!(cf >= MIN - 1 && cf * 1.0 / (double)R.candidates[t].images_.size() > 0.75)) R.stage[t] = 25;
             else if (occupied.count(postKey[t])) R.stage[t] = 26;
-            else if (sequential && (maybeOcc.count(postKey[t]) || occGuard.count(postKey[t]) || hits(writes[t], guard))) {
+            else if (sequential && (maybeOcc.has(postKey[t]) || occGuard.has(postKey[t]) || writes_hit_guard((size_t)fpi[t], wave))) {
                 R.counts[3 * t] = R.counts[3 * t + 1] = R.counts[3 * t + 2] = -1;
                 defer(t);
             } else {
                 occupied.insert(postKey[t]);
                 R.stage[t] = 0;
                 R.accepted.push_back(t); accNow.push_back(t);
-                dirty.insert(writes[t].begin(), writes[t].end());
+                open[(size_t)fpi[t]] = wave;
             }
         }
+        double w2 = level_now();
+        t_walk += w2 - w1;
         if (!accNow.empty()) {
             std::vector<const Patch3d*> ap(accNow.size());
             for (size_t k = 0; k < accNow.size(); k++) ap[k] = ptr[accNow[k]];
             if (!scene_p->setDepths(ap.data(), ap.size())) return false;
         }
+        t_set += level_now() - w2;
+        if (level_times()) std::fprintf(stderr, "extendLevel wave %d: %zu pending (%zu refined), %zu accepted, %zu deferred\n",
+                                        R.waves, pending.size(), todo.size(), accNow.size(), deferred.size());
         pending.swap(deferred);
     }
+    if (level_times())
+        std::fprintf(stderr, "extendLevel %zu candidates (%zu refined): candidates' leaves %.1f ms, refinement %.1f ms, footprints %.1f ms, "
+                             "conflict graph %.1f ms (%zu + %zu edges), waves: gates %.1f ms, walk %.1f ms, setDepths %.1f ms\n", T, rptr.size(),
+                     1e3 * (t_pre - t_begin), 1e3 * (t_ref - t_pre), 1e3 * (t_fp - t_ref), 1e3 * (t_graph - t_fp), G.flow_adj.size(), G.anti_adj.size(),
+                     1e3 * t_gates, 1e3 * t_walk, 1e3 * t_set);
     std::sort(R.accepted.begin(), R.accepted.end());
     return true;
 }

@@ -2,7 +2,9 @@
 refinement + conflict-free waves, tests/native/bench_extend_level) against the oracle's TRUE sequential loop (orc_extend_round,
 live maps; reference CellProcessor.cpp:84-178 leaf by leaf), every candidate's fate compared.
 
-    python tools/extend_level_scale.py [views w h seeds leaves levels]      (default: 12 1920 1080 100000 16384 1)
+    python tools/extend_level_scale.py [views w h seeds leaves levels [start_level]]      (default: 12 1920 1080 100000 16384 1 4)
+(a lower START_LEVEL makes the patches -- and the leaves -- smaller: the same number of leaves covers less of the surface, fewer
+candidates find their leaf taken and more of them are refined and interact through the depth maps)
 
 Compared per candidate: stage (the C++ result folds the refinement / scale / drift failures into 1), the three depth-gate counts at
 decision time, centre and normal of every candidate that was refined (bit for bit), the accepted set.  Writes one JSON line.
@@ -24,7 +26,7 @@ from hpmvs_amd import api, synth  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 V, W_, H_, NSEEDS, NLEAVES, LEVELS = (int(a) for a in sys.argv[1:7]) if len(sys.argv) > 6 else (12, 1920, 1080, 100000, 16384, 1)
-SL = 4
+SL = int(sys.argv[7]) if len(sys.argv) > 7 else 4
 MARGIN = 1.0
 dev = torch.device("cuda", 0)
 scene = synth.make_scene(V, W_, H_, n_waves=24, device=dev)
@@ -56,11 +58,12 @@ with open(dump, "wb") as f:
     f.write(struct.pack("f", width))
 exe = os.path.join(ROOT, "tests", "native", "bench_extend_level")
 t0 = time.perf_counter()
-r = subprocess.run([exe, dump, outp, str(LEVELS), "0"], capture_output=True, text=True)
+r = subprocess.run([exe, dump, outp, str(LEVELS), "0"], capture_output=True, text=True, env=dict(os.environ, HPMVS_LEVEL_TIMES="1"))
 t_proc = time.perf_counter() - t0
 if r.returncode != 0:
     raise SystemExit(f"bench_extend_level failed: {r.stdout}\n{r.stderr}")
 print(r.stdout.strip())
+print("\n".join(l for l in r.stderr.splitlines() if l.startswith("extendLevel")))
 
 cand_t = np.dtype([("stage", "<i4"), ("counts", "<i4", 3), ("center", "<f4", 3), ("normal", "<f4", 3), ("scale", "<f4"), ("n_images", "<i4")])
 gpu_levels = []
