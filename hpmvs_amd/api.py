@@ -55,7 +55,7 @@ EXPORTS = [
     "hpmvs_expand_batch", "hpmvs_expand_directions", "hpmvs_selftest_bobyqa",
     "hpmvs_pack_records", "hpmvs_unpack_records", "hpmvs_allgather_records", "hpmvs_pack_record_tails", "hpmvs_unpack_record_tails",
     "hpmvs_scene_depth_reset", "hpmvs_scene_depth_set_level", "hpmvs_scene_depth_get_level",
-    "hpmvs_set_depths_batch", "hpmvs_depth_gates_batch", "hpmvs_depth_footprints_batch",
+    "hpmvs_set_depths_batch", "hpmvs_depth_gates_batch", "hpmvs_depth_footprints_batch", "hpmvs_depth_ops_batch", "hpmvs_level_support_batch",
     "hpmvs_host_alloc", "hpmvs_host_free", "hpmvs_last_staging",
 ]
 
@@ -110,6 +110,8 @@ def lib():
                                                C.c_int, C.c_void_p]
     L.hpmvs_depth_gates_batch.argtypes = [C.c_void_p, C.POINTER(PatchBatch), C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_void_p]
+    L.hpmvs_depth_ops_batch.argtypes = [C.c_void_p, C.POINTER(PatchBatch), C.c_void_p, C.c_int, C.c_void_p]
+    L.hpmvs_level_support_batch.argtypes = [C.c_void_p, C.POINTER(PatchBatch), C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     _lib = L
     return L
 
@@ -371,6 +373,22 @@ def set_depths_batch(scene: Scene, batch: Batch):
     """Scene::setDepths for every patch of the batch with ok != 0 (reference Scene.cpp:351-381)."""
     b = batch.c_struct()
     _chk(lib().hpmvs_set_depths_batch(scene.h, C.byref(b), 0, None))
+
+
+def depth_ops_batch(scene: Scene, batch: Batch, subtract):
+    """Scene::setDepths(patch_i, subtract[i]) for the patches with ok != 0, in batch order, with the sequential loop's maps
+    (reference Scene.cpp:351-381; subtract: CellProcessor.cpp:276-279)."""
+    b = batch.c_struct()
+    sub = np.ascontiguousarray(subtract, dtype=np.uint8).reshape(batch.n)
+    _chk(lib().hpmvs_depth_ops_batch(scene.h, C.byref(b), sub.ctypes.data, 0, None))
+
+
+def level_support_batch(scene: Scene, batch: Batch, min_level=0):
+    """Scene::getLevelSupport(patch, min_level) per patch (reference Scene.cpp:334-343)."""
+    b = batch.c_struct()
+    out = np.zeros(batch.n, dtype=np.int32)
+    _chk(lib().hpmvs_level_support_batch(scene.h, C.byref(b), int(min_level), out.ctypes.data, 0, None))
+    return out
 
 
 def depth_gates_batch(scene: Scene, batch: Batch, margin=1.0, abs_int=0):

@@ -1541,6 +1541,91 @@ int hpmvs_set_depths_batch(hpmvs_scene* s, const hpmvs_patch_batch* b, int on_de
     if (!on_device) HIPCHK(hipStreamSynchronize(st));
     return HPMVS_OK;
 }
+// Scene::setDepths(patch_i, subtract[i]) for i = 0 .. n - 1 IN THAT ORDER (kernel_depth.hip: keys, sort, per-cell replay).
+// Without a subtraction the calls commute and the batch goes to set_depths_kernel.
+int hpmvs_depth_ops_batch(hpmvs_scene* s, const hpmvs_patch_batch* b, const uint8_t* subtract, int on_device, void* stream) {
+    int rc = check_depth_batch(s, b, "depth_ops_batch");
+    if (rc) return rc;
+    if (b->n == 0) return HPMVS_OK;
+    if (!subtract) return hpmvs_set_depths_batch(s, b, on_device, stream);
+    const size_t cap = (size_t)b->n * (size_t)b->max_images;
+    if (cap >= ((size_t)1 << 28)) return fail(HPMVS_ERR_ARG, "depth_ops_batch: n * max_images must stay below 2^28 (apply the level in pieces: the order between pieces is kept)");
+    if (s->depth_floats >= ((size_t)1 << 32)) return fail(HPMVS_ERR_STATE, "depth_ops_batch: the scene's depth maps hold 2^32 cells or more");
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    Staged sg;
+    sg.scene = s;
+    const uint8_t* dsub = nullptr;
+    unsigned long long *keys = nullptr, *sorted = nullptr;
+    unsigned int* counter = nullptr;
+    {
+        Exclusive ex(s);  // the allocations of this call (see Exclusive)
+        if (!on_device) {
+            if ((rc = stage_batch(sg, b, false, false))) return rc;
+            if (b->ok) { if ((rc = stage_in(sg, sg.d.ok, b->ok, (size_t)b->n, true))) return rc; }
+            uint8_t* t = nullptr;
+            if ((rc = stage_in(sg, t, subtract, (size_t)b->n, true))) return rc;
+            dsub = t;
+        } else {
+            if ((rc = stage_batch(sg, b, true, false))) return rc;
+            dsub = subtract;
+        }
+        void* p = nullptr;
+        HIPCHK(hipMalloc(&p, cap * sizeof(unsigned long long))); sg.tmp.push_back(p); keys = (unsigned long long*)p;
+        HIPCHK(hipMalloc(&p, cap * sizeof(unsigned long long))); sg.tmp.push_back(p); sorted = (unsigned long long*)p;
+        HIPCHK(hipMalloc(&p, sizeof(unsigned int))); sg.tmp.push_back(p); counter = (unsigned int*)p;
+    }
+    if ((rc = stage_flush(sg))) return rc;
+    HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned int), st));
+    launch_depth_ops_keys(dev_scene(s), s->ddepth, s->depth_pool, sg.d, keys, counter, st);
+    HIPCHK(hipGetLastError());
+    unsigned int count = 0;
+    HIPCHK(hipMemcpyAsync(&count, counter, sizeof(count), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (count == 0) return HPMVS_OK;
+    size_t temp_bytes = 0;
+    if (depth_ops_sort(nullptr, &temp_bytes, keys, sorted, count, st) != 0) return fail(HPMVS_ERR_HIP, "depth_ops_batch: rocPRIM size query failed");
+    void* temp = nullptr;
+    {
+        Exclusive ex(s);
+        HIPCHK(hipMalloc(&temp, temp_bytes ? temp_bytes : 1)); sg.tmp.push_back(temp);
+    }
+    if (depth_ops_sort(temp, &temp_bytes, keys, sorted, count, st) != 0) return fail(HPMVS_ERR_HIP, "depth_ops_batch: rocPRIM sort failed");
+    launch_depth_ops_apply(dev_scene(s), s->ddepth, s->depth_pool, sg.d, dsub, sorted, count, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));   // (the temporaries are freed when this call returns)
+    return HPMVS_OK;
+}
+// Scene::getLevelSupport(patch, minLevel) (src/hpmvs/Scene.cpp:334-343) per patch
+int hpmvs_level_support_batch(const hpmvs_scene* s, const hpmvs_patch_batch* b, int min_level, int32_t* support, int on_device, void* stream) {
+    if (!s || !b || !support) return fail(HPMVS_ERR_ARG, "level_support_batch: null argument");
+    if (!s->committed) return fail(HPMVS_ERR_STATE, "level_support_batch: scene not committed");
+    if (b->n < 0 || b->max_images < 1 || b->max_images > HPMVS_MAX_IMAGES) return fail(HPMVS_ERR_ARG, "level_support_batch: bad n/max_images");
+    if (b->n > 0 && (!b->center || !b->scale || !b->n_images || !b->images)) return fail(HPMVS_ERR_ARG, "level_support_batch: batch input arrays missing");
+    if (b->n == 0) return HPMVS_OK;
+    int rc;
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    Staged sg;
+    sg.scene = s;
+    if (on_device) {
+        if ((rc = stage_batch(sg, b, true, false))) return rc;
+        launch_level_support(dev_scene(s), sg.d, min_level, support, st);
+        HIPCHK(hipGetLastError());
+        return HPMVS_OK;
+    }
+    int32_t* dsup = nullptr;
+    {
+        Exclusive ex(s);
+        if ((rc = stage_batch(sg, b, false, false))) return rc;
+        if ((rc = stage_in(sg, dsup, support, (size_t)b->n, false))) return rc;
+    }
+    if ((rc = stage_flush(sg))) return rc;
+    launch_level_support(dev_scene(s), sg.d, min_level, dsup, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return stage_out(support, dsup, (size_t)b->n);
+}
 int hpmvs_depth_gates_batch(const hpmvs_scene* s, const hpmvs_patch_batch* b, float margin, int abs_int,
                             int32_t* n_visible, int32_t* n_blocking, int32_t* n_free, int on_device, void* stream) {
     int rc = check_depth_batch(s, b, "depth_gates_batch");

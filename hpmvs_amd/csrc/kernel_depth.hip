@@ -12,6 +12,8 @@
 // Read-only on the gate side; setDepths is a float minimum (order-independent), done with atomicMin on the bit
 // patterns of non-negative floats.
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <cmath>
 
@@ -268,6 +270,114 @@ __global__ void __launch_bounds__(256) depth_footprints_kernel(DevScene sc, cons
                 }
             }
     }
+}
+
+// ---- Scene::setDepths(patch, subtract) for a whole batch with the result of the SEQUENTIAL loop (round 6).
+// subtract = false is a minimum per cell -- any order gives the same maps (set_depths_kernel) -- but subtract = true
+// (Scene.cpp:373-376: a cell that holds exactly this patch's depth becomes MAX_DEPTH again; CellProcessor::branch takes the
+// depths of the patch of a leaf it splits back, CellProcessor.cpp:276-279, and enters the children's) is not: whether a cell
+// ends at MAX_DEPTH, at the old patch's depth or at a child's depends on the order of the calls that touch it.  So a batch
+// with subtractions is applied cell by cell in call order: every (patch, attached image) that reaches a cell becomes a key
+// (cell index in the scene's map pool << 32 | call index), the keys are sorted, and the thread that finds the first key of a
+// cell replays that cell's calls in order.  Cells are independent, calls on one cell are sequential: the sequential loop's maps.
+__global__ void __launch_bounds__(256) depth_ops_keys_kernel(DevScene sc, const DevDepthView* __restrict__ depths, const float* pool, DevBatch b,
+                                                             unsigned long long* __restrict__ keys, unsigned int* __restrict__ counter) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = (int)(t / b.max_images), k = (int)(t - (long long)p * b.max_images);
+    bool valid = false;
+    unsigned long long key = 0ull;
+    if (p < b.n && !(b.ok && !b.ok[p])) {
+        const int nimg = b.n_images[p];
+        if (k < nimg && k < b.max_images) {
+            const int idx = b.images[(size_t)p * b.max_images + k];
+            if (idx >= 0 && idx < sc.n_views) {
+                const float c[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
+                const DevDepthView& D = depths[idx];
+                int level, x, y;
+                float d;
+                if (set_depths_cell(sc, sc.views[idx], D, c, b.scale[p], level, x, y, d)) {
+                    const size_t cell = (size_t)(&D.d[level][y + (size_t)x * D.rows[level]] - pool);
+                    key = ((unsigned long long)cell << 32) | (unsigned long long)(unsigned int)t;
+                    valid = true;
+                }
+            }
+        }
+    }
+    // one atomic per wavefront; the order of the keys in the buffer does not matter (they are sorted next)
+    const unsigned long long m = __ballot(valid);
+    if (m) {
+        const int lane = lane_id();
+        unsigned int base = 0;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, (unsigned int)__popcll(m));
+        base = (unsigned int)__builtin_amdgcn_readlane((int)base, __ffsll((long long)m) - 1);
+        if (valid) keys[base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = key;
+    }
+}
+__global__ void __launch_bounds__(256) depth_ops_apply_kernel(DevScene sc, const DevDepthView* __restrict__ depths, float* pool, DevBatch b,
+                                                              const uint8_t* __restrict__ subtract, const unsigned long long* __restrict__ keys,
+                                                              unsigned int count) {
+    const unsigned int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const unsigned long long cell = keys[j] >> 32;
+    if (j > 0 && (keys[j - 1] >> 32) == cell) return;   // not the first call on this cell
+    float v = pool[cell];
+    for (unsigned int q = j; q < count; q++) {
+        const unsigned long long key = keys[q];
+        if ((key >> 32) != cell) break;
+        const unsigned int t = (unsigned int)key;
+        const int p = (int)(t / (unsigned int)b.max_images), k = (int)(t - (unsigned int)p * (unsigned int)b.max_images);
+        const int idx = b.images[(size_t)p * b.max_images + k];
+        const float c[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
+        int level, x, y;
+        float d;
+        set_depths_cell(sc, sc.views[idx], depths[idx], c, b.scale[p], level, x, y, d);   // (the same cell; its depth)
+        if (subtract && subtract[p]) { if (v == d) v = kMaxDepth; }   // Scene.cpp:373-374
+        else if (d < v) v = d;                                        // :375-376
+    }
+    pool[cell] = v;
+}
+// Scene::getLevelSupport (Scene.cpp:334-343): the attached images with std::round(getLevel) > minLevel, i.e. (float)log2(r) >=
+// minLevel + 0.5 -- the threshold DevScene::lvl_thr[minLevel] was bisected for against the host's log2 (photometric.hpp)
+__global__ void __launch_bounds__(256) level_support_kernel(DevScene sc, DevBatch b, int min_level, int32_t* __restrict__ support) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= b.n) return;
+    const float c[3] = {b.center[4 * p], b.center[4 * p + 1], b.center[4 * p + 2]};
+    const float scale = b.scale[p];
+    int nimg = b.n_images[p];
+    nimg = nimg < 0 ? 0 : (nimg > b.max_images ? b.max_images : nimg);
+    int n = 0;
+    for (int k = 0; k < nimg; k++) {
+        const int idx = b.images[(size_t)p * b.max_images + k];
+        if (idx < 0 || idx >= sc.n_views) continue;
+        const DevView& V = sc.views[idx];
+        if (min_level >= 0 && min_level < kMaxLevels - 1) {
+            const float d0 = c[0] - V.center[0], d1 = c[1] - V.center[1], d2 = c[2] - V.center[2];
+            const float fz = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+            const double r = (double)(scale * V.fsum) / (2.0 * (double)fz);
+            n += (r >= sc.lvl_thr[min_level]) ? 1 : 0;
+        } else n += (level_rounded(V, c, scale) > min_level) ? 1 : 0;
+    }
+    support[p] = n;
+}
+
+void launch_level_support(const DevScene& sc, const DevBatch& b, int min_level, int32_t* support, hipStream_t st) {
+    if (b.n <= 0) return;
+    hipLaunchKernelGGL(level_support_kernel, dim3((unsigned)((b.n + 255) / 256)), dim3(256), 0, st, sc, b, min_level, support);
+}
+void launch_depth_ops_keys(const DevScene& sc, const DevDepthView* depths, const float* pool, const DevBatch& b, unsigned long long* keys,
+                           unsigned int* counter, hipStream_t st) {
+    if (b.n <= 0) return;
+    const size_t threads = (size_t)b.n * (size_t)b.max_images;
+    hipLaunchKernelGGL(depth_ops_keys_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, sc, depths, pool, b, keys, counter);
+}
+// sorts `count` keys from keys_in to keys_out; temp == nullptr: only reports the temporary bytes rocPRIM needs
+int depth_ops_sort(void* temp, size_t* temp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out, unsigned int count, hipStream_t st) {
+    return (int)rocprim::radix_sort_keys(temp, *temp_bytes, keys_in, keys_out, (size_t)count, 0u, 64u, st);
+}
+void launch_depth_ops_apply(const DevScene& sc, const DevDepthView* depths, float* pool, const DevBatch& b, const uint8_t* subtract,
+                            const unsigned long long* keys, unsigned int count, hipStream_t st) {
+    if (!count) return;
+    hipLaunchKernelGGL(depth_ops_apply_kernel, dim3((count + 255) / 256), dim3(256), 0, st, sc, depths, pool, b, subtract, keys, count);
 }
 
 void launch_depth_footprints(const DevScene& sc, const DevDepthView* depths, const DevBatch& b, int32_t* wr, int32_t* fr, int32_t* at,

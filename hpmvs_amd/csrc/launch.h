@@ -42,6 +42,14 @@ void launch_set_depths(const DevScene& sc, const DevDepthView* depths, const Dev
 void launch_depth_gates(const DevScene& sc, const DevDepthView* depths, const DevBatch& b, float margin, int abs_int,
                         int32_t* n_visible, int32_t* n_blocking, int32_t* n_free, hipStream_t st);
 
+// Scene::setDepths(patch, subtract) in call order (keys -> sort -> per-cell replay) and Scene::getLevelSupport
+void launch_level_support(const DevScene& sc, const DevBatch& b, int min_level, int32_t* support, hipStream_t st);
+void launch_depth_ops_keys(const DevScene& sc, const DevDepthView* depths, const float* pool, const DevBatch& b, unsigned long long* keys,
+                           unsigned int* counter, hipStream_t st);
+int depth_ops_sort(void* temp, size_t* temp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out, unsigned int count, hipStream_t st);
+void launch_depth_ops_apply(const DevScene& sc, const DevDepthView* depths, float* pool, const DevBatch& b, const uint8_t* subtract,
+                            const unsigned long long* keys, unsigned int count, hipStream_t st);
+
 // the cells a batch's gates read and setDepths would write (the scheduler's conflict test; layouts at the kernel)
 void launch_depth_footprints(const DevScene& sc, const DevDepthView* depths, const DevBatch& b, int32_t* wr, int32_t* fr, int32_t* at,
                              int32_t* vb, hipStream_t st);

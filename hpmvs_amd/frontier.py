@@ -192,3 +192,50 @@ def extend_level(scene: api.Scene, parents: api.Batch, width: float, occupied: s
         pending = deferred
     accepted.sort()
     return LevelResult(out, stage, counts, accepted, waves, deferred_log)
+
+
+@dataclass
+class BranchResult:
+    candidates: api.Batch          # the 4 n children (refined where they were refined; stage 20: not built / not refined)
+    support: np.ndarray            # Scene::getLevelSupport of every leaf's patch
+    split: np.ndarray              # [n] 1: the leaf was split (its patch's depths taken back, the children's entered)
+    children: np.ndarray           # [n, 4] bool: the children that go into the new leaves
+
+
+def branch_level(scene: api.Scene, parents: api.Batch, cell_center, cell_width, final_level, options=None) -> BranchResult:
+    """One priority level of CellProcessor::branch (reference CellProcessor.cpp:210-307) over `parents` -- the patches of the
+    level's leaves, in the scheduler's order -- as ONE hpmvs_level_support_batch (the first gate, :221-224), ONE
+    hpmvs_expand_batch (the four diagonal children, Cell::contains before and after optimize, :233-258: the refinement reads
+    neither the maps nor the tree) and ONE hpmvs_depth_ops_batch that replays the leaves' map updates in the reference's
+    order: per split leaf its patch's depths taken back (:276-279), then its children's entered (:296) -- subtraction does not
+    commute with the minimum, so the order is part of the result.  `final_level[i]`: nodeLevel(leaf i) >= PATCH_FINAL_MINLEVEL
+    (the scheduler's knowledge): such a leaf keeps its patch when no child survived (:265-266).  The tree operations (split,
+    the children's leaves, the queue) stay with the caller; the result names what to do.  Equals the sequential loop's
+    (`orc_branch_round`): children, split decisions, every depth map (tests/test_gpu_branch_level.py)."""
+    o = options or api.default_options()
+    n = parents.n
+    cc = np.ascontiguousarray(cell_center, dtype=np.float32).reshape(n, 3)
+    cw = np.ascontiguousarray(cell_width, dtype=np.float32).reshape(n)
+    final = np.ascontiguousarray(final_level).astype(bool).reshape(n)
+    support = api.level_support_batch(scene, parents, int(o.MINLEVEL))
+    skip = np.repeat(support < 1, 4).astype(np.uint8)   # an exhausted leaf builds nothing
+    out = api.expand_batch(scene, api.EXPAND_BRANCH, parents, cc, cw, skip, options=o)
+    children = ((out.stage == 0) & (skip == 0)).reshape(n, 4)
+    split = (support >= 1) & ~(final & (children.sum(axis=1) == 0))
+    # the map updates in the reference's order: leaf by leaf, the old patch out, the children in
+    M = max(parents.max_images, out.max_images)
+    widen = lambda a: np.pad(a, ((0, 0), (0, M - a.shape[1])), constant_values=-1)
+    rows_c, rows_n, rows_s, rows_m, rows_i, sub = [], [], [], [], [], []
+    pimg, cimg = widen(parents.images), widen(out.images)
+    for i in np.nonzero(split)[0]:
+        rows_c.append(parents.center[i]); rows_n.append(parents.normal[i]); rows_s.append(parents.scale[i])
+        rows_m.append(parents.n_images[i]); rows_i.append(pimg[i]); sub.append(1)
+        for k in np.nonzero(children[i])[0]:
+            t = 4 * i + k
+            rows_c.append(out.center[t]); rows_n.append(out.normal[t]); rows_s.append(out.scale[t])
+            rows_m.append(out.n_images[t]); rows_i.append(cimg[t]); sub.append(0)
+    if sub:
+        ops = api.Batch(np.array(rows_c), np.array(rows_n), np.array(rows_s), np.array(rows_m), np.array(rows_i))
+        ops.ok[:] = 1
+        api.depth_ops_batch(scene, ops, np.array(sub, np.uint8))
+    return BranchResult(out, support, split.astype(np.uint8), children)

@@ -219,6 +219,15 @@ int hpmvs_scene_depth_get_level(const hpmvs_scene *s, int view, int level, float
 int hpmvs_set_depths_batch(hpmvs_scene *s, const hpmvs_patch_batch *b, int on_device, void *stream);
 int hpmvs_depth_gates_batch(const hpmvs_scene *s, const hpmvs_patch_batch *b, float margin, int abs_int,
                             int32_t *n_visible, int32_t *n_blocking, int32_t *n_free, int on_device, void *stream);
+/* Scene::setDepths(patch_i, subtract[i]) for i = 0 .. n - 1 with ok[i] != 0, IN THAT ORDER (src/hpmvs/Scene.cpp:351-381).
+ * subtract[i] != 0 takes patch i's depths back: a cell that still holds exactly that patch's depth becomes MAX_DEPTH again
+ * (:373-374) -- what CellProcessor::branch does for the patch of a leaf it splits before it enters the children's depths
+ * (src/hpmvs/CellProcessor.cpp:276-279, 296).  Unlike the minimum of subtract = 0 that depends on the order of the calls that
+ * reach a cell, so the batch is applied cell by cell in call order (sorted keys, one thread replays a cell's calls): the maps
+ * are those of the sequential loop.  subtract == NULL: hpmvs_set_depths_batch.  n * max_images < 2^28 per call.
+ * hpmvs_level_support_batch: Scene::getLevelSupport(patch, min_level) (src/hpmvs/Scene.cpp:334-343), branch's first gate. */
+int hpmvs_depth_ops_batch(hpmvs_scene *s, const hpmvs_patch_batch *b, const uint8_t *subtract, int on_device, void *stream);
+int hpmvs_level_support_batch(const hpmvs_scene *s, const hpmvs_patch_batch *b, int min_level, int32_t *support, int on_device, void *stream);
 /* The cells those calls touch, as integers: what a scheduler needs to run one priority level's candidates in conflict-free
  * waves and still end with the reference's SEQUENTIAL result (CellProcessor.cpp:130-142 reads maps that earlier candidates
  * of the same level have written, Scene.cpp:351-381; hpmvs_amd/frontier.py is that scheduler, INTEGRATION.md has the recipe).

@@ -1041,8 +1041,10 @@ static void cam_mult(const orc_camera *cam, const float *X, int level, float *r)
     for (int k = 0; k < 3; k++)
         r[k] = sum4(P[k * 4 + 0] * X[0], P[k * 4 + 1] * X[1], P[k * 4 + 2] * X[2], P[k * 4 + 3] * X[3]);
 }
-/* Scene::setDepths(patch, subtract = false), src/hpmvs/Scene.cpp:351-381 */
-void orc_set_depths(const orc_scene *s, orc_depths *D, const orc_patch *p) {
+/* Scene::setDepths(patch, subtract), src/hpmvs/Scene.cpp:351-381: subtract = false offers the patch's depth to one cell per
+ * attached image (a minimum); subtract = true takes it back -- a cell that still holds exactly this patch's depth becomes
+ * MAX_DEPTH again (CellProcessor::branch does that for the patch of a leaf it splits, CellProcessor.cpp:276-279) */
+void orc_set_depths_ex(const orc_scene *s, orc_depths *D, const orc_patch *p, int subtract) {
     for (int i = 0; i < p->n_images; i++) {
         const int idx = p->images[i];
         const orc_camera *cam = &s->cams[idx];
@@ -1055,8 +1057,19 @@ void orc_set_depths(const orc_scene *s, orc_depths *D, const orc_patch *p) {
         const int k = idx * ORC_MAX_LEVELS + level;
         if (x < 0 || x >= D->cols[k] || y < 0 || y >= D->rows[k]) continue;
         float *cell = &D->d[k][y + (size_t)x * D->rows[k]];
-        if (d < *cell) *cell = d;
+        const float old = *cell;
+        if (old == d && subtract) *cell = ORC_MAX_DEPTH;
+        else if (!subtract && d < old) *cell = d;
     }
+}
+void orc_set_depths(const orc_scene *s, orc_depths *D, const orc_patch *p) { orc_set_depths_ex(s, D, p, 0); }
+/* Scene::getLevelSupport(patch, minLevel), src/hpmvs/Scene.cpp:334-343: the attached images in which the patch could still be
+ * seen on a finer pyramid level */
+int orc_level_support(const orc_scene *s, const orc_patch *p, int min_level) {
+    int n = 0;
+    for (int i = 0; i < p->n_images; i++)
+        if (roundf(cam_get_level(&s->cams[p->images[i]], p->center, p->scale)) > (float)min_level) n++;
+    return n;
 }
 /* Scene::getFullDepth, src/hpmvs/Scene.cpp:406-432 */
 static float get_full_depth(const orc_scene *s, const orc_depths *D, int img, int xx, int yy) {
@@ -1220,4 +1233,34 @@ int orc_extend_round(const orc_scene *s, const orc_options *o, orc_depths *D, in
     if (frozen_gates) orc_depths_destroy(G);
     *n_occ = occ.n;
     return accepted;
+}
+
+/* One priority level of CellProcessor::branch (src/hpmvs/CellProcessor.cpp:210-307), leaf by leaf in order.  Per leaf: its
+ * patch must have level support (:221-224), the four diagonal children are built, gated by Cell::contains before and after
+ * optimize (:247-258: orc_expand, mode 1); a leaf on the final tree level that got no child keeps its patch (:265-266,
+ * `final_level[i]` = nodeLevel(cell) >= PATCH_FINAL_MINLEVEL, the scheduler's knowledge); otherwise the leaf is split: its
+ * patch's depths are taken back (:276-279) and the children's are entered (:296).  The octree itself (split, the new leaves,
+ * the queue) stays with the caller.  out: 4 candidates per leaf; split[i]: 1 if leaf i was split.  Returns the split leaves. */
+int orc_branch_round(const orc_scene *s, const orc_options *o, orc_depths *D, int n_leaves, const orc_patch *parents,
+                     const float *cell_center, const float *cell_width, const unsigned char *final_level, orc_patch *out,
+                     unsigned char *split, int which) {
+    int n_split = 0;
+    for (int i = 0; i < n_leaves; i++) {
+        orc_patch *four = out + (size_t)4 * i;
+        split[i] = 0;
+        if (orc_level_support(s, &parents[i], o->MINLEVEL) < 1) {   /* exhausted: nothing is built */
+            const unsigned char all[4] = {1, 1, 1, 1};
+            orc_expand(s, o, 1, &parents[i], cell_center + 3 * i, cell_width[i], all, four, which);
+            for (int k = 0; k < 4; k++) four[k].stage = 27;
+            continue;
+        }
+        orc_expand(s, o, 1, &parents[i], cell_center + 3 * i, cell_width[i], NULL, four, which);
+        int children = 0;
+        for (int k = 0; k < 4; k++) children += four[k].stage == 0 ? 1 : 0;
+        if (final_level[i] && children == 0) continue;
+        split[i] = 1; n_split++;
+        orc_set_depths_ex(s, D, &parents[i], 1);
+        for (int k = 0; k < 4; k++) if (four[k].stage == 0) orc_set_depths_ex(s, D, &four[k], 0);
+    }
+    return n_split;
 }

@@ -160,6 +160,14 @@ orc_depths *orc_depths_create(const orc_scene *s);
 void orc_depths_destroy(orc_depths *D);
 float *orc_depths_level(orc_depths *D, int view, int level, int *rows, int *cols);
 void orc_set_depths(const orc_scene *s, orc_depths *D, const orc_patch *p);
+/* Scene::setDepths(patch, subtract) (Scene.cpp:351-381; subtract = 1: a cell that holds exactly this patch's depth becomes
+ * MAX_DEPTH again), Scene::getLevelSupport (Scene.cpp:334-343), and one priority level of CellProcessor::branch
+ * (CellProcessor.cpp:210-307) leaf by leaf: see hpmvs_oracle.c */
+void orc_set_depths_ex(const orc_scene *s, orc_depths *D, const orc_patch *p, int subtract);
+int orc_level_support(const orc_scene *s, const orc_patch *p, int min_level);
+int orc_branch_round(const orc_scene *s, const orc_options *o, orc_depths *D, int n_leaves, const orc_patch *parents,
+                     const float *cell_center, const float *cell_width, const unsigned char *final_level, orc_patch *out,
+                     unsigned char *split, int which_optimizer);
 void orc_depth_gates(const orc_scene *s, const orc_depths *D, const orc_patch *p, float margin, int abs_int,
                      int *n_visible, int *n_blocking, int *n_free);
 

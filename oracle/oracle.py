@@ -91,6 +91,10 @@ def lib():
     L.orc_depths_level.restype = C.POINTER(C.c_float)
     L.orc_depths_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.orc_set_depths.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Patch)]
+    L.orc_set_depths_ex.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Patch), C.c_int]
+    L.orc_level_support.argtypes = [C.c_void_p, C.POINTER(Patch), C.c_int]
+    L.orc_branch_round.argtypes = [C.c_void_p, C.POINTER(Options), C.c_void_p, C.c_int, C.POINTER(Patch), C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.POINTER(Patch), C.c_void_p, C.c_int]
     L.orc_cell_key.restype = C.c_longlong
     L.orc_cell_key.argtypes = [C.POINTER(C.c_float), C.c_float]
     L.orc_extend_round.argtypes = [C.c_void_p, C.POINTER(Options), C.c_void_p, C.c_int, C.POINTER(Patch), C.c_float, C.c_float,
@@ -204,8 +208,9 @@ class OracleDepths:
         p = lib().orc_depths_level(self.h, view, level, C.byref(r), C.byref(c))
         return np.ctypeslib.as_array(p, shape=(c.value, r.value))
 
-    def set_depths(self, patch):
-        lib().orc_set_depths(self.scene.h, self.h, C.byref(patch))
+    def set_depths(self, patch, subtract=False):
+        """Scene::setDepths(patch, subtract) (Scene.cpp:351-381)."""
+        lib().orc_set_depths_ex(self.scene.h, self.h, C.byref(patch), 1 if subtract else 0)
 
     def gates(self, patch, margin=1.0, abs_int=0):
         v, b, f = C.c_int(), C.c_int(), C.c_int()
@@ -378,3 +383,24 @@ def extend_round(scene: OracleScene, depths: OracleDepths, parents, width, occup
     occupied.clear()
     occupied.update(int(keys[i]) for i in range(n_occ.value))
     return out, np.array(counts[:], dtype=np.int32).reshape(6 * n, 3)
+
+
+def level_support(scene: OracleScene, patch, min_level=0) -> int:
+    """Scene::getLevelSupport (Scene.cpp:334-343)."""
+    return int(lib().orc_level_support(scene.h, C.byref(patch), int(min_level)))
+
+
+def branch_round(scene: OracleScene, depths: OracleDepths, parents, cell_center, cell_width, final_level, which=None, options=None):
+    """One priority level of CellProcessor::branch, leaf by leaf (reference CellProcessor.cpp:210-307) on the depth maps
+    `depths` (updated in place).  Returns (candidates[4 n], split[n])."""
+    which = best_optimizer() if which is None else which
+    o = options or default_options()
+    n = len(parents)
+    cc = np.ascontiguousarray(cell_center, dtype=np.float32).reshape(n, 3)
+    cw = np.ascontiguousarray(cell_width, dtype=np.float32).reshape(n)
+    fl = np.ascontiguousarray(final_level, dtype=np.uint8).reshape(n)
+    out = (Patch * (4 * n))()
+    split = np.zeros(n, np.uint8)
+    lib().orc_branch_round(scene.h, C.byref(o), depths.h, n, parents, cc.ctypes.data, cw.ctypes.data, fl.ctypes.data, out,
+                           split.ctypes.data, which)
+    return out, split
