@@ -577,6 +577,27 @@ bool Scene::setDepths(const Patch3d* const* patches, size_t n) const {
     if (hpmvs_set_depths_batch(dev, &hb.b, 0, nullptr) != HPMVS_OK) { std::cerr << "hpmvs: " << hpmvs_last_error() << std::endl; return false; }
     return true;
 }
+bool Scene::setDepths(const Patch3d* const* patches, size_t n, const uint8_t* subtract) const {
+    if (!subtract) return setDepths(patches, n);
+    hpmvs_scene* dev = deviceScene();
+    if (!dev) return false;
+    if (n == 0) return true;
+    HostBatch hb(patches, n);
+    PVec<uint8_t> sub(subtract, subtract + n, PinnedAlloc<uint8_t>(true));
+    if (hpmvs_depth_ops_batch(dev, &hb.b, sub.data(), 0, nullptr) != HPMVS_OK) { std::cerr << "hpmvs: " << hpmvs_last_error() << std::endl; return false; }
+    return true;
+}
+bool Scene::levelSupport(const Patch3d* const* patches, size_t n, int minLevel, std::vector<int>& support) const {
+    support.assign(n, 0);
+    hpmvs_scene* dev = deviceScene();
+    if (!dev) return false;
+    if (n == 0) return true;
+    HostBatch hb(patches, n);
+    PVec<int32_t> out(n, PinnedAlloc<int32_t>(true));
+    if (hpmvs_level_support_batch(dev, &hb.b, minLevel, out.data(), 0, nullptr) != HPMVS_OK) { std::cerr << "hpmvs: " << hpmvs_last_error() << std::endl; return false; }
+    for (size_t i = 0; i < n; i++) support[i] = out[i];
+    return true;
+}
 bool Scene::depthGates(const Patch3d* const* patches, size_t n, float margin, std::vector<int>& nVisible,
                        std::vector<int>& nBlocking, std::vector<int>& nFree, bool absInt) const {
     nVisible.assign(n, 0); nBlocking.assign(n, 0); nFree.assign(n, 0);
@@ -1066,6 +1087,30 @@ int PatchOptimizer::expandBatch(ExpandMode mode, const mo3d::Patch3d* const* par
         }
     }
     return N;
+}
+
+bool PatchOptimizer::branchLevel(const mo3d::Patch3d* const* parents, const CellRef* cells, size_t n, const uint8_t* finalLevel,
+                                 BranchResult& R) {
+    R = BranchResult();
+    if (n == 0) return true;
+    if (!scene_p->levelSupport(parents, n, options_p->MINLEVEL, R.support)) return false;
+    std::vector<uint8_t> skip(4 * n, 0), acc;
+    for (size_t i = 0; i < n; i++) if (R.support[i] < 1) for (int k = 0; k < 4; k++) skip[4 * i + k] = 1;   // exhausted: builds nothing
+    expandBatch(BRANCH, parents, cells, n, skip.data(), R.candidates, acc);
+    if (R.candidates.size() != 4 * n) return false;
+    R.child.assign(4 * n, 0);
+    R.split.assign(n, 0);
+    std::vector<const Patch3d*> ops;
+    std::vector<uint8_t> sub;
+    for (size_t i = 0; i < n; i++) {
+        int children = 0;
+        for (int k = 0; k < 4; k++) { R.child[4 * i + k] = (acc[4 * i + k] && !skip[4 * i + k]) ? 1 : 0; children += R.child[4 * i + k]; }
+        if (R.support[i] < 1 || (finalLevel && finalLevel[i] && children == 0)) continue;
+        R.split[i] = 1;
+        ops.push_back(parents[i]); sub.push_back(1);                       // the old patch out (CellProcessor.cpp:276-279)
+        for (int k = 0; k < 4; k++) if (R.child[4 * i + k]) { ops.push_back(&R.candidates[4 * i + k]); sub.push_back(0); }   // the children in (:296)
+    }
+    return ops.empty() || scene_p->setDepths(ops.data(), ops.size(), sub.data());
 }
 
 // HPMVS_LEVEL_TIMES=1: extendLevel prints where its time went (stderr)

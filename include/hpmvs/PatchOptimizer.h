@@ -54,6 +54,19 @@ public:
     typedef uint64_t (*LeafKeyFn)(const Eigen::Vector3f& p, float width, void* user);
     bool extendLevel(const mo3d::Patch3d* const* parents, size_t n, float width, std::unordered_set<uint64_t>& occupied,
                      float margin, bool absInt, LevelResult& out, bool sequential = true, LeafKeyFn leafKey = nullptr, void* user = nullptr);
+    // One priority level of CellProcessor::branch (reference src/hpmvs/CellProcessor.cpp:210-307) over the patches of the level's
+    // leaves, in the scheduler's order: level-support gate (:221-224), the four diagonal children with Cell::contains before and
+    // after optimize (:233-258) as ONE expandBatch, then the depth maps in the reference's order -- per split leaf its patch taken
+    // back (:276-279), its children entered (:296) -- as ONE ordered Scene::setDepths call.  finalLevel[i]: nodeLevel(leaf i) >=
+    // PATCH_FINAL_MINLEVEL (the scheduler's knowledge): such a leaf keeps its patch when no child survived (:265-266).  The tree
+    // operations (split, the children's leaves, the queue) stay with the caller; the result says what to do with every leaf.
+    struct BranchResult {
+        std::vector<mo3d::Patch3d> candidates;   // 4 per leaf
+        std::vector<uint8_t> child;              // 4 per leaf: goes into the new leaves
+        std::vector<int> support;                // Scene::getLevelSupport of the leaf's patch
+        std::vector<uint8_t> split;              // per leaf: split (its patch's depths are out of the maps, the children's in)
+    };
+    bool branchLevel(const mo3d::Patch3d* const* parents, const CellRef* cells, size_t n, const uint8_t* finalLevel, BranchResult& out);
     // diagnostics of the last optimize()/optimizeBatch() call that the reference computes and drops
     // (final mean robust INCC f*, PatchOptimizer.cpp:365,376): one entry per patch
     const std::vector<double>& lastObjective() const { return lastF_; }

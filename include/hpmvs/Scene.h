@@ -38,6 +38,13 @@ public:
     // absInt selects C's abs(int) for the unqualified abs() at Scene.cpp:571 (default: the <cmath> overload).
     bool resetDepths() const;
     bool setDepths(const Patch3d* const* patches, size_t n) const;
+    // Scene::setDepths(patch, subtract) for a list of calls IN ORDER (src/hpmvs/Scene.cpp:351-381): subtract[i] != 0 takes patch i's
+    // depths back (a cell that still holds exactly its depth becomes MAX_DEPTH again, :373-374 -- CellProcessor::branch does that
+    // for the patch of a leaf it splits, CellProcessor.cpp:276-279).  That does not commute with the minimum of an ordinary call,
+    // so the list is applied cell by cell in call order on the device: the maps are those of the sequential loop.
+    bool setDepths(const Patch3d* const* patches, size_t n, const uint8_t* subtract) const;
+    // Scene::getLevelSupport(patch, minLevel) (src/hpmvs/Scene.cpp:334-343) for every patch
+    bool levelSupport(const Patch3d* const* patches, size_t n, int minLevel, std::vector<int>& support) const;
     bool depthGates(const Patch3d* const* patches, size_t n, float margin, std::vector<int>& nVisible,
                     std::vector<int>& nBlocking, std::vector<int>& nFree, bool absInt = false) const;
     // The map cells those tests READ and the cells setDepths would WRITE, per patch, as packed keys -- what a scheduler needs to

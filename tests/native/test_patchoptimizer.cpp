@@ -164,6 +164,32 @@ int main(int argc, char** argv) {
             }
         }
     }
+    // (7) one priority level of CellProcessor::branch (PatchOptimizer::branchLevel): the first 60 refined patches are the leaves'
+    //     patches, every leaf centred on its patch (width 2 * scale / 0.9), every second one on the final tree level; the maps
+    //     afterwards are fingerprinted by the three gate counts of the leaves' patches
+    {
+        std::vector<const mo3d::Patch3d*> leaves;
+        for (int i = 0; i < np && leaves.size() < 60; i++) if (ok[i]) leaves.push_back(patches[i].get());
+        if (!leaves.empty()) {
+            std::vector<mo3d::PatchOptimizer::CellRef> cells(leaves.size());
+            std::vector<unsigned char> fin(leaves.size());
+            for (size_t i = 0; i < leaves.size(); i++) {
+                cells[i].c = Eigen::Vector3f(leaves[i]->center_[0], leaves[i]->center_[1], leaves[i]->center_[2]);
+                cells[i].width = leaves[i]->scale_3dx_ * (2.0f / 0.9f);
+                fin[i] = (unsigned char)(i & 1);
+            }
+            mo3d::PatchOptimizer::BranchResult B;
+            std::vector<int> vis, blk, fre;
+            bool fine = scene.resetDepths() && scene.setDepths(leaves.data(), leaves.size());
+            fine = fine && optimizers[1].branchLevel(leaves.data(), cells.data(), leaves.size(), fin.data(), B);
+            fine = fine && scene.depthGates(leaves.data(), leaves.size(), 1.0f, vis, blk, fre);
+            if (!fine) printf("branch failed\n");
+            else
+                for (size_t i = 0; i < leaves.size(); i++)
+                    printf("branch %zu %d %d %d %d %d %d %d %d %d\n", i, B.support[i], (int)B.split[i], (int)B.child[4 * i], (int)B.child[4 * i + 1],
+                           (int)B.child[4 * i + 2], (int)B.child[4 * i + 3], vis[i], blk[i], fre[i]);
+        }
+    }
     // (5) the per-thread cache of pinned blocks stays under its cap whatever sizes the rounds have (a frontier
     //     loop whose round size changes every round must not pile up one pinned block per size class)
     {

@@ -119,6 +119,19 @@ def test_cpp_patchoptimizer_equals_c_abi(tiny_scene, tiny_seeds, gpu_scene, tmp_
     assert np.array_equal(cnt_cpp, res.counts)
     assert int(summ[0][1]) == res.waves and int(summ[0][2]) == len(res.accepted) and int(summ[0][3]) == len(occ)
     assert res.waves > 1 and len(res.accepted) >= 20
+    # PatchOptimizer::branchLevel (C++: one level of CellProcessor::branch, ordered depth ops) == hpmvs_amd.frontier.branch_level
+    rows = [l.split() for l in out if l.startswith("branch ")]
+    assert len(rows) == leaves.n and rows[0][1] != "failed", [l for l in out if l.startswith("branch")][:3]
+    api.depth_reset(gpu_scene)
+    leaves.ok[:] = 1
+    api.set_depths_batch(gpu_scene, leaves)
+    bw = (leaves.scale * np.float32(2.0 / 0.9)).astype(np.float32)
+    br = frontier.branch_level(gpu_scene, leaves, leaves.center[:, :3].copy(), bw, (np.arange(leaves.n) & 1).astype(np.uint8))
+    v2, b2, f2 = api.depth_gates_batch(gpu_scene, leaves, 1.0, 0)
+    got = np.array([[int(x) for x in r[2:11]] for r in rows])
+    want = np.column_stack([br.support, br.split, br.children.astype(np.int64), v2, b2, f2])
+    assert np.array_equal(got, want), np.nonzero((got != want).any(axis=1))[0][:10]
+    assert br.split.sum() >= 20 and br.children.sum() >= 20
 
 
 def _dump_scene(path, scene, seeds, n):
