@@ -16,6 +16,8 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <unordered_map>
+#include <unordered_set>
 #include <omp.h>
 
 #include <hpmvs/Camera.h>
@@ -836,6 +838,77 @@ void build_conflict_graph(const RawFootprints& F, int nLevels, int maxW, int max
     csr(e_anti, G.anti_off, G.anti_adj);
 }
 }  // namespace
+
+// Test hook (tests/test_cpu_host_logic.py; no device needed): random footprints -- blocks at the image border and beyond it,
+// writes on every pyramid level, cells that collide -- and the conflict graph of build_conflict_graph against the definition
+// itself: candidate j is a neighbour of i iff a cell key j would write is among the cell keys i reads (the vectors of
+// Scene::depthFootprints).  Returns the number of (i, j) pairs on which the two disagree (0), or -1 for bad arguments.
+extern "C" int hpmvs_host_selftest_conflict_graph(unsigned seed, int n, int n_views, int max_w, int max_h, int n_levels, int max_images, int* n_edges) {
+    if (n < 1 || n_views < 1 || max_w < 8 || max_h < 8 || n_levels < 1 || n_levels > 7 || max_images < 1) return -1;
+    RawFootprints F;
+    F.n = (size_t)n; F.V = (size_t)n_views; F.M = (size_t)max_images;
+    F.nimg.assign(F.n, 0);
+    F.wr.assign(F.n * F.M * 4, -1); F.fr.assign(F.n * F.M * 4, -1); F.at.assign(F.n * F.M * 3, -1); F.vb.assign(F.n * F.V * 3, 0);
+    unsigned long long st = 0x9E3779B97F4A7C15ull ^ ((unsigned long long)seed * 0xD1B54A32D192ED03ull);
+    auto rnd = [&](int m) { st = st * 6364136223846793005ull + 1442695040888963407ull; return (int)((st >> 33) % (unsigned long long)m); };
+    // everything happens in a few small windows of the images, so that candidates really meet
+    const int wx = max_w / 4 < 24 ? max_w / 4 : 24, wy = max_h / 4 < 24 ? max_h / 4 : 24;
+    for (size_t i = 0; i < F.n; i++) {
+        const int m = 1 + rnd(max_images);
+        F.nimg[i] = m;
+        const int corner = rnd(4);   // windows at the four corners: blocks reach outside the image there
+        const int bx = (corner & 1) ? max_w - wx - 1 : -2, by = (corner & 2) ? max_h - wy - 1 : -2;
+        for (int k = 0; k < m; k++) {
+            const int view = rnd(n_views), px = bx + rnd(wx + 3), py = by + rnd(wy + 3);
+            int32_t* a = &F.at[(i * F.M + k) * 3];
+            if (rnd(8)) { a[0] = view; a[1] = px - 1; a[2] = py - 1; }
+            const int l = rnd(n_levels);
+            const int cx = (px < 0 ? 0 : px) >> (1 + l), cy = (py < 0 ? 0 : py) >> (1 + l);
+            int32_t* w = &F.wr[(i * F.M + k) * 4];
+            if (rnd(6)) { w[0] = view; w[1] = l; w[2] = cx + rnd(2); w[3] = cy + rnd(2); }
+            const int lf = rnd(n_levels);
+            int32_t* f = &F.fr[(i * F.M + k) * 4];
+            if (rnd(6)) { f[0] = view; f[1] = lf; f[2] = ((px < 0 ? 0 : px) >> (1 + lf)) + rnd(2); f[3] = ((py < 0 ? 0 : py) >> (1 + lf)) + rnd(2); }
+        }
+        for (int v = 0; v < n_views; v++)
+            if (rnd(3) == 0) { int32_t* b = &F.vb[(i * F.V + (size_t)v) * 3]; b[0] = 1; b[1] = bx + rnd(wx + 3) - 1; b[2] = by + rnd(wy + 3) - 1; }
+    }
+    ConflictGraph G;
+    build_conflict_graph(F, n_levels, max_w, max_h, G);
+    // the definition: cell key -> the candidates that would write it
+    std::unordered_map<uint64_t, std::vector<uint32_t> > writers;
+    for (size_t j = 0; j < F.n; j++) for_write_cells(F, j, [&](uint64_t k) { writers[k].push_back((uint32_t)j); return false; });
+    int bad = 0;
+    for (size_t i = 0; i < F.n; i++) {
+        std::unordered_set<uint32_t> want_flow, want_anti_of;   // j < i that write what i reads; j > i that write what i reads (i is in anti[j])
+        for_read_cells(F, i, n_levels, [&](uint64_t k) {
+            auto it = writers.find(k);
+            if (it != writers.end()) for (uint32_t j : it->second) { if (j < i) want_flow.insert(j); else if (j > i) want_anti_of.insert(j); }
+            return false;
+        });
+        std::unordered_set<uint32_t> got_flow(G.flow_adj.begin() + G.flow_off[i], G.flow_adj.begin() + G.flow_off[i + 1]);
+        if (got_flow != want_flow || got_flow.size() != (size_t)(G.flow_off[i + 1] - G.flow_off[i])) bad++;
+        for (uint32_t j : want_anti_of) {
+            bool found = false;
+            for (uint32_t q = G.anti_off[j]; q < G.anti_off[j + 1]; q++) found |= G.anti_adj[q] == (uint32_t)i;
+            if (!found) bad++;
+        }
+    }
+    // ... and no anti edge that the definition does not have
+    size_t want_anti_total = 0;
+    for (size_t i = 0; i < F.n; i++) {
+        std::unordered_set<uint32_t> later;
+        for_read_cells(F, i, n_levels, [&](uint64_t k) {
+            auto it = writers.find(k);
+            if (it != writers.end()) for (uint32_t j : it->second) if (j > i) later.insert(j);
+            return false;
+        });
+        want_anti_total += later.size();
+    }
+    if (want_anti_total != G.anti_adj.size()) bad++;
+    if (n_edges) *n_edges = (int)(G.flow_adj.size() + G.anti_adj.size());
+    return bad;
+}
 
 bool Scene::depthFootprints(const Patch3d* const* patches, size_t n, std::vector<std::vector<uint64_t> >& reads,
                             std::vector<std::vector<uint64_t> >& writes, int nLevels) const {
