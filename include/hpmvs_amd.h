@@ -224,7 +224,8 @@ int hpmvs_depth_gates_batch(const hpmvs_scene *s, const hpmvs_patch_batch *b, fl
  * (:373-374) -- what CellProcessor::branch does for the patch of a leaf it splits before it enters the children's depths
  * (src/hpmvs/CellProcessor.cpp:276-279, 296).  Unlike the minimum of subtract = 0 that depends on the order of the calls that
  * reach a cell, so the batch is applied cell by cell in call order (sorted keys, one thread replays a cell's calls): the maps
- * are those of the sequential loop.  subtract == NULL: hpmvs_set_depths_batch.  n * max_images < 2^28 per call.
+ * are those of the sequential loop.  subtract == NULL: hpmvs_set_depths_batch.  n * max_images < 2^28 per call.  The call is
+ * host-synchronous also with on_device = 1 (the number of keys is read back before the sort; its temporaries are freed on return).
  * hpmvs_level_support_batch: Scene::getLevelSupport(patch, min_level) (src/hpmvs/Scene.cpp:334-343), branch's first gate. */
 int hpmvs_depth_ops_batch(hpmvs_scene *s, const hpmvs_patch_batch *b, const uint8_t *subtract, int on_device, void *stream);
 int hpmvs_level_support_batch(const hpmvs_scene *s, const hpmvs_patch_batch *b, int min_level, int32_t *support, int on_device, void *stream);
