@@ -117,7 +117,11 @@ static int acquire_workspace(const hpmvs_scene* s, int32_t** q, int* slot, hipSt
     if (k < 0 && s->n_queues < kQueueSlots) {
         int32_t* w = nullptr;
         HIPCHK(hipMalloc((void**)&w, s->ws_bytes));
-        if (hipMemset(w, 0, s->ws_bytes) != hipSuccess) { hipFree(w); return fail(HPMVS_ERR_HIP, "cannot clear a launch workspace"); }
+        // cleared ON THE LAUNCH STREAM: hipMemset on the null stream returns before the fill has run and is not ordered with the
+        // non-blocking streams small host batches are launched on -- the fill of a workspace that was grown under concurrent
+        // single-patch calls ran INTO the first launch that used it and zeroed its image-list rows (round 6: one call in a few
+        // hundred came back with another refinement; tests/test_gpu_wide_lists.py, tools/_conc_probe in the commit message)
+        if (hipMemsetAsync(w, 0, s->ws_bytes, st) != hipSuccess) { hipFree(w); return fail(HPMVS_ERR_HIP, "cannot clear a launch workspace"); }
         k = s->n_queues;
         s->dqueue[k] = w;
         s->n_queues++;
@@ -346,6 +350,7 @@ int hpmvs_scene_commit(hpmvs_scene* s) {
     s->ws_bytes = (optimize_workspace_bytes(s->n_cus) + 255) & ~(size_t)255;
     HIPCHK(hipMalloc((void**)&s->dqueue[0], s->ws_bytes));  // the others on first concurrent use (acquire_workspace)
     HIPCHK(hipMemset(s->dqueue[0], 0, s->ws_bytes));
+    HIPCHK(hipStreamSynchronize(nullptr));   // (the fills of the upload have run before any launch on another stream can start)
     s->n_queues = 1;
     s->bytes += s->ws_bytes;
     s->bytes += sizeof(DevView) * (size_t)s->n_views + sizeof(int32_t) * (off.size() + flat.size());
@@ -509,13 +514,16 @@ int stage_in(Staged& st, T*& dst, const T* host, size_t count, bool copy, bool n
 // With a launch stream the fills are issued ON it (ordered with the launch, and not waiting behind an open-batch kernel the
 // way null-stream work can: ADVICE r4); a pageable source is consumed before hipMemcpyAsync returns.
 int stage_flush(Staged& st, hipStream_t on = nullptr) {
+    bool null_fill = false;
     for (const Staged::Fill& f : st.fills) {
         if (on) {
             if (f.src) HIPCHK(hipMemcpyAsync(f.dst, f.src, f.bytes, hipMemcpyHostToDevice, on));
             else HIPCHK(hipMemsetAsync(f.dst, 0, f.bytes, on));
         } else if (f.src) HIPCHK(hipMemcpy(f.dst, f.src, f.bytes, hipMemcpyHostToDevice));
-        else HIPCHK(hipMemset(f.dst, 0, f.bytes));
+        else { HIPCHK(hipMemset(f.dst, 0, f.bytes)); null_fill = true; }
     }
+    // a null-stream fill returns before it has run; the launch that follows may go to a non-blocking stream of the caller's
+    if (null_fill) HIPCHK(hipStreamSynchronize(nullptr));
     st.fills.clear();
     return HPMVS_OK;
 }

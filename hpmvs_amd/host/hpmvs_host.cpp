@@ -1054,6 +1054,14 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
         return 0;
     }
     memcpy(ok, okp.data(), n);
+    {   // HPMVS_DEBUG_CALLS=1: one line per call of up to four patches (what came back, per attempt)
+        static const bool dbg = [] { const char* e = getenv("HPMVS_DEBUG_CALLS"); return e && e[0] == '1'; }();
+        if (dbg && n <= 4)
+            for (size_t i = 0; i < n; i++)
+                std::fprintf(stderr, "hpmvs call: in %.9g %.9g %.9g (%zu ids) rows %d full %d -> ok %d stage %d nimg %d evals %d out %.9g %.9g %.9g\n",
+                             patches[i]->center_[0], patches[i]->center_[1], patches[i]->center_[2], patches[i]->images_.size(), stride, (int)tl_full_rows,
+                             (int)ok[i], stage[i], nimg[i], evals[i], center[4 * i], center[4 * i + 1], center[4 * i + 2]);
+    }
     // The rows of a call of up to four patches are the open batch's 64 ids.  A patch that ends at stage 100 there (its refined
     // list is longer than that: a dense scene) was left untouched; the reference's list is unbounded, so it is refined again
     // with rows as wide as a list can get.

@@ -105,7 +105,12 @@ int main(int argc, char** argv) {
     const double cpu_sys = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + 1e-6 * (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec);
     int mismatches = 0, good = 0;
     for (int i = 0; i < np; i++) {
-        if (okA[i] != okB[i] || !same(A[i], B[i])) mismatches++;
+        if (okA[i] != okB[i] || !same(A[i], B[i])) {
+            mismatches++;
+            fprintf(stderr, "bench_callers: patch %d differs: batch ok %d (%zu images, centre %.9g %.9g %.9g) / call ok %d (%zu images, centre %.9g %.9g %.9g)\n", i,
+                    (int)okA[i], A[i].images_.size(), A[i].center_[0], A[i].center_[1], A[i].center_[2], (int)okB[i], B[i].images_.size(),
+                    B[i].center_[0], B[i].center_[1], B[i].center_[2]);
+        }
         good += okA[i];
     }
     // (3) a lone call
