@@ -519,10 +519,11 @@ int stage_flush(Staged& st, hipStream_t on = nullptr) {
         if (on) {
             if (f.src) HIPCHK(hipMemcpyAsync(f.dst, f.src, f.bytes, hipMemcpyHostToDevice, on));
             else HIPCHK(hipMemsetAsync(f.dst, 0, f.bytes, on));
-        } else if (f.src) HIPCHK(hipMemcpy(f.dst, f.src, f.bytes, hipMemcpyHostToDevice));
+        } else if (f.src) { HIPCHK(hipMemcpy(f.dst, f.src, f.bytes, hipMemcpyHostToDevice)); null_fill = true; }
         else { HIPCHK(hipMemset(f.dst, 0, f.bytes)); null_fill = true; }
     }
-    // a null-stream fill returns before it has run; the launch that follows may go to a non-blocking stream of the caller's
+    // a null-stream fill may return before it has run (hipMemset always, a copy from pageable memory once it is staged); the launch
+    // that follows may go to a non-blocking stream of the caller's
     if (null_fill) HIPCHK(hipStreamSynchronize(nullptr));
     st.fills.clear();
     return HPMVS_OK;
