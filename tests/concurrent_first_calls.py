@@ -7,7 +7,10 @@ in a few came back with another refinement.)   usage: concurrent_first_calls.py 
 import sys, threading, numpy as np, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hpmvs_amd import api, synth
-scene = synth.make_scene(120, 640, 360, n_waves=16)
+if os.environ.get('HPMVS_TEST_LIB'):   # (a variant build: showing that the test fails without the fix)
+    api.LIB_PATH = os.environ['HPMVS_TEST_LIB']
+import torch
+scene = synth.make_scene(120, 640, 360, n_waves=16, device=torch.device('cuda', 0))   # (rendered on the GPU: seconds instead of half a minute)
 n = 160
 seeds = synth.make_seeds(scene, n, start_level=1, max_images=256, seed=synth.SEED + 22)
 g = api.Scene(scene)

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("rows", [120, 64])
 def test_first_concurrent_single_patch_calls_equal_the_batch(rows):
-    for _ in range(1):   # (a fresh process: the workspaces are grown once per process)
+    for _ in range(4):   # (fresh processes: the workspaces are grown once per process; the old clear failed about one process in six)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "concurrent_first_calls.py"), str(rows), "8", "1"],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
