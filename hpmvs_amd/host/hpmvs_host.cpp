@@ -1022,7 +1022,13 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
     for (size_t i = 0; i < n; i++) longest_in = std::max(longest_in, patches[i]->images_.size());
     // (tl_full_rows: the retry below -- rows as wide as a list can get, whatever the batch size)
     const int full = list_stride(scene_p->cameras_.size(), (size_t)-1, longest_in);
-    const int stride = tl_full_rows ? full : list_stride(scene_p->cameras_.size(), n, longest_in);
+    // A call of up to four patches takes the open batch's 64-id rows first and is refined again with full rows when a list outgrows
+    // them (below).  In a dense scene nearly every patch does: after such a retry the next small calls of this optimizer go straight
+    // to full rows (a batch launch of their own, whose wide kernel takes the long lists) instead of failing twice first; the result is
+    // the same patch either way.  Every 16th small call tries the cheap way again.
+    const bool straight = !tl_full_rows && n <= 4 && preferFullRows_ > 0;
+    if (straight) preferFullRows_--;
+    const int stride = (tl_full_rows || straight) ? full : list_stride(scene_p->cameras_.size(), n, longest_in);
     const PinnedAlloc<char> pin(n > kPinFrom);
     PVec<float> center(4 * n, pin), normal(4 * n, pin), scale(n, pin), color(3 * n, pin), ncc(n, pin);
     PVec<int32_t> nimg(n, pin), images(n * stride, -1, pin), evals(n, pin), stage(n, pin);
@@ -1082,6 +1088,7 @@ size_t PatchOptimizer::optimizeBatch(mo3d::Patch3d* const* patches, size_t n, ui
         good++;
     }
     if (!again.empty()) {
+        preferFullRows_ = 16;
         std::vector<mo3d::Patch3d*> sub(again.size());
         std::vector<uint8_t> sok(again.size(), 0);
         for (size_t k = 0; k < again.size(); k++) sub[k] = patches[again[k]];

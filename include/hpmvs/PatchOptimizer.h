@@ -83,6 +83,7 @@ private:
     const mo3d::Scene* scene_p;
     std::vector<double> lastF_;
     std::vector<int> lastEvals_;
+    int preferFullRows_ = 0;   // small calls that go straight to rows as wide as a list can get (a dense scene: optimizeBatch)
 };
 }  // namespace mo3d
 #endif
