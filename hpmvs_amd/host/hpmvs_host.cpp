@@ -1201,6 +1201,51 @@ bool PatchOptimizer::branchLevel(const mo3d::Patch3d* const* parents, const Cell
     return ops.empty() || scene_p->setDepths(ops.data(), ops.size(), sub.data());
 }
 
+// The centres of a level's candidates BEFORE optimize (CellProcessor.cpp:103-116: the leaf look-up of :118-122 uses them): the device's
+// own construction with every candidate skipped, read back without building 6 n Patch3d objects, in rows just wide enough for the
+// parents' lists (nothing is refined, no list grows).  centers: 3 floats per candidate.
+static bool candidate_centers(const Scene* scene, const HpmvsOptions* opt, int mode, const mo3d::Patch3d* const* parents, const float* widths,
+                              size_t n, std::vector<float>& centers) {
+    const size_t N = mode == 0 ? 6 : 4, m = n * N;
+    centers.assign(3 * m, 0.0f);
+    if (n == 0) return true;
+    hpmvs_scene* dev = scene->deviceScene();
+    if (!dev) return false;
+    size_t stride = 1;
+    for (size_t i = 0; i < n; i++) stride = std::max(stride, parents[i]->images_.size());
+    if (stride > (size_t)HPMVS_MAX_IMAGES) stride = HPMVS_MAX_IMAGES;
+    const PinnedAlloc<char> pin(true);
+    PVec<float> pc(4 * n, pin), pn(4 * n, pin), ps(n, pin), cc(3 * n, 0.0f, pin), cw(widths, widths + n, pin);
+    PVec<int32_t> pnimg(n, pin), pimg(n * stride, -1, pin);
+    for (size_t i = 0; i < n; i++) {
+        const Patch3d& p = *parents[i];
+        for (int k = 0; k < 4; k++) { pc[4 * i + k] = p.center_[k]; pn[4 * i + k] = p.normal_[k]; }
+        ps[i] = p.scale_3dx_;
+        const size_t mi = std::min(p.images_.size(), stride);
+        pnimg[i] = (int32_t)mi;
+        for (size_t k = 0; k < mi; k++) pimg[i * stride + k] = p.images_[k];
+    }
+    PVec<float> center(4 * m, pin), normal(4 * m, pin), scale(m, pin);
+    PVec<int32_t> nimg(m, pin), images(m * stride, pin);
+    PVec<uint8_t> okp(m, pin), skp(m, (uint8_t)1, pin);
+    hpmvs_options o;
+    o.MAXLEVEL = opt->MAXLEVEL; o.MINLEVEL = opt->MINLEVEL; o.MAX_ANGLE = opt->MAX_ANGLE; o.MIN_ANGLE = opt->MIN_ANGLE;
+    o.MAX_IMAGES_PER_PATCH = opt->MAX_IMAGES_PER_PATCH; o.MIN_IMAGES_PER_PATCH = opt->MIN_IMAGES_PER_PATCH;
+    o.NCC_ALPHA_1 = opt->NCC_ALPHA_1; o.NCC_ALPHA_2 = opt->NCC_ALPHA_2;
+    hpmvs_patch_batch pb, ob;
+    memset(&pb, 0, sizeof(pb)); memset(&ob, 0, sizeof(ob));
+    pb.n = (int32_t)n; pb.max_images = (int32_t)stride;
+    pb.center = pc.data(); pb.normal = pn.data(); pb.scale = ps.data(); pb.n_images = pnimg.data(); pb.images = pimg.data();
+    ob.n = (int32_t)m; ob.max_images = (int32_t)stride;
+    ob.center = center.data(); ob.normal = normal.data(); ob.scale = scale.data(); ob.n_images = nimg.data(); ob.images = images.data(); ob.ok = okp.data();
+    if (hpmvs_expand_batch(dev, &o, mode, &pb, cc.data(), cw.data(), skp.data(), &ob, 0, nullptr) != HPMVS_OK) {
+        std::cerr << "hpmvs: " << hpmvs_last_error() << std::endl;
+        return false;
+    }
+    for (size_t t = 0; t < m; t++) for (int k = 0; k < 3; k++) centers[3 * t + k] = center[4 * t + k];
+    return true;
+}
+
 // HPMVS_LEVEL_TIMES=1: extendLevel prints where its time went (stderr)
 static bool level_times() { static const bool on = [] { const char* e = getenv("HPMVS_LEVEL_TIMES"); return e && e[0] == '1'; }(); return on; }
 static double level_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -1220,13 +1265,12 @@ bool PatchOptimizer::extendLevel(const mo3d::Patch3d* const* parents, size_t n, 
     std::vector<CellRef> cells(n);
     for (size_t i = 0; i < n; i++) { cells[i].c = Eigen::Vector3f(0.0f, 0.0f, 0.0f); cells[i].width = width; }
     // the candidates before optimize (everything skipped: constructed only) -> their leaves
-    std::vector<uint8_t> all(T, 1), acc0, skip(T, 0), refined;
-    std::vector<mo3d::Patch3d> pre;
-    expandBatch(EXTEND, parents, cells.data(), n, all.data(), pre, acc0);
-    if (pre.size() != T) return false;
+    std::vector<uint8_t> skip(T, 0), refined;
+    std::vector<float> pre, widths(n, width);
+    if (!candidate_centers(scene_p, options_p, (int)EXTEND, parents, widths.data(), n, pre)) return false;
     std::vector<uint64_t> preKey(T), postKey(T, 0);
     for (size_t t = 0; t < T; t++) {
-        preKey[t] = leafKey(Eigen::Vector3f(pre[t].center_[0], pre[t].center_[1], pre[t].center_[2]), width, user);
+        preKey[t] = leafKey(Eigen::Vector3f(pre[3 * t], pre[3 * t + 1], pre[3 * t + 2]), width, user);
         skip[t] = occupied.count(preKey[t]) ? 1 : 0;   // level-start occupancy: those are never refined
     }
     const double t_pre = level_now();
