@@ -120,7 +120,7 @@ static int acquire_workspace(const hpmvs_scene* s, int32_t** q, int* slot, hipSt
         // cleared ON THE LAUNCH STREAM: hipMemset on the null stream returns before the fill has run and is not ordered with the
         // non-blocking streams small host batches are launched on -- the fill of a workspace that was grown under concurrent
         // single-patch calls ran INTO the first launch that used it and zeroed its image-list rows (round 6: one call in a few
-        // hundred came back with another refinement; tests/test_gpu_wide_lists.py, tools/_conc_probe in the commit message)
+        // hundred came back with another refinement; tests/test_gpu_concurrent_first_calls.py)
         if (hipMemsetAsync(w, 0, s->ws_bytes, st) != hipSuccess) { hipFree(w); return fail(HPMVS_ERR_HIP, "cannot clear a launch workspace"); }
         k = s->n_queues;
         s->dqueue[k] = w;
