@@ -1158,7 +1158,10 @@ int PatchOptimizer::expandBatch(ExpandMode mode, const mo3d::Patch3d* const* par
     }
     memcpy(accepted.data(), accp.data(), m);
     candidates.resize(m);
-    for (size_t t = 0; t < m; t++) {
+    // (a frontier of 1e5 candidates: 1e5 copies of a parent with its image vector -- in parallel from 4096 candidates on)
+#pragma omp parallel for schedule(static) num_threads(m < 4096 ? 1 : std::min(omp_get_max_threads(), 16))
+    for (long long tt = 0; tt < (long long)m; tt++) {
+        const size_t t = (size_t)tt;
         Patch3d& q = candidates[t];
         q = *parents[t / N];  // *newP = *p (CellProcessor.cpp:113, 238)
         q.expanded_ = false;
