@@ -38,7 +38,34 @@ def worker(t):
         calls[t] += 1; patches[t] += m
         if not same.all():
             with lock: bad.append((t, lo, m, rows, np.nonzero(~same)[0][:5].tolist()))
-ths = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+# ... and, beside them, ONE thread that runs the same level of CellProcessor::extend and the same level of ::branch over and over on the
+# scene's depth maps (frontier.extend_level / branch_level: refinement launches, footprints, gate passes, ordered depth ops): every
+# repetition must give the first one's result
+from hpmvs_amd import frontier
+lv_bad, lv_reps = [], [0]
+def level_worker():
+    keep = np.nonzero(full.ok)[0][:300]
+    leaves = api.Batch(full.center[keep], full.normal[keep], full.scale[keep], full.n_images[keep], full.images[keep])
+    width = float(np.float32(2.0 * np.median(leaves.scale) / 0.9))
+    occ0 = {frontier.cell_key(leaves.center[k], width) for k in range(leaves.n)}
+    first = None
+    while time.time() < stop:
+        api.depth_reset(g)
+        leaves.ok[:] = 1
+        api.set_depths_batch(g, leaves)
+        occ = set(occ0)
+        r = frontier.extend_level(g, leaves, width, occ, 1.0, 0)
+        cw = (leaves.scale * np.float32(2.0 / 0.9)).astype(np.float32)
+        br = frontier.branch_level(g, leaves, leaves.center[:, :3].copy(), cw, (np.arange(leaves.n) & 1).astype(np.uint8))
+        v, b, f = api.depth_gates_batch(g, leaves, 1.0, 0)
+        sig = (r.stage.tobytes(), r.counts.tobytes(), tuple(r.accepted), r.waves, br.candidates.stage.tobytes(), br.split.tobytes(), v.tobytes(), b.tobytes(), f.tobytes(),
+               r.candidates.center.tobytes(), br.candidates.center.tobytes())
+        if first is None: first = sig
+        elif sig != first: lv_bad.append(lv_reps[0])
+        lv_reps[0] += 1
+ths = [threading.Thread(target=worker, args=(t,)) for t in range(T)] + [threading.Thread(target=level_worker)]
 [t.start() for t in ths]; [t.join() for t in ths]
+print('level thread: repetitions', lv_reps[0], 'differing from the first', len(lv_bad), lv_bad[:5])
+bad = bad + [('level', r) for r in lv_bad]
 print('threads', T, 'seconds', SECS, 'calls', sum(calls), 'patches', sum(patches), 'calls with a differing patch', len(bad), bad[:8])
 sys.exit(1 if bad else 0)
