@@ -1304,7 +1304,7 @@ bool PatchOptimizer::extendLevel(const mo3d::Patch3d* const* parents, size_t n, 
     {
         int maxW = 1, maxH = 1;
         for (const Image& im : scene_p->images_) { maxW = std::max(maxW, im.getWidth()); maxH = std::max(maxH, im.getHeight()); }
-        build_conflict_graph(F, nLevels, maxW, maxH, G);
+        if (sequential && F.n > 0) build_conflict_graph(F, nLevels, maxW, maxH, G);   // (the plain frontier round decides everything in one wave)
     }
     const double t_graph = level_now();
     // open[i] == w: candidate i (footprint index) was accepted or deferred in wave w -- its writes are not in the maps this wave's
