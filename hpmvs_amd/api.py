@@ -18,7 +18,7 @@ except Exception:  # pragma: no cover - torch is optional plumbing
     torch = None
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhpmvs_amd.so")
+LIB_PATH = os.environ.get("HPMVS_LIB") or os.path.join(HERE, "libhpmvs_amd.so")   # (HPMVS_LIB: a variant build, measurements only)
 MAX_IMAGES = 256   # HPMVS_MAX_IMAGES: ids per list row the C ABI takes
 FAST_IMAGES = 64   # HPMVS_FAST_IMAGES: lists that never outgrow this run in the batch kernel alone
 MAX_LEVELS = 8

@@ -241,10 +241,16 @@ __shared__ int bq_lds_i[13 * BQ_SLOTS];
 #endif
 #if defined(BQ_COLD_GLOBAL)
 typedef unsigned int bq_u2 __attribute__((ext_vector_type(2)));
+#ifndef BQ_COLD_LD_AUX
+#define BQ_COLD_LD_AUX 0   /* cache-policy bits of the cold block's loads / stores (lab: 2 = non-temporal) */
+#endif
+#ifndef BQ_COLD_ST_AUX
+#define BQ_COLD_ST_AUX 0
+#endif
 struct bq_cold_ref {  // one float64 of the cold block: reads convert, assignments store
     __amdgpu_buffer_rsrc_t r; unsigned voff; int soff;
-    __device__ __forceinline__ operator double() const { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, 0)); }
-    __device__ __forceinline__ void operator=(double v) const { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bq_u2, v), r, (int)voff, soff, 0); }
+    __device__ __forceinline__ operator double() const { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, BQ_COLD_LD_AUX)); }
+    __device__ __forceinline__ void operator=(double v) const { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bq_u2, v), r, (int)voff, soff, BQ_COLD_ST_AUX); }
     __device__ __forceinline__ void operator=(const bq_cold_ref& o) const { *this = (double)o; }
     __device__ __forceinline__ void operator+=(double v) const { *this = (double)*this + v; }
     __device__ __forceinline__ void operator-=(double v) const { *this = (double)*this - v; }

@@ -174,6 +174,15 @@ __device__ __forceinline__ void page_in(const uint4* __restrict__ park, uint4* h
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+// HPMVS_PARK_NT_STORE=1 (lab): the parking stores carry the non-temporal hint (lines that come back a whole round later)
+#ifndef HPMVS_PARK_NT_STORE
+#define HPMVS_PARK_NT_STORE 0
+#endif
+#if HPMVS_PARK_NT_STORE
+#define HPMVS_PARK_ST(dst, v) __builtin_nontemporal_store((v), &(dst))
+#else
+#define HPMVS_PARK_ST(dst, v) (dst) = (v)
+#endif
 // A REAL call: inlined into the kernel (every VGPR taken) the compiler left it one register quad, i.e. ds_read_b128,
 // s_waitcnt, global_store, 78 times in a row -- 113 cycles per KiB, 8.8 k cycles per page-out with 58 slots, all of it
 // while the region is held.  As a function it has the caller-saved registers to itself: eight reads in flight.
@@ -190,12 +199,12 @@ __device__ __attribute__((noinline)) void page_out(uint4* __restrict__ park, int
                     v3 = region[(c + 3) * 64 + lane], v4 = region[(c + 4) * 64 + lane], v5 = region[(c + 5) * 64 + lane],
                     v6 = region[(c + 6) * 64 + lane], v7 = region[(c + 7) * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);  // all eight reads are issued before the first store waits for its data
-        out[(c + 0) * 64 + lane] = v0; out[(c + 1) * 64 + lane] = v1; out[(c + 2) * 64 + lane] = v2; out[(c + 3) * 64 + lane] = v3;
-        out[(c + 4) * 64 + lane] = v4; out[(c + 5) * 64 + lane] = v5; out[(c + 6) * 64 + lane] = v6; out[(c + 7) * 64 + lane] = v7;
+        HPMVS_PARK_ST(out[(c + 0) * 64 + lane], v0); HPMVS_PARK_ST(out[(c + 1) * 64 + lane], v1); HPMVS_PARK_ST(out[(c + 2) * 64 + lane], v2); HPMVS_PARK_ST(out[(c + 3) * 64 + lane], v3);
+        HPMVS_PARK_ST(out[(c + 4) * 64 + lane], v4); HPMVS_PARK_ST(out[(c + 5) * 64 + lane], v5); HPMVS_PARK_ST(out[(c + 6) * 64 + lane], v6); HPMVS_PARK_ST(out[(c + 7) * 64 + lane], v7);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (; c < HPMVS_REGION_KIB; c++) out[c * 64 + lane] = region[c * 64 + lane];
+    for (; c < HPMVS_REGION_KIB; c++) { const u4 v = region[c * 64 + lane]; HPMVS_PARK_ST(out[c * 64 + lane], v); }
 }
 
 }  // namespace

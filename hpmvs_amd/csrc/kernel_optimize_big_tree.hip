@@ -22,5 +22,17 @@
 #ifndef HPMVS_SINGLE_FAST
 #define HPMVS_SINGLE_FAST 0
 #endif
+// The parking traffic of this build (a wavefront's 52 KB of optimiser states out to its buffer and back in, once per round) carries the
+// NON-TEMPORAL hint both ways: a line comes back a whole round (~250 us, hundreds of MB of other traffic) later, so keeping it in L2
+// only evicts what IS reused within microseconds -- the spilled registers, the cold matrices, the result rows.  Round 6, same gpurun
+// call: C2 199.8 -> 192.0 ms, 250 k seeds 59.5 -> 57.7, 2e6 seeds of the 200-view scene 369.5 -> 357.1; either direction alone 198-199;
+// the hint on the cold matrices as well: 195-202 (they ARE reused).  The 29-slot build keeps plain accesses (C1 22.5 -> 23.4 ms with the
+// hint, a 125 k-seed shard 34.7 -> 35.3): profiles/r06/park_nontemporal.txt.
+#ifndef HPMVS_PARK_AUX
+#define HPMVS_PARK_AUX 2          /* cache-policy bits of global_load_lds: 2 = nt */
+#endif
+#ifndef HPMVS_PARK_NT_STORE
+#define HPMVS_PARK_NT_STORE 1
+#endif
 #define HPMVS_VARIANT_SUFFIX _big_tree
 #include "kernel_optimize.hip"
